@@ -1,0 +1,152 @@
+/*
+ * pemap_hip.h -- C-ABI of the MI355X (gfx950) PEMapper / PECaller hot path.
+ *
+ * Plain C: opaque handles, plain pointers and sizes, int return codes (0 = ok, non-zero = error; the text is in
+ * pemap_dev_last_error()).  Nothing here depends on torch or on C++ types.  A host program written in C (the
+ * reference's language) links libpemap_hip.so and calls these; pecaller_amd/csrc/pemapper_main.c does exactly that.
+ *
+ * What each entry replaces in the reference (wingolab-org/pecaller, paths under src/):
+ *
+ *   pemap_dev_create / _destroy      the process-wide globals of pemapper.c:140-176 (one object per GPU instead)
+ *   pemap_dev_load_index             init_index_buffer + genome/.sdx load, pemapper.c:411-494, 2129-2155
+ *   pemap_dev_build_index            index_genome_whole.c:93-354 (rolling 16-mer, N resets, len-15 coordinates), on device
+ *   pemap_dev_set_params             argv parsing of max_dist/min_dist/is_bisulfite/min_match, pemapper.c:233-297
+ *   pemap_dev_map_batch              pthread_create(..., map_everything, batch) + the result fold,
+ *                                    pemapper.c:684, 759, 907-1309 (initial_map, find_matches, smith_waterman_align,
+ *                                    find_mate_pairs, smith_waterman_backtrack)
+ *   pemap_dev_stage_reads/_run/_collect   the same call split in three, so that a caller can time the device part
+ *   pemap_dev_fetch_pileup           the final genome walk that feeds the pileup / indel writers, pemapper.c:819-866
+ *   pemap_dev_summary                total_reads/total_bases/total_dist/no_dists/mate_counts, pemapper.c:144-149, 1238-1265
+ *   pecall_dev_*                     fill_sample_like and its callers, pecaller.c:2448-2507 (see below)
+ *
+ * Threading: calls on different pemap_dev objects may run concurrently from different host threads; calls on one
+ * object must be serialised by the caller (the reference serialises a batch behind its own mutex, pemapper.c:661).
+ * Ownership: the caller owns every host buffer and may reuse it as soon as a call returns; the object owns all
+ * device memory.
+ */
+#ifndef PEMAP_HIP_H
+#define PEMAP_HIP_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PEMAP_MAX_HITS   200    /* max_hits, pemapper.c:162 */
+#define PEMAP_MIN_READ   16     /* one full 16-mer segment (pemapper.c:1573-1587 reads garbage below this) */
+#define PEMAP_MAX_READ   278    /* L + 21 window rows must fit the reference's 300 x 300 matrices (pemapper.c:155, 932-956) */
+
+/* mapping_type values, pemapper.c:37-45 */
+enum
+{
+  PEMAP_UNIQUE_MATE = 0, PEMAP_UNIQUE_SLIP = 1, PEMAP_UNIQUE_SINGLE = 2, PEMAP_UNIQUE_MIS = 3, PEMAP_NON_MATE = 4,
+  PEMAP_NON_MIS = 5, PEMAP_FRAG_MIS = 6, PEMAP_NON_NO = 7, PEMAP_NEITHER_MAP = 8
+};
+
+typedef struct pemap_dev pemap_dev;
+
+/* insertion callback for pemap_dev_fetch_pileup: pos = 0-based index into .seq, seq = inserted bases in read order */
+typedef void (*pemap_ins_cb) (void *user, uint32_t pos, const char *seq, int len);
+
+const char *pemap_dev_last_error (const pemap_dev * dev);       /* dev may be NULL: error of the last failed create */
+
+int pemap_dev_create (pemap_dev ** out, int device_id);
+void pemap_dev_destroy (pemap_dev * dev);
+
+/* Index from the reference's on-disk arrays already in host memory.  pos_index has 2^32 + 1 entries (.idx inflated),
+ * mers has n_mers entries (.mdx), genome is the upper-cased .seq stream, contig_starts has n_contigs + 1 entries:
+ * prefix sums of the .sdx "len-15" column (pemapper.c:434-448).  idepth is the last .sdx line (16). */
+int pemap_dev_load_index (pemap_dev * dev, const uint32_t * pos_index, const uint32_t * mers, uint64_t n_mers,
+                          const char *genome, uint64_t genome_size, const uint32_t * contig_starts, int n_contigs,
+                          int idepth);
+
+/* Index built on the device from the concatenated genome letters (what .seq holds) and the contig lengths
+ * (full lengths, not len-15).  Produces exactly the arrays the reference builder writes.  bisulfite = the builder's
+ * "bisulfite converted" answer (C indexed as T, index_genome_whole.c:174-177). */
+int pemap_dev_build_index (pemap_dev * dev, const char *genome, uint64_t genome_size, const uint32_t * contig_len,
+                           int n_contigs, int bisulfite);
+
+/* Same, from letters already in device memory (d_genome is a device pointer; the object takes a copy). */
+int pemap_dev_build_index_resident (pemap_dev * dev, const void *d_genome, uint64_t genome_size,
+                                    const uint32_t * contig_len, int n_contigs, int bisulfite);
+
+/* Multi-GPU replica set-up: allocate empty index arrays of the given sizes so that a collective (RCCL broadcast
+ * from the rank that loaded or built the index) can fill them, then pemap_dev_index_commit(). */
+int pemap_dev_index_alloc (pemap_dev * dev, uint64_t n_mers, uint64_t genome_size, int n_contigs, int idepth);
+int pemap_dev_index_commit (pemap_dev * dev);
+
+/* Device pointers and sizes of the resident arrays: which = 0 pos_index (u32[2^32+1]), 1 mers (u32[n_mers]),
+ * 2 genome (u8[genome_size]), 3 contig_starts (u32[n_contigs+1]), 4 pileup counters (u32[genome_size][6]).
+ * For collectives (broadcast of 0..3 at start-up, sum of 4 at the end) and for copying the index back to the host. */
+int pemap_dev_buffer (pemap_dev * dev, int which, void **d_ptr, uint64_t * n_bytes);
+int pemap_dev_index_info (pemap_dev * dev, uint64_t * n_mers, uint64_t * genome_size, int *n_contigs, int *idepth);
+/* copy one of the buffers above (or a byte range of it) to host memory */
+int pemap_dev_read_buffer (pemap_dev * dev, int which, uint64_t byte_offset, void *host_dst, uint64_t n_bytes);
+
+int pemap_dev_set_params (pemap_dev * dev, int paired, int min_dist, int max_dist, double min_align, int bisulfite);
+
+/* One batch.  reads are `stride`-spaced byte rows (not necessarily NUL terminated), len1/len2 their lengths,
+ * PEMAP_MIN_READ <= len <= PEMAP_MAX_READ, reads2/len2/m2 NULL in single-end mode.  m1/m2 receive
+ * 0 (unmapped) or the reference's coordinate (0-based index of the last aligned reference base, + 2),
+ * mapping_type the class.  The pileup and the summary counters accumulate on the object. */
+int pemap_dev_map_batch (pemap_dev * dev, const char *reads1, const int *len1, const char *reads2, const int *len2,
+                         int n, int stride, uint32_t * m1, uint32_t * m2, int *mapping_type);
+
+/* The same in three steps.  stage: host -> device copy of a batch; run: the kernels (asynchronous on the object's
+ * stream unless sync != 0); collect: device -> host copy of the results + summary fold.  After stage, run may be
+ * called repeatedly (each run maps the staged batch again and adds to the pileup): that is what bench.py times. */
+int pemap_dev_stage_reads (pemap_dev * dev, const char *reads1, const int *len1, const char *reads2, const int *len2,
+                           int n, int stride);
+int pemap_dev_run (pemap_dev * dev, int sync);
+int pemap_dev_collect (pemap_dev * dev, uint32_t * m1, uint32_t * m2, int *mapping_type);
+int pemap_dev_sync (pemap_dev * dev);
+
+/* Synthetic workload, generated on the device (bench and scale tests): a seeded genome of
+ * n_contigs contigs (repeat families, N runs at contig ends), and a staged batch of n read pairs of length read_len
+ * sampled from the resident genome with substitutions/indels.  synth_genome fills contig_len[n_contigs]. */
+int pemap_dev_synth_genome (pemap_dev * dev, uint64_t seed, uint64_t genome_size, int n_contigs, double repeat_frac,
+                            void **d_genome, uint32_t * contig_len);
+int pemap_dev_synth_reads (pemap_dev * dev, uint64_t seed, int n, int read_len, int paired, double sub_rate,
+                           double indel_rate, uint64_t first_read);
+/* copy the staged batch back (for the CPU baseline): reads as stride-spaced rows */
+int pemap_dev_staged_reads (pemap_dev * dev, char *reads1, int *len1, char *reads2, int *len2, int stride);
+
+/* counts[genome_size][6] u16 (A,C,G,T,Del,Ins), wrapping as the reference's unsigned short counters do
+ * (pemapper.c:53-58); cb (may be NULL) is called once per logged insertion, in unspecified order. */
+int pemap_dev_fetch_pileup (pemap_dev * dev, uint16_t * counts, pemap_ins_cb cb, void *user);
+/* compacted 16-byte records {u32 pos; u16 A,C,G,T,Del,Ins} of the non-zero sites in [first, first+count), ascending;
+ * returns the number of records through n_records (out may be NULL to count only). */
+int pemap_dev_fetch_records (pemap_dev * dev, uint64_t first, uint64_t count, void *out, uint64_t out_capacity,
+                             uint64_t * n_records);
+int pemap_dev_reset_pileup (pemap_dev * dev);
+
+/* out13: total_reads, total_bases, total_dist, no_dists, mate_counts[0..8] */
+int pemap_dev_summary (pemap_dev * dev, long *out13);
+
+/* Counters the reference does not have: per run of the staged batch --
+ * stats[0] = read-ends, [1] = positions gathered from .mdx (P), [2] = SW score problems (H), [3] = SW trace problems,
+ * [4] = DP cells scored, [5] = DP cells traced, [6] = pileup increments, [7] = insertions logged.
+ * times_ms[0..3] = seed, score, select, trace kernel durations of the last run (HIP events on the object's stream). */
+int pemap_dev_run_stats (pemap_dev * dev, uint64_t * stats8, float *times_ms4);
+
+/* Debug/parity taps: per read-end hit lists and per-hit SW results of the last run.
+ * n_hits[n_ends]; the other arrays are [n_ends][PEMAP_MAX_HITS]. Any pointer may be NULL. end = 2*pair + mate in paired mode. */
+int pemap_dev_debug_hits (pemap_dev * dev, int *n_hits, uint32_t * spot, uint8_t * orient, uint32_t * win_start,
+                          int *win_len, double *score, int *start_k, int *start_i);
+
+/* ---- PECaller: per-site Dirichlet-multinomial genotype log-likelihood, fill_sample_like (pecaller.c:2448-2507) ---- */
+typedef struct pecall_dev pecall_dev;
+int pecall_dev_create (pecall_dev ** out, int device_id);
+void pecall_dev_destroy (pecall_dev * dev);
+const char *pecall_dev_last_error (const pecall_dev * dev);
+/* reads[n_sites][indiv][6] u16; coef[n_sites][indiv] = the multinomial coefficient term computed by the caller as
+ * pecaller.c:1230-1260 does; alpha_mean[n_sites][14][6]; norm = the pass's normal_factor scale.
+ * like[n_sites][indiv][14] receives the log-likelihoods (0 for samples the reference skips, tot <= 2). */
+int pecall_dev_site_like (pecall_dev * dev, const uint16_t * reads, const double *coef, const double *alpha_mean,
+                          int n_sites, int indiv, double norm, double *like);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
