@@ -99,6 +99,8 @@ int pemap_dev_map_batch (pemap_dev * dev, const char *reads1, const int *len1, c
 int pemap_dev_stage_reads (pemap_dev * dev, const char *reads1, const int *len1, const char *reads2, const int *len2,
                            int n, int stride);
 int pemap_dev_run (pemap_dev * dev, int sync);
+/* map only rows [first, first + n) of the staged reads (one bench "step" = one slice of a resident read set) */
+int pemap_dev_run_slice (pemap_dev * dev, int first, int n, int sync);
 int pemap_dev_collect (pemap_dev * dev, uint32_t * m1, uint32_t * m2, int *mapping_type);
 int pemap_dev_sync (pemap_dev * dev);
 
@@ -111,6 +113,9 @@ int pemap_dev_synth_reads (pemap_dev * dev, uint64_t seed, int n, int read_len, 
                            double indel_rate, uint64_t first_read);
 /* copy the staged batch back (for the CPU baseline): reads as stride-spaced rows */
 int pemap_dev_staged_reads (pemap_dev * dev, char *reads1, int *len1, char *reads2, int *len2, int stride);
+int pemap_dev_staged_info (pemap_dev * dev, int *n, int *stride, int *paired);
+/* release a device allocation handed out by pemap_dev_synth_genome */
+int pemap_dev_free (pemap_dev * dev, void *d_ptr);
 
 /* counts[genome_size][6] u16 (A,C,G,T,Del,Ins), wrapping as the reference's unsigned short counters do
  * (pemapper.c:53-58); cb (may be NULL) is called once per logged insertion, in unspecified order. */
@@ -135,16 +140,26 @@ int pemap_dev_run_stats (pemap_dev * dev, uint64_t * stats8, float *times_ms4);
 int pemap_dev_debug_hits (pemap_dev * dev, int *n_hits, uint32_t * spot, uint8_t * orient, uint32_t * win_start,
                           int *win_len, double *score, int *start_k, int *start_i);
 
-/* ---- PECaller: per-site Dirichlet-multinomial genotype log-likelihood, fill_sample_like (pecaller.c:2448-2507) ---- */
+/* ---- PECaller: per-(site, sample) Dirichlet-multinomial genotype log-likelihood ----
+ * fill_sample_like (pecaller.c:2448-2507) together with the per-sample set-up it depends on (pecaller.c:1230-1260:
+ * tot = A+C+G+T+Del, coef = ln tot! - sum ln reads[i]! over all six counts).
+ *   reads[n_sites][indiv][6] u16        one pileup column per sample, the 6 counters of the pileup record
+ *   alpha_mean[n_sites][14][6] f64      d_alpha_mean of the pass (pecaller.c:1354-1364)
+ *   max_gen / min_depth                 14 / 2 diploid, as set at pecaller.c:326-336 for haploid
+ *   norm                                new_norm[pass] (pecaller.c:1339-1344)
+ *   like[n_sites][indiv][14]            log-likelihoods (0 where the reference skips the sample: tot <= min_depth)
+ *   best[n_sites][indiv]  (may be NULL) initial_call, 14 where skipped;  margin (may be NULL) initial_p
+ * The confidence ordering (qsort at 2506) and the configuration search stay on the host. */
 typedef struct pecall_dev pecall_dev;
 int pecall_dev_create (pecall_dev ** out, int device_id);
 void pecall_dev_destroy (pecall_dev * dev);
 const char *pecall_dev_last_error (const pecall_dev * dev);
-/* reads[n_sites][indiv][6] u16; coef[n_sites][indiv] = the multinomial coefficient term computed by the caller as
- * pecaller.c:1230-1260 does; alpha_mean[n_sites][14][6]; norm = the pass's normal_factor scale.
- * like[n_sites][indiv][14] receives the log-likelihoods (0 for samples the reference skips, tot <= 2). */
-int pecall_dev_site_like (pecall_dev * dev, const uint16_t * reads, const double *coef, const double *alpha_mean,
-                          int n_sites, int indiv, double norm, double *like);
+int pecall_dev_site_like (pecall_dev * dev, const uint16_t * reads, const double *alpha_mean, int n_sites, int indiv,
+                          int max_gen, int min_depth, double norm, double *like, int8_t * best, double *margin);
+/* the same call in three steps (host->device, kernel, device->host), so that the kernel can be timed on resident data */
+int pecall_dev_stage (pecall_dev * dev, const uint16_t * reads, const double *alpha_mean, int n_sites, int indiv);
+int pecall_dev_run (pecall_dev * dev, int n_sites, int indiv, int max_gen, int min_depth, double norm, int sync);
+int pecall_dev_collect (pecall_dev * dev, int n_sites, int indiv, double *like, int8_t * best, double *margin);
 
 #ifdef __cplusplus
 }

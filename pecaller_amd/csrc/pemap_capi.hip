@@ -1,0 +1,988 @@
+// pemap_capi.hip -- the C-ABI of include/pemap_hip.h on top of the gfx950 kernels.
+//
+// Built as libpemap_hip.so:  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared ...
+// There is no CPU fallback in this library: every entry either runs on the GPU or returns an error.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdarg.h>
+#include <cstring>
+#include <vector>
+#include "../../include/pemap_hip.h"
+#include "pemap_kernels.hip.h"
+#include "pemap_aux.hip.h"
+#include <rocprim/rocprim.hpp>
+
+static char g_create_err[512] = "";
+
+struct pemap_dev
+{
+  int device;
+  hipStream_t stream;
+  char err[512];
+  // index
+  uint32_t *d_pos_index, *d_mers;
+  uint8_t *d_genome;
+  uint32_t *d_contig_starts;
+  uint64_t n_mers, gsize;
+  int n_contigs, idepth;
+  bool index_ready;
+  uint32_t *d_counts;           // [gsize][6]
+  // params
+  int paired, min_dist, max_dist, bisulfite;
+  double min_align;
+  // staged reads (capacity cap_reads rows each)
+  uint8_t *d_reads1, *d_reads2;
+  int *d_len1, *d_len2;
+  int cap_reads, n_staged, stride, staged_paired, max_len_staged, min_len_staged;
+  std::vector < int >h_len1, h_len2;
+  // per-run work arrays (capacity cap_ends read-ends)
+  int cap_ends;
+  PmHits hits;
+  uint32_t *d_tasks, *d_trace;
+  uint32_t *d_m1, *d_m2;
+  int *d_mtype;
+  int cap_out;
+  PmCounters *d_ctr;
+  uint32_t *d_seed_scratch;
+  uint32_t *d_dirbuf;
+  uint8_t *d_ins_log;
+  unsigned ins_cap;
+  int seed_grid, sw_grid;
+  // run bookkeeping
+  int run_first, run_n;
+  hipEvent_t ev[5];
+  PmCounters last_ctr;
+  float last_ms[4];
+  std::vector < uint8_t > h_ins;        // host copy of all insertion-log bytes so far
+  long summary[13];
+};
+
+static int fail (pemap_dev * d, const char *fmt, ...)
+{
+  va_list ap;
+  va_start (ap, fmt);
+  vsnprintf (d ? d->err : g_create_err, 512, fmt, ap);
+  va_end (ap);
+  return 1;
+}
+
+#define HIPCHK(d, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail (d, "%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString (e_)); } while (0)
+
+template < class T > static int dev_alloc (pemap_dev * d, T ** p, size_t n)
+{
+  *p = nullptr;
+  if (n == 0)
+    n = 1;
+  HIPCHK (d, hipMalloc ((void **) p, n * sizeof (T)));
+  return 0;
+}
+
+#define TRY(x) do { int r_ = (x); if (r_) return r_; } while (0)
+
+extern "C" const char *pemap_dev_last_error (const pemap_dev * dev)
+{
+  return dev ? dev->err : g_create_err;
+}
+
+extern "C" int pemap_dev_create (pemap_dev ** out, int device_id)
+{
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount (&n) != hipSuccess || n <= 0)
+    return fail (nullptr, "no HIP device visible: this library has no CPU path");
+  if (device_id < 0 || device_id >= n)
+    return fail (nullptr, "device %d out of range (0..%d)", device_id, n - 1);
+  pemap_dev *d = new pemap_dev ();
+  memset (d->err, 0, sizeof (d->err));
+  d->device = device_id;
+  d->d_pos_index = d->d_mers = nullptr;
+  d->d_genome = nullptr;
+  d->d_contig_starts = nullptr;
+  d->d_counts = nullptr;
+  d->n_mers = d->gsize = 0;
+  d->n_contigs = 0;
+  d->idepth = 16;
+  d->index_ready = false;
+  d->paired = 1;
+  d->min_dist = 0;
+  d->max_dist = 500;
+  d->bisulfite = 0;
+  d->min_align = 0.9;           // MIN_ALIGN default, pemapper.c:151
+  d->d_reads1 = d->d_reads2 = nullptr;
+  d->d_len1 = d->d_len2 = nullptr;
+  d->cap_reads = d->n_staged = d->stride = 0;
+  d->staged_paired = 0;
+  d->cap_ends = 0;
+  memset (&d->hits, 0, sizeof (d->hits));
+  d->d_tasks = d->d_trace = d->d_m1 = d->d_m2 = nullptr;
+  d->d_mtype = nullptr;
+  d->cap_out = 0;
+  d->d_ctr = nullptr;
+  d->d_seed_scratch = nullptr;
+  d->d_dirbuf = nullptr;
+  d->d_ins_log = nullptr;
+  d->ins_cap = 0;
+  d->run_first = d->run_n = 0;
+  memset (&d->last_ctr, 0, sizeof (d->last_ctr));
+  memset (d->last_ms, 0, sizeof (d->last_ms));
+  memset (d->summary, 0, sizeof (d->summary));
+  if (hipSetDevice (device_id) != hipSuccess)
+    {
+      delete d;
+      return fail (nullptr, "hipSetDevice(%d) failed", device_id);
+    }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties (&prop, device_id) != hipSuccess)
+    {
+      delete d;
+      return fail (nullptr, "hipGetDeviceProperties failed");
+    }
+  if (strncmp (prop.gcnArchName, "gfx950", 6) != 0)
+    {
+      fail (nullptr, "device %d is %s: this library is built for gfx950 (MI355X) only", device_id, prop.gcnArchName);
+      delete d;
+      return 1;
+    }
+  int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  d->seed_grid = cus * 8;
+  d->sw_grid = cus * 8;
+  if (hipStreamCreateWithFlags (&d->stream, hipStreamNonBlocking) != hipSuccess)
+    {
+      delete d;
+      return fail (nullptr, "hipStreamCreate failed");
+    }
+  for (int i = 0; i < 5; i++)
+    hipEventCreate (&d->ev[i]);
+  if (hipMalloc ((void **) &d->d_ctr, sizeof (PmCounters)) != hipSuccess)
+    {
+      delete d;
+      return fail (nullptr, "hipMalloc failed");
+    }
+  hipMemset (d->d_ctr, 0, sizeof (PmCounters));
+  *out = d;
+  return 0;
+}
+
+static void free_index (pemap_dev * d)
+{
+  hipFree (d->d_pos_index);
+  hipFree (d->d_mers);
+  hipFree (d->d_genome);
+  hipFree (d->d_contig_starts);
+  hipFree (d->d_counts);
+  d->d_pos_index = d->d_mers = nullptr;
+  d->d_genome = nullptr;
+  d->d_contig_starts = nullptr;
+  d->d_counts = nullptr;
+  d->index_ready = false;
+}
+
+static void free_work (pemap_dev * d)
+{
+  hipFree (d->hits.n_hits);
+  hipFree (d->hits.spot);
+  hipFree (d->hits.gpos);
+  hipFree (d->hits.nn);
+  hipFree (d->hits.orient);
+  hipFree (d->hits.score);
+  hipFree (d->hits.sti);
+  hipFree (d->hits.stk);
+  memset (&d->hits, 0, sizeof (d->hits));
+  hipFree (d->d_tasks);
+  hipFree (d->d_trace);
+  d->d_tasks = d->d_trace = nullptr;
+  d->cap_ends = 0;
+}
+
+extern "C" void pemap_dev_destroy (pemap_dev * d)
+{
+  if (!d)
+    return;
+  hipSetDevice (d->device);
+  hipStreamSynchronize (d->stream);
+  free_index (d);
+  free_work (d);
+  hipFree (d->d_reads1);
+  hipFree (d->d_reads2);
+  hipFree (d->d_len1);
+  hipFree (d->d_len2);
+  hipFree (d->d_m1);
+  hipFree (d->d_m2);
+  hipFree (d->d_mtype);
+  hipFree (d->d_ctr);
+  hipFree (d->d_seed_scratch);
+  hipFree (d->d_dirbuf);
+  hipFree (d->d_ins_log);
+  for (int i = 0; i < 5; i++)
+    hipEventDestroy (d->ev[i]);
+  hipStreamDestroy (d->stream);
+  delete d;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+static const uint64_t POS_INDEX_N = (1ull << 32) + 1ull;
+static int drain_ins (pemap_dev * d);
+
+extern "C" int pemap_dev_index_alloc (pemap_dev * d, uint64_t n_mers, uint64_t genome_size, int n_contigs, int idepth)
+{
+  HIPCHK (d, hipSetDevice (d->device));
+  if (genome_size == 0 || genome_size >= (1ull << 32) - 400 || n_contigs < 1)
+    return fail (d, "index_alloc: genome_size %llu / n_contigs %d not supported (positions are u32)",
+                 (unsigned long long) genome_size, n_contigs);
+  if (idepth != 16)
+    return fail (d, "index_alloc: idepth %d: the .idx table is addressed by 16-mers (index_genome_whole.c:149)", idepth);
+  free_index (d);
+  d->n_mers = n_mers;
+  d->gsize = genome_size;
+  d->n_contigs = n_contigs;
+  d->idepth = idepth;
+  TRY (dev_alloc (d, &d->d_pos_index, POS_INDEX_N));
+  TRY (dev_alloc (d, &d->d_mers, n_mers + 128));
+  TRY (dev_alloc (d, &d->d_genome, genome_size + 512));
+  TRY (dev_alloc (d, &d->d_contig_starts, (size_t) n_contigs + 2));
+  TRY (dev_alloc (d, &d->d_counts, genome_size * 6 + 6));
+  HIPCHK (d, hipMemset (d->d_genome + genome_size, 0, 512));
+  HIPCHK (d, hipMemset (d->d_counts, 0, (genome_size * 6 + 6) * sizeof (uint32_t)));
+  return 0;
+}
+
+extern "C" int pemap_dev_index_commit (pemap_dev * d)
+{
+  if (!d->d_pos_index)
+    return fail (d, "index_commit: no index arrays allocated");
+  HIPCHK (d, hipSetDevice (d->device));
+  HIPCHK (d, hipDeviceSynchronize ());
+  d->index_ready = true;
+  return 0;
+}
+
+extern "C" int pemap_dev_load_index (pemap_dev * d, const uint32_t * pos_index, const uint32_t * mers, uint64_t n_mers,
+                                     const char *genome, uint64_t genome_size, const uint32_t * contig_starts, int n_contigs,
+                                     int idepth)
+{
+  TRY (pemap_dev_index_alloc (d, n_mers, genome_size, n_contigs, idepth));
+  HIPCHK (d, hipMemcpy (d->d_pos_index, pos_index, POS_INDEX_N * sizeof (uint32_t), hipMemcpyHostToDevice));
+  HIPCHK (d, hipMemcpy (d->d_mers, mers, n_mers * sizeof (uint32_t), hipMemcpyHostToDevice));
+  HIPCHK (d, hipMemcpy (d->d_genome, genome, genome_size, hipMemcpyHostToDevice));
+  HIPCHK (d, hipMemcpy (d->d_contig_starts, contig_starts, ((size_t) n_contigs + 1) * sizeof (uint32_t), hipMemcpyHostToDevice));
+  return pemap_dev_index_commit (d);
+}
+
+static int build_from_device_genome (pemap_dev * d, const uint32_t * contig_len, int n_contigs, int bisulfite)
+{
+  const uint64_t gsize = d->gsize;
+  std::vector < uint64_t > real_starts (n_contigs + 1);
+  std::vector < uint32_t > cstarts (n_contigs + 1);
+  real_starts[0] = 0;
+  cstarts[0] = 0;
+  for (int c = 0; c < n_contigs; c++)
+    {
+      if (contig_len[c] < 16)
+        return fail (d, "build_index: contig %d has %u letters; fewer than 16 is not indexable", c, contig_len[c]);
+      real_starts[c + 1] = real_starts[c] + contig_len[c];
+      cstarts[c + 1] = cstarts[c] + (contig_len[c] - 15);       // index_genome_whole.c:213, 316, 349
+    }
+  if (real_starts[n_contigs] != gsize)
+    return fail (d, "build_index: contig lengths sum to %llu, genome has %llu letters", (unsigned long long) real_starts[n_contigs],
+                 (unsigned long long) gsize);
+  HIPCHK (d, hipMemcpy (d->d_contig_starts, cstarts.data (), (n_contigs + 1) * sizeof (uint32_t), hipMemcpyHostToDevice));
+  uint64_t *d_real = nullptr;
+  TRY (dev_alloc (d, &d_real, (size_t) n_contigs + 1));
+  HIPCHK (d, hipMemcpy (d_real, real_starts.data (), (n_contigs + 1) * sizeof (uint64_t), hipMemcpyHostToDevice));
+  const uint64_t n_tiles = (gsize + IX_PER_BLOCK - 1) / IX_PER_BLOCK;
+  uint32_t *d_tc = nullptr;
+  uint64_t *d_to = nullptr, *d_total = nullptr;
+  TRY (dev_alloc (d, &d_tc, n_tiles));
+  TRY (dev_alloc (d, &d_to, n_tiles));
+  TRY (dev_alloc (d, &d_total, 1));
+  hipLaunchKernelGGL (ix_count_kernel, dim3 ((unsigned) n_tiles), dim3 (IX_BLOCK), 0, d->stream, d->d_genome, d_real, n_contigs, gsize,
+                      bisulfite, d_tc);
+  hipLaunchKernelGGL (ix_scan_tiles_kernel, dim3 (1), dim3 (1024), 0, d->stream, d_tc, d_to, n_tiles, d_total);
+  uint64_t n_mers = 0;
+  HIPCHK (d, hipMemcpyAsync (&n_mers, d_total, sizeof (uint64_t), hipMemcpyDeviceToHost, d->stream));
+  HIPCHK (d, hipStreamSynchronize (d->stream));
+  if (n_mers == 0)
+    return fail (d, "build_index: the genome has no 16-mer free of N");
+  uint32_t *d_keys = nullptr, *d_vals = nullptr, *d_keys2 = nullptr;
+  TRY (dev_alloc (d, &d_keys, n_mers));
+  TRY (dev_alloc (d, &d_vals, n_mers));
+  TRY (dev_alloc (d, &d_keys2, n_mers));
+  hipFree (d->d_mers);
+  d->d_mers = nullptr;
+  TRY (dev_alloc (d, &d->d_mers, n_mers + 128));
+  d->n_mers = n_mers;
+  hipLaunchKernelGGL (ix_emit_kernel, dim3 ((unsigned) n_tiles), dim3 (IX_BLOCK), 0, d->stream, d->d_genome, d_real, n_contigs, gsize,
+                      bisulfite, d_to, d_keys, d_vals);
+  // stable LSD radix sort by k-mer: equal k-mers keep genome order, which is the .mdx order
+  size_t tmp_bytes = 0;
+  HIPCHK (d, rocprim::radix_sort_pairs (nullptr, tmp_bytes, d_keys, d_keys2, d_vals, d->d_mers, (size_t) n_mers, 0, 32, d->stream));
+  void *d_tmp = nullptr;
+  HIPCHK (d, hipMalloc (&d_tmp, tmp_bytes ? tmp_bytes : 1));
+  HIPCHK (d, rocprim::radix_sort_pairs (d_tmp, tmp_bytes, d_keys, d_keys2, d_vals, d->d_mers, (size_t) n_mers, 0, 32, d->stream));
+  // prefix table: bucket ends scattered, then a running maximum over 2^32 + 1 entries
+  HIPCHK (d, hipMemsetAsync (d->d_pos_index, 0, POS_INDEX_N * sizeof (uint32_t), d->stream));
+  hipLaunchKernelGGL (ix_run_ends_kernel, dim3 ((unsigned) ((n_mers + 255) / 256)), dim3 (256), 0, d->stream, d_keys2, n_mers,
+                      d->d_pos_index);
+  const uint64_t sc_tiles = (POS_INDEX_N + SC_TILE - 1) / SC_TILE;
+  uint32_t *d_tmax = nullptr;
+  TRY (dev_alloc (d, &d_tmax, sc_tiles));
+  hipLaunchKernelGGL (ix_maxscan_reduce_kernel, dim3 ((unsigned) sc_tiles), dim3 (SC_BLOCK), 0, d->stream, d->d_pos_index, POS_INDEX_N, d_tmax);
+  hipLaunchKernelGGL (ix_maxscan_tiles_kernel, dim3 (1), dim3 (1024), 0, d->stream, d_tmax, sc_tiles);
+  hipLaunchKernelGGL (ix_maxscan_apply_kernel, dim3 ((unsigned) sc_tiles), dim3 (SC_BLOCK), 0, d->stream, d->d_pos_index, POS_INDEX_N, d_tmax);
+  HIPCHK (d, hipStreamSynchronize (d->stream));
+  HIPCHK (d, hipGetLastError ());
+  hipFree (d_tmp);
+  hipFree (d_tmax);
+  hipFree (d_keys);
+  hipFree (d_keys2);
+  hipFree (d_vals);
+  hipFree (d_tc);
+  hipFree (d_to);
+  hipFree (d_total);
+  hipFree (d_real);
+  return pemap_dev_index_commit (d);
+}
+
+extern "C" int pemap_dev_build_index (pemap_dev * d, const char *genome, uint64_t genome_size, const uint32_t * contig_len,
+                                      int n_contigs, int bisulfite)
+{
+  TRY (pemap_dev_index_alloc (d, 0, genome_size, n_contigs, 16));
+  HIPCHK (d, hipMemcpy (d->d_genome, genome, genome_size, hipMemcpyHostToDevice));
+  return build_from_device_genome (d, contig_len, n_contigs, bisulfite);
+}
+
+extern "C" int pemap_dev_build_index_resident (pemap_dev * d, const void *d_genome, uint64_t genome_size,
+                                               const uint32_t * contig_len, int n_contigs, int bisulfite)
+{
+  TRY (pemap_dev_index_alloc (d, 0, genome_size, n_contigs, 16));
+  HIPCHK (d, hipMemcpy (d->d_genome, d_genome, genome_size, hipMemcpyDeviceToDevice));
+  return build_from_device_genome (d, contig_len, n_contigs, bisulfite);
+}
+
+extern "C" int pemap_dev_buffer (pemap_dev * d, int which, void **d_ptr, uint64_t * n_bytes)
+{
+  if (!d->d_pos_index)
+    return fail (d, "buffer: no index");
+  switch (which)
+    {
+    case 0: *d_ptr = d->d_pos_index; *n_bytes = POS_INDEX_N * 4; break;
+    case 1: *d_ptr = d->d_mers; *n_bytes = d->n_mers * 4; break;
+    case 2: *d_ptr = d->d_genome; *n_bytes = d->gsize; break;
+    case 3: *d_ptr = d->d_contig_starts; *n_bytes = ((uint64_t) d->n_contigs + 1) * 4; break;
+    case 4: *d_ptr = d->d_counts; *n_bytes = d->gsize * 6 * 4; break;
+    default: return fail (d, "buffer: which = %d", which);
+    }
+  return 0;
+}
+
+extern "C" int pemap_dev_index_info (pemap_dev * d, uint64_t * n_mers, uint64_t * genome_size, int *n_contigs, int *idepth)
+{
+  if (!d->index_ready)
+    return fail (d, "index_info: no index");
+  *n_mers = d->n_mers;
+  *genome_size = d->gsize;
+  *n_contigs = d->n_contigs;
+  *idepth = d->idepth;
+  return 0;
+}
+
+extern "C" int pemap_dev_read_buffer (pemap_dev * d, int which, uint64_t byte_offset, void *host_dst, uint64_t n_bytes)
+{
+  void *p;
+  uint64_t nb;
+  TRY (pemap_dev_buffer (d, which, &p, &nb));
+  if (byte_offset + n_bytes > nb)
+    return fail (d, "read_buffer: range beyond buffer %d (%llu bytes)", which, (unsigned long long) nb);
+  HIPCHK (d, hipSetDevice (d->device));
+  HIPCHK (d, hipStreamSynchronize (d->stream));
+  HIPCHK (d, hipMemcpy (host_dst, (const char *) p + byte_offset, n_bytes, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+extern "C" int pemap_dev_set_params (pemap_dev * d, int paired, int min_dist, int max_dist, double min_align, int bisulfite)
+{
+  d->paired = paired ? 1 : 0;
+  d->min_dist = min_dist;
+  d->max_dist = max_dist;
+  d->min_align = min_align;
+  d->bisulfite = bisulfite ? 1 : 0;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+static int ensure_reads (pemap_dev * d, int n, int stride, int paired)
+{
+  if (n > d->cap_reads || stride != d->stride || (paired && !d->d_reads2))
+    {
+      hipFree (d->d_reads1);
+      hipFree (d->d_reads2);
+      hipFree (d->d_len1);
+      hipFree (d->d_len2);
+      d->d_reads1 = d->d_reads2 = nullptr;
+      d->d_len1 = d->d_len2 = nullptr;
+      int cap = n > d->cap_reads ? n : d->cap_reads;
+      TRY (dev_alloc (d, &d->d_reads1, (size_t) cap * stride + 64));
+      TRY (dev_alloc (d, &d->d_len1, (size_t) cap));
+      TRY (dev_alloc (d, &d->d_reads2, (size_t) cap * stride + 64));
+      TRY (dev_alloc (d, &d->d_len2, (size_t) cap));
+      d->cap_reads = cap;
+      d->stride = stride;
+    }
+  if (n > d->cap_out)
+    {
+      hipFree (d->d_m1);
+      hipFree (d->d_m2);
+      hipFree (d->d_mtype);
+      TRY (dev_alloc (d, &d->d_m1, (size_t) n));
+      TRY (dev_alloc (d, &d->d_m2, (size_t) n));
+      TRY (dev_alloc (d, &d->d_mtype, (size_t) n));
+      d->cap_out = n;
+    }
+  return 0;
+}
+
+static int ensure_work (pemap_dev * d, int n_ends)
+{
+  if (n_ends > d->cap_ends)
+    {
+      free_work (d);
+      size_t nh = (size_t) n_ends * PM_MAX_HITS;
+      TRY (dev_alloc (d, &d->hits.n_hits, (size_t) n_ends));
+      TRY (dev_alloc (d, &d->hits.spot, nh));
+      TRY (dev_alloc (d, &d->hits.gpos, nh));
+      TRY (dev_alloc (d, &d->hits.nn, nh));
+      TRY (dev_alloc (d, &d->hits.orient, nh));
+      TRY (dev_alloc (d, &d->hits.score, nh));
+      TRY (dev_alloc (d, &d->hits.sti, nh));
+      TRY (dev_alloc (d, &d->hits.stk, nh));
+      TRY (dev_alloc (d, &d->d_tasks, nh));
+      TRY (dev_alloc (d, &d->d_trace, (size_t) n_ends));
+      d->cap_ends = n_ends;
+    }
+  if (!d->d_seed_scratch)
+    TRY (dev_alloc (d, &d->d_seed_scratch, (size_t) d->seed_grid * 2 * PM_MAX_SEG * PM_SEG_LIST_MAX));
+  if (!d->d_dirbuf)
+    TRY (dev_alloc (d, &d->d_dirbuf, (size_t) d->sw_grid * PM_TMAX * 64 * 5));
+  // insertion log: one run cannot log more than 5 bytes per read base on average (8-byte header per >= 1 inserted base
+  // after at least one aligned base, padded to 4); 64 bytes per end is ample for real data and overflow is an error
+  size_t want = (size_t) n_ends * 64 + (1u << 20);
+  if (want > 0xF0000000ull)
+    want = 0xF0000000ull;
+  if (want > d->ins_cap)
+    {
+      hipFree (d->d_ins_log);
+      TRY (dev_alloc (d, &d->d_ins_log, want));
+      d->ins_cap = (unsigned) want;
+    }
+  return 0;
+}
+
+static int check_lengths (pemap_dev * d, const int *len, int n, int *mx, int *mn)
+{
+  for (int i = 0; i < n; i++)
+    {
+      if (len[i] < PEMAP_MIN_READ || len[i] > PEMAP_MAX_READ)
+        return fail (d, "read %d has length %d: supported range is %d..%d", i, len[i], PEMAP_MIN_READ, PEMAP_MAX_READ);
+      if (len[i] > *mx)
+        *mx = len[i];
+      if (len[i] < *mn)
+        *mn = len[i];
+    }
+  return 0;
+}
+
+extern "C" int pemap_dev_stage_reads (pemap_dev * d, const char *reads1, const int *len1, const char *reads2, const int *len2,
+                                      int n, int stride)
+{
+  HIPCHK (d, hipSetDevice (d->device));
+  if (n <= 0)
+    return fail (d, "stage_reads: n = %d", n);
+  if (d->paired && (!reads2 || !len2))
+    return fail (d, "stage_reads: paired mode needs reads2/len2");
+  if (stride < PEMAP_MIN_READ)
+    return fail (d, "stage_reads: stride %d", stride);
+  int mx = 0, mn = 1 << 30;
+  TRY (check_lengths (d, len1, n, &mx, &mn));
+  if (d->paired)
+    TRY (check_lengths (d, len2, n, &mx, &mn));
+  if (mx > stride)
+    return fail (d, "stage_reads: a read is longer than the row stride %d", stride);
+  HIPCHK (d, hipStreamSynchronize (d->stream));
+  TRY (ensure_reads (d, n, stride, d->paired));
+  HIPCHK (d, hipMemcpy (d->d_reads1, reads1, (size_t) n * stride, hipMemcpyHostToDevice));
+  HIPCHK (d, hipMemcpy (d->d_len1, len1, (size_t) n * sizeof (int), hipMemcpyHostToDevice));
+  d->h_len1.assign (len1, len1 + n);
+  d->h_len2.clear ();
+  if (d->paired)
+    {
+      HIPCHK (d, hipMemcpy (d->d_reads2, reads2, (size_t) n * stride, hipMemcpyHostToDevice));
+      HIPCHK (d, hipMemcpy (d->d_len2, len2, (size_t) n * sizeof (int), hipMemcpyHostToDevice));
+      d->h_len2.assign (len2, len2 + n);
+    }
+  d->n_staged = n;
+  d->staged_paired = d->paired;
+  d->max_len_staged = mx;
+  d->min_len_staged = mn;
+  return 0;
+}
+
+template < int W > static void launch_sw (pemap_dev * d, const PmIndex & ix, const PmBatch & b, const PmParams & prm)
+{
+  hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_score_kernel < W >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, ix, b, prm, d->hits,
+                      d->d_tasks, d->d_ctr);
+}
+
+template < int W > static void launch_trace (pemap_dev * d, const PmIndex & ix, const PmBatch & b, const PmParams & prm)
+{
+  hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_trace_kernel < W >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, ix, b, prm, d->hits,
+                      d->d_trace, d->d_ctr, d->d_dirbuf, d->d_counts, d->d_ins_log, d->ins_cap);
+}
+
+static int run_slice (pemap_dev * d, int first, int n, int sync)
+{
+  HIPCHK (d, hipSetDevice (d->device));
+  if (!d->index_ready)
+    return fail (d, "run: no index loaded");
+  if (d->n_staged <= 0)
+    return fail (d, "run: no reads staged");
+  if (first < 0 || n <= 0 || first + n > d->n_staged)
+    return fail (d, "run: slice [%d, %d) outside the %d staged reads", first, first + n, d->n_staged);
+  if (d->staged_paired != d->paired)
+    return fail (d, "run: reads were staged in %s mode", d->staged_paired ? "paired" : "single");
+  const int n_ends = d->paired ? 2 * n : n;
+  if ((uint64_t) n_ends * PM_MAX_HITS >= 0xFFFFFFFFull)
+    return fail (d, "run: batch of %d read-ends is too large (limit 21 million)", n_ends);
+  TRY (ensure_work (d, n_ends));
+  PmIndex ix;
+  ix.pos_index = d->d_pos_index;
+  ix.mers = d->d_mers;
+  ix.genome = d->d_genome;
+  ix.contig_starts = d->d_contig_starts;
+  ix.n_mers = d->n_mers;
+  ix.gsize = d->gsize;
+  ix.n_contigs = d->n_contigs;
+  ix.idepth = d->idepth;
+  PmBatch b;
+  b.reads1 = d->d_reads1 + (size_t) first * d->stride;
+  b.reads2 = d->paired ? d->d_reads2 + (size_t) first * d->stride : nullptr;
+  b.len1 = d->d_len1 + first;
+  b.len2 = d->paired ? d->d_len2 + first : nullptr;
+  b.n = n;
+  b.stride = d->stride;
+  b.paired = d->paired;
+  b.n_ends = n_ends;
+  PmParams prm;
+  prm.min_dist = d->min_dist;
+  prm.max_dist = d->max_dist;
+  prm.min_align = d->min_align;
+  prm.bisulfite = d->bisulfite;
+  // the insertion log of the previous run is drained in collect(); a run without collect keeps appending
+  HIPCHK (d, hipMemsetAsync (d->d_ctr, 0, offsetof (PmCounters, ins_bytes), d->stream));
+  HIPCHK (d, hipMemsetAsync (&d->d_ctr->positions, 0, sizeof (PmCounters) - offsetof (PmCounters, positions), d->stream));
+  hipEventRecord (d->ev[0], d->stream);
+  int sgrid = d->seed_grid < n_ends ? d->seed_grid : n_ends;
+  hipLaunchKernelGGL (pm_seed_kernel, dim3 (sgrid), dim3 (64), 0, d->stream, ix, b, prm, d->hits, d->d_tasks, d->d_ctr,
+                      d->d_seed_scratch);
+  hipEventRecord (d->ev[1], d->stream);
+  const int L = d->max_len_staged;
+  if (L <= 8 * 13) launch_sw < 13 > (d, ix, b, prm);
+  else if (L <= 8 * 19) launch_sw < 19 > (d, ix, b, prm);
+  else if (L <= 8 * 26) launch_sw < 26 > (d, ix, b, prm);
+  else if (L <= 8 * 32) launch_sw < 32 > (d, ix, b, prm);
+  else launch_sw < 38 > (d, ix, b, prm);
+  hipEventRecord (d->ev[2], d->stream);
+  hipLaunchKernelGGL (pm_select_kernel, dim3 ((n + 255) / 256), dim3 (256), 0, d->stream, b, prm, d->hits, d->d_trace, d->d_ctr,
+                      d->d_m1 + first, d->paired ? d->d_m2 + first : nullptr, d->d_mtype + first);
+  hipEventRecord (d->ev[3], d->stream);
+  if (L <= 8 * 13) launch_trace < 13 > (d, ix, b, prm);
+  else if (L <= 8 * 19) launch_trace < 19 > (d, ix, b, prm);
+  else if (L <= 8 * 26) launch_trace < 26 > (d, ix, b, prm);
+  else if (L <= 8 * 32) launch_trace < 32 > (d, ix, b, prm);
+  else launch_trace < 38 > (d, ix, b, prm);
+  hipEventRecord (d->ev[4], d->stream);
+  HIPCHK (d, hipGetLastError ());
+  d->run_first = first;
+  d->run_n = n;
+  if (sync)
+    return pemap_dev_sync (d);
+  return 0;
+}
+
+extern "C" int pemap_dev_run (pemap_dev * d, int sync)
+{
+  return run_slice (d, 0, d->n_staged, sync);
+}
+
+extern "C" int pemap_dev_run_slice (pemap_dev * d, int first, int n, int sync)
+{
+  return run_slice (d, first, n, sync);
+}
+
+extern "C" int pemap_dev_sync (pemap_dev * d)
+{
+  HIPCHK (d, hipSetDevice (d->device));
+  HIPCHK (d, hipStreamSynchronize (d->stream));
+  HIPCHK (d, hipMemcpy (&d->last_ctr, d->d_ctr, sizeof (PmCounters), hipMemcpyDeviceToHost));
+  for (int i = 0; i < 4; i++)
+    if (hipEventElapsedTime (&d->last_ms[i], d->ev[i], d->ev[i + 1]) != hipSuccess)
+      d->last_ms[i] = 0.f;
+  if (d->last_ctr.ins_overflow)
+    return fail (d, "insertion log overflow (%u bytes): collect() more often or use smaller slices", d->ins_cap);
+  if (d->last_ctr.ins_bytes > d->ins_cap / 2)
+    return drain_ins (d);
+  return 0;
+}
+
+// drain the device insertion log into the host copy and reset the cursor
+static int drain_ins (pemap_dev * d)
+{
+  unsigned nb = d->last_ctr.ins_bytes;
+  if (nb)
+    {
+      size_t at = d->h_ins.size ();
+      d->h_ins.resize (at + nb);
+      HIPCHK (d, hipMemcpy (d->h_ins.data () + at, d->d_ins_log, nb, hipMemcpyDeviceToHost));
+      HIPCHK (d, hipMemset (&d->d_ctr->ins_bytes, 0, sizeof (unsigned)));
+      d->last_ctr.ins_bytes = 0;
+    }
+  return 0;
+}
+
+extern "C" int pemap_dev_collect (pemap_dev * d, uint32_t * m1, uint32_t * m2, int *mapping_type)
+{
+  TRY (pemap_dev_sync (d));
+  const int n = d->run_n, first = d->run_first;
+  if (n <= 0)
+    return fail (d, "collect: nothing was run");
+  HIPCHK (d, hipMemcpy (m1, d->d_m1 + first, (size_t) n * sizeof (uint32_t), hipMemcpyDeviceToHost));
+  if (d->paired && m2)
+    HIPCHK (d, hipMemcpy (m2, d->d_m2 + first, (size_t) n * sizeof (uint32_t), hipMemcpyDeviceToHost));
+  HIPCHK (d, hipMemcpy (mapping_type, d->d_mtype + first, (size_t) n * sizeof (int), hipMemcpyDeviceToHost));
+  TRY (drain_ins (d));
+  // result fold, pemapper.c:1238-1265
+  long *S = d->summary;
+  for (int j = 0; j < n; j++)
+    {
+      uint32_t a = m1[j], b = (d->paired && m2) ? m2[j] : 0;
+      int la = d->h_len1[first + j], lb = d->paired ? d->h_len2[first + j] : 0;
+      S[4 + mapping_type[j]]++;
+      if (a)
+        {
+          S[0]++;
+          S[1] += la;
+          if (b)
+            {
+              S[0]++;
+              S[1] += lb;
+              long test = (long) (uint32_t) (a - b);    // unsigned difference widened to long, pemapper.c:1250
+              if (test < (long) d->max_dist * 4)
+                {
+                  S[2] += test;
+                  S[3]++;
+                }
+            }
+        }
+      else if (b)
+        {
+          S[0]++;
+          S[1] += lb;
+        }
+    }
+  return 0;
+}
+
+extern "C" int pemap_dev_map_batch (pemap_dev * d, const char *reads1, const int *len1, const char *reads2, const int *len2,
+                                    int n, int stride, uint32_t * m1, uint32_t * m2, int *mapping_type)
+{
+  TRY (pemap_dev_stage_reads (d, reads1, len1, reads2, len2, n, stride));
+  TRY (pemap_dev_run (d, 1));
+  return pemap_dev_collect (d, m1, m2, mapping_type);
+}
+
+extern "C" int pemap_dev_summary (pemap_dev * d, long *out13)
+{
+  memcpy (out13, d->summary, sizeof (d->summary));
+  return 0;
+}
+
+extern "C" int pemap_dev_run_stats (pemap_dev * d, uint64_t * s, float *t)
+{
+  const PmCounters & c = d->last_ctr;
+  if (s)
+    {
+      s[0] = (uint64_t) (d->paired ? 2 * d->run_n : d->run_n);
+      s[1] = c.positions;
+      s[2] = c.n_tasks;
+      s[3] = c.n_trace;
+      s[4] = c.cells_score;
+      s[5] = c.cells_trace;
+      s[6] = c.pile_incs;
+      s[7] = c.n_ins;
+    }
+  if (t)
+    memcpy (t, d->last_ms, sizeof (d->last_ms));
+  return 0;
+}
+
+extern "C" int pemap_dev_debug_hits (pemap_dev * d, int *n_hits, uint32_t * spot, uint8_t * orient, uint32_t * win_start,
+                                     int *win_len, double *score, int *start_k, int *start_i)
+{
+  HIPCHK (d, hipSetDevice (d->device));
+  HIPCHK (d, hipStreamSynchronize (d->stream));
+  const int n_ends = d->paired ? 2 * d->run_n : d->run_n;
+  const size_t nh = (size_t) n_ends * PM_MAX_HITS;
+  if (n_hits)
+    HIPCHK (d, hipMemcpy (n_hits, d->hits.n_hits, (size_t) n_ends * sizeof (int), hipMemcpyDeviceToHost));
+  if (spot)
+    HIPCHK (d, hipMemcpy (spot, d->hits.spot, nh * 4, hipMemcpyDeviceToHost));
+  if (orient)
+    HIPCHK (d, hipMemcpy (orient, d->hits.orient, nh, hipMemcpyDeviceToHost));
+  if (win_start)
+    HIPCHK (d, hipMemcpy (win_start, d->hits.gpos, nh * 4, hipMemcpyDeviceToHost));
+  if (score)
+    HIPCHK (d, hipMemcpy (score, d->hits.score, nh * 8, hipMemcpyDeviceToHost));
+  if (win_len || start_i)
+    {
+      std::vector < int16_t > t (nh);
+      if (win_len)
+        {
+          HIPCHK (d, hipMemcpy (t.data (), d->hits.nn, nh * 2, hipMemcpyDeviceToHost));
+          for (size_t i = 0; i < nh; i++)
+            win_len[i] = t[i];
+        }
+      if (start_i)
+        {
+          HIPCHK (d, hipMemcpy (t.data (), d->hits.sti, nh * 2, hipMemcpyDeviceToHost));
+          for (size_t i = 0; i < nh; i++)
+            start_i[i] = t[i];
+        }
+    }
+  if (start_k)
+    {
+      std::vector < uint8_t > t (nh);
+      HIPCHK (d, hipMemcpy (t.data (), d->hits.stk, nh, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < nh; i++)
+        start_k[i] = t[i];
+    }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+extern "C" int pemap_dev_reset_pileup (pemap_dev * d)
+{
+  HIPCHK (d, hipSetDevice (d->device));
+  if (!d->d_counts)
+    return fail (d, "reset_pileup: no index");
+  HIPCHK (d, hipStreamSynchronize (d->stream));
+  HIPCHK (d, hipMemset (d->d_counts, 0, (d->gsize * 6 + 6) * sizeof (uint32_t)));
+  HIPCHK (d, hipMemset (&d->d_ctr->ins_bytes, 0, sizeof (unsigned)));
+  d->h_ins.clear ();
+  memset (d->summary, 0, sizeof (d->summary));
+  return 0;
+}
+
+extern "C" int pemap_dev_fetch_pileup (pemap_dev * d, uint16_t * counts, pemap_ins_cb cb, void *user)
+{
+  HIPCHK (d, hipSetDevice (d->device));
+  if (!d->d_counts)
+    return fail (d, "fetch_pileup: no index");
+  TRY (pemap_dev_sync (d));
+  TRY (drain_ins (d));
+  if (counts)
+    {
+      const uint64_t n_words = d->gsize * 6;
+      const uint64_t chunk = 1ull << 28;
+      uint16_t *d_tmp = nullptr;
+      TRY (dev_alloc (d, &d_tmp, (size_t) (n_words < chunk ? n_words : chunk)));
+      for (uint64_t o = 0; o < n_words; o += chunk)
+        {
+          uint64_t m = n_words - o < chunk ? n_words - o : chunk;
+          hipLaunchKernelGGL (pile_to_u16_kernel, dim3 ((unsigned) ((m + 255) / 256)), dim3 (256), 0, d->stream, d->d_counts + o, m, d_tmp);
+          HIPCHK (d, hipStreamSynchronize (d->stream));
+          HIPCHK (d, hipMemcpy (counts + o, d_tmp, m * sizeof (uint16_t), hipMemcpyDeviceToHost));
+        }
+      hipFree (d_tmp);
+    }
+  if (cb)
+    {
+      size_t at = 0;
+      const std::vector < uint8_t > &L = d->h_ins;
+      char buf[512];
+      while (at + 8 <= L.size ())
+        {
+          uint32_t pos, len;
+          memcpy (&pos, &L[at], 4);
+          memcpy (&len, &L[at + 4], 4);
+          if (len == 0 || len > 300 || at + 8 + len > L.size ())
+            return fail (d, "fetch_pileup: corrupt insertion log at byte %zu", at);
+          memcpy (buf, &L[at + 8], len);
+          buf[len] = 0;
+          cb (user, pos, buf, (int) len);
+          at += 8 + ((len + 3u) & ~3u);
+        }
+    }
+  return 0;
+}
+
+extern "C" int pemap_dev_fetch_records (pemap_dev * d, uint64_t first, uint64_t count, void *out, uint64_t out_capacity,
+                                        uint64_t * n_records)
+{
+  HIPCHK (d, hipSetDevice (d->device));
+  if (!d->d_counts)
+    return fail (d, "fetch_records: no index");
+  if (first + count > d->gsize)
+    return fail (d, "fetch_records: range beyond the genome");
+  if (count == 0)
+    {
+      *n_records = 0;
+      return 0;
+    }
+  if (count > (1ull << 31))
+    return fail (d, "fetch_records: at most 2^31 sites per call");
+  HIPCHK (d, hipStreamSynchronize (d->stream));
+  const uint64_t n_tiles = (count + PR_BLOCK - 1) / PR_BLOCK;
+  uint32_t *d_tc = nullptr;
+  uint64_t *d_to = nullptr, *d_total = nullptr;
+  TRY (dev_alloc (d, &d_tc, n_tiles));
+  TRY (dev_alloc (d, &d_to, n_tiles));
+  TRY (dev_alloc (d, &d_total, 1));
+  hipLaunchKernelGGL (pile_count_kernel, dim3 ((unsigned) n_tiles), dim3 (PR_BLOCK), 0, d->stream, d->d_counts, first, count, d_tc);
+  hipLaunchKernelGGL (ix_scan_tiles_kernel, dim3 (1), dim3 (1024), 0, d->stream, d_tc, d_to, n_tiles, d_total);
+  uint64_t total = 0;
+  HIPCHK (d, hipMemcpyAsync (&total, d_total, 8, hipMemcpyDeviceToHost, d->stream));
+  HIPCHK (d, hipStreamSynchronize (d->stream));
+  *n_records = total;
+  int rc = 0;
+  if (out && total)
+    {
+      if (total > out_capacity)
+        rc = fail (d, "fetch_records: %llu records do not fit the caller's %llu", (unsigned long long) total,
+                   (unsigned long long) out_capacity);
+      else
+        {
+          PileRec *d_out = nullptr;
+          rc = dev_alloc (d, &d_out, (size_t) total);
+          if (!rc)
+            {
+              hipLaunchKernelGGL (pile_emit_kernel, dim3 ((unsigned) n_tiles), dim3 (PR_BLOCK), 0, d->stream, d->d_counts, first, count, d_to,
+                                  d_out, total);
+              if (hipStreamSynchronize (d->stream) != hipSuccess
+                  || hipMemcpy (out, d_out, total * sizeof (PileRec), hipMemcpyDeviceToHost) != hipSuccess)
+                rc = fail (d, "fetch_records: copy failed");
+              hipFree (d_out);
+            }
+        }
+    }
+  hipFree (d_tc);
+  hipFree (d_to);
+  hipFree (d_total);
+  return rc;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+extern "C" int pemap_dev_synth_genome (pemap_dev * d, uint64_t seed, uint64_t genome_size, int n_contigs, double repeat_frac,
+                                       void **d_genome_out, uint32_t * contig_len)
+{
+  HIPCHK (d, hipSetDevice (d->device));
+  if (n_contigs < 1 || genome_size < (uint64_t) n_contigs * 1000)
+    return fail (d, "synth_genome: bad sizes");
+  // hg38-like relative contig lengths (chr1..22, X, Y, M in Mbp) when 25 contigs are asked for, equal split otherwise
+  static const double hg[25] = { 248.9, 242.2, 198.3, 190.2, 181.5, 170.8, 159.3, 145.1, 138.4, 133.8, 135.1, 133.3, 114.4, 107.0,
+    102.0, 90.3, 83.3, 80.4, 58.6, 64.4, 46.7, 50.8, 156.0, 57.2, 0.0166
+  };
+  std::vector < uint64_t > real (n_contigs + 1);
+  double tot = 0;
+  for (int c = 0; c < n_contigs; c++)
+    tot += (n_contigs == 25) ? hg[c] : 1.0;
+  real[0] = 0;
+  uint64_t used = 0;
+  for (int c = 0; c < n_contigs; c++)
+    {
+      uint64_t ln = (uint64_t) ((double) genome_size * ((n_contigs == 25) ? hg[c] : 1.0) / tot);
+      if (ln < 64)
+        ln = 64;
+      if (c == n_contigs - 1)
+        ln = genome_size - used;
+      contig_len[c] = (uint32_t) ln;
+      used += ln;
+      real[c + 1] = used;
+    }
+  if (used != genome_size)
+    return fail (d, "synth_genome: contig split failed");
+  uint8_t *g = nullptr;
+  TRY (dev_alloc (d, &g, genome_size + 512));
+  uint64_t *d_real = nullptr;
+  TRY (dev_alloc (d, &d_real, (size_t) n_contigs + 1));
+  HIPCHK (d, hipMemcpy (d_real, real.data (), (n_contigs + 1) * 8, hipMemcpyHostToDevice));
+  unsigned thr = (unsigned) (repeat_frac * 16777216.0);
+  hipLaunchKernelGGL (sy_genome_kernel, dim3 ((unsigned) ((genome_size + 255) / 256)), dim3 (256), 0, d->stream, seed, g, genome_size, d_real,
+                      n_contigs, thr);
+  HIPCHK (d, hipStreamSynchronize (d->stream));
+  hipFree (d_real);
+  *d_genome_out = g;
+  return 0;
+}
+
+extern "C" int pemap_dev_free (pemap_dev * d, void *d_ptr)
+{
+  HIPCHK (d, hipSetDevice (d->device));
+  HIPCHK (d, hipFree (d_ptr));
+  return 0;
+}
+
+extern "C" int pemap_dev_synth_reads (pemap_dev * d, uint64_t seed, int n, int read_len, int paired, double sub_rate,
+                                      double indel_rate, uint64_t first_read)
+{
+  HIPCHK (d, hipSetDevice (d->device));
+  if (!d->index_ready)
+    return fail (d, "synth_reads: needs the resident genome");
+  if (read_len < PEMAP_MIN_READ || read_len > PEMAP_MAX_READ || n <= 0)
+    return fail (d, "synth_reads: bad n/read_len");
+  if (d->gsize < 2000)
+    return fail (d, "synth_reads: genome too small");
+  int stride = (read_len + 15) & ~15;
+  d->paired = paired ? 1 : 0;
+  HIPCHK (d, hipStreamSynchronize (d->stream));
+  TRY (ensure_reads (d, n, stride, paired));
+  int ends = paired ? 2 * n : n;
+  hipLaunchKernelGGL (sy_reads_kernel, dim3 ((ends + 255) / 256), dim3 (256), 0, d->stream, seed, d->d_genome, d->gsize, n, read_len, paired,
+                      (unsigned) (sub_rate * 16777216.0), (unsigned) (indel_rate * 16777216.0), first_read, d->d_reads1, d->d_len1,
+                      d->d_reads2, d->d_len2, stride);
+  HIPCHK (d, hipStreamSynchronize (d->stream));
+  d->h_len1.assign (n, read_len);
+  if (paired)
+    d->h_len2.assign (n, read_len);
+  else
+    d->h_len2.clear ();
+  d->n_staged = n;
+  d->staged_paired = paired ? 1 : 0;
+  d->max_len_staged = d->min_len_staged = read_len;
+  return 0;
+}
+
+extern "C" int pemap_dev_staged_reads (pemap_dev * d, char *reads1, int *len1, char *reads2, int *len2, int stride)
+{
+  HIPCHK (d, hipSetDevice (d->device));
+  if (d->n_staged <= 0)
+    return fail (d, "staged_reads: nothing staged");
+  if (stride != d->stride)
+    return fail (d, "staged_reads: the staged row stride is %d", d->stride);
+  HIPCHK (d, hipStreamSynchronize (d->stream));
+  HIPCHK (d, hipMemcpy (reads1, d->d_reads1, (size_t) d->n_staged * stride, hipMemcpyDeviceToHost));
+  HIPCHK (d, hipMemcpy (len1, d->d_len1, (size_t) d->n_staged * 4, hipMemcpyDeviceToHost));
+  if (d->staged_paired && reads2)
+    {
+      HIPCHK (d, hipMemcpy (reads2, d->d_reads2, (size_t) d->n_staged * stride, hipMemcpyDeviceToHost));
+      HIPCHK (d, hipMemcpy (len2, d->d_len2, (size_t) d->n_staged * 4, hipMemcpyDeviceToHost));
+    }
+  return 0;
+}
+
+extern "C" int pemap_dev_staged_info (pemap_dev * d, int *n, int *stride, int *paired)
+{
+  *n = d->n_staged;
+  *stride = d->stride;
+  *paired = d->staged_paired;
+  return 0;
+}

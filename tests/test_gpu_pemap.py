@@ -1,0 +1,135 @@
+"""GPU parity tests: the HIP path, called through the C-ABI (libpemap_hip.so), against the reference's golden outputs
+and against the oracle on the same inputs.  Bit-exact: integer coordinates, counters, and fp64 SW scores."""
+import numpy as np
+import pytest
+import fixtures
+import oracle_py
+import refio
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from pecaller_amd import PemapDev
+    d = PemapDev(0)
+    ix = fixtures.index()
+    d.build_index(ix["genome"], ix["contig_len"])
+    yield d
+    d.close()
+
+
+def test_device_index_equals_reference_index(dev):
+    """pemap_dev_build_index must produce the arrays index_genome_whole.c writes (.mdx bytes, .idx prefix table)."""
+    ix = fixtures.index()
+    m = fixtures.meta()["index"]
+    n_mers, gsize, n_contigs, idepth = dev.index_info()
+    assert (n_mers, gsize, n_contigs, idepth) == (m["n_mers"], m["seq_len"], 10, 16)
+    mers = dev.read_buffer(1, np.uint32)
+    assert refio.md5(mers) == m["mdx_md5"]
+    assert np.array_equal(dev.read_buffer(3, np.uint32), ix["contig_starts"])
+    assert np.array_equal(dev.read_buffer(2, np.uint8), ix["genome"])
+    # prefix table: pos_index[k] = number of indexed positions whose k-mer is < k; checked on four 64 Mi-entry
+    # windows, on both ends, and at every bucket boundary
+    uk, us = ix["ukmer"].astype(np.int64), ix["ustart"]
+    W = 1 << 26
+    for start in (0, (1 << 30) + 12345, (1 << 31) - W // 2, (1 << 32) + 1 - W):
+        got = dev.read_buffer(0, np.uint32, offset_bytes=start * 4, n_bytes=W * 4)
+        k = np.arange(start, start + W, dtype=np.int64)
+        exp = us[np.searchsorted(uk, k, side="left")]
+        assert np.array_equal(got, exp), start
+    full_last = dev.read_buffer(0, np.uint32, offset_bytes=(1 << 32) * 4, n_bytes=4)
+    assert full_last[0] == n_mers
+    rng = np.random.default_rng(1)
+    for i in rng.integers(0, len(uk), size=2000):
+        two = dev.read_buffer(0, np.uint32, offset_bytes=int(uk[i]) * 4, n_bytes=8)
+        assert two[0] == us[i] and two[1] == us[i + 1]
+
+
+@pytest.mark.parametrize("name", ["r150", "r100", "r250"])
+def test_map_matches_reference_golden(dev, name):
+    s = fixtures.SETS[name]
+    r1, l1, r2, l2 = fixtures.reads(name)
+    dev.set_params(paired=s["paired"], min_dist=0, max_dist=500, min_align=0.85)
+    dev.reset_pileup()
+    m1, m2, mt = dev.map_batch(r1, l1, r2, l2)
+    g1 = fixtures.golden_m(name, 1)
+    assert np.array_equal(m1, g1), "m1 differs at %s" % np.nonzero(m1 != g1)[0][:10]
+    if s["paired"]:
+        g2 = fixtures.golden_m(name, 2)
+        assert np.array_equal(m2, g2), "m2 differs at %s" % np.nonzero(m2 != g2)[0][:10]
+    counts, ins = dev.fetch_pileup()
+    rec = fixtures.check_pileup_against_golden(name, counts)
+    # the compacted record stream the pileup writer consumes is the same thing
+    assert np.array_equal(dev.fetch_records(), rec)
+    names, contigs = fixtures.genome()
+    gold_ins, _ = fixtures.golden_insertions(name)
+    assert fixtures.ins_to_named(ins, names, contigs) == gold_ins
+    tot, head, rows = fixtures.golden_summary(name)
+    sm = dev.summary()
+    assert sm[0] == tot
+    assert head[3] == "%g" % (sm[1] / sm[0])
+    assert head[7] == "%g" % ((sm[2] / sm[3]) if sm[3] else 0.0)
+    if s["paired"]:
+        assert rows["Unique Mate-Paired"] == sm[4] and rows["Non-Unique Mate-Paired"] == sm[8] and rows["Neither Map"] == sm[12]
+    else:
+        assert rows["Unique Mapping"] == sm[6] and rows["Non-Unique Mapping, discarded"] == sm[11]
+
+
+def test_hits_and_scores_match_oracle(dev):
+    """per read-end: the hit list (spot, strand) in order, the SW window, and per hit the fp64 score bits and start cell"""
+    ix = fixtures.index()
+    r1, l1, r2, l2 = fixtures.reads("r150")
+    n = 4000
+    dev.set_params(paired=True, min_dist=0, max_dist=500, min_align=0.85)
+    dev.reset_pileup()
+    m1, m2, mt = dev.map_batch(r1[:n], l1[:n], r2[:n], l2[:n])
+    dbg = dev.debug_hits(2 * n)
+    o = oracle_py.Oracle(ix, paired=True)
+    om1, om2, omt, d1, d2 = o.map_batch(r1[:n], l1[:n], r2[:n], l2[:n], debug=True, threads=8)
+    assert np.array_equal(m1, om1) and np.array_equal(m2, om2) and np.array_equal(mt, omt)
+    multi = 0
+    for which, od in ((0, d1), (1, d2)):
+        nh = dbg["n_hits"][which::2]
+        assert np.array_equal(nh, od["n_hits"])
+        for i in np.nonzero(nh)[0]:
+            k = nh[i]
+            e = 2 * i + which
+            assert np.array_equal(dbg["spot"][e, :k], od["spot"][i, :k])
+            assert np.array_equal(dbg["orient"][e, :k], od["orient"][i, :k])
+            assert np.array_equal(dbg["win_start"][e, :k].astype(np.int32), od["win_start"][i, :k])
+            assert np.array_equal(dbg["win_len"][e, :k], od["win_len"][i, :k])
+            # scores as bits
+            assert np.array_equal(dbg["score"][e, :k].view(np.uint64), od["score"][i, :k].view(np.uint64)), (e, k)
+            assert np.array_equal(dbg["start_k"][e, :k], od["start"][i, :k, 0])
+            assert np.array_equal(dbg["start_i"][e, :k], od["start"][i, :k, 1])
+            multi += k > 1
+    assert multi > 10
+    stats, times = dev.run_stats()
+    assert stats["ends"] == 2 * n and stats["sw_score"] == int(dbg["n_hits"].sum())
+
+
+def test_rerun_is_additive_and_slices_compose(dev):
+    """running the staged batch twice doubles every counter; two half slices equal one full run"""
+    r1, l1, r2, l2 = fixtures.reads("r150")
+    n = 2000
+    dev.set_params(paired=True, min_dist=0, max_dist=500, min_align=0.85)
+    dev.reset_pileup()
+    dev.stage_reads(r1[:n], l1[:n], r2[:n], l2[:n])
+    dev.run()
+    a1 = dev.collect()
+    c1, i1 = dev.fetch_pileup()
+    dev.run()
+    dev.collect()
+    c2, i2 = dev.fetch_pileup()
+    assert np.array_equal(c2, (2 * c1.astype(np.uint32)).astype(np.uint16))
+    assert len(i2) == 2 * len(i1)
+    dev.reset_pileup()
+    dev.run_slice(0, n // 2)
+    b1 = dev.collect()
+    dev.run_slice(n // 2, n - n // 2)
+    b2 = dev.collect()
+    c3, i3 = dev.fetch_pileup()
+    assert np.array_equal(c3, c1) and i3 == i1
+    assert np.array_equal(np.concatenate([b1[0], b2[0]]), a1[0])
+    assert np.array_equal(np.concatenate([b1[1], b2[1]]), a1[1])
