@@ -527,16 +527,29 @@ extern "C" int pemap_dev_stage_reads (pemap_dev * d, const char *reads1, const i
   return 0;
 }
 
-template < int W > static void launch_sw (pemap_dev * d, const PmIndex & ix, const PmBatch & b, const PmParams & prm)
+template < int W, bool UNI > static void launch_sw (pemap_dev * d, const PmIndex & ix, const PmBatch & b, const PmParams & prm, int mmu)
 {
-  hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_score_kernel < W >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, ix, b, prm, d->hits,
-                      d->d_tasks, d->d_ctr);
+  hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_score_kernel < W, UNI >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, ix, b, prm, d->hits,
+                      d->d_tasks, d->d_ctr, mmu);
 }
 
-template < int W > static void launch_trace (pemap_dev * d, const PmIndex & ix, const PmBatch & b, const PmParams & prm)
+template < int W, bool UNI > static void launch_trace (pemap_dev * d, const PmIndex & ix, const PmBatch & b, const PmParams & prm, int mmu)
 {
-  hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_trace_kernel < W >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, ix, b, prm, d->hits,
-                      d->d_trace, d->d_ctr, d->d_dirbuf, d->d_counts, d->d_ins_log, d->ins_cap);
+  hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_trace_kernel < W, UNI >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, ix, b, prm, d->hits,
+                      d->d_trace, d->d_ctr, d->d_dirbuf, d->d_counts, d->d_ins_log, d->ins_cap, mmu);
+}
+
+// W columns per lane: the smallest instantiation with 8 * W >= the longest staged read
+template < bool UNI > static void dispatch_sw (pemap_dev * d, bool trace, int L, const PmIndex & ix, const PmBatch & b, const PmParams & prm,
+                                               int mmu)
+{
+#define PM_CASE(Wv) do { if (trace) launch_trace < Wv, UNI > (d, ix, b, prm, mmu); else launch_sw < Wv, UNI > (d, ix, b, prm, mmu); } while (0)
+  if (L <= 8 * 13) PM_CASE (13);
+  else if (L <= 8 * 19) PM_CASE (19);
+  else if (L <= 8 * 26) PM_CASE (26);
+  else if (L <= 8 * 32) PM_CASE (32);
+  else PM_CASE (38);
+#undef PM_CASE
 }
 
 static int run_slice (pemap_dev * d, int first, int n, int sync)
@@ -586,20 +599,19 @@ static int run_slice (pemap_dev * d, int first, int n, int sync)
                       d->d_seed_scratch);
   hipEventRecord (d->ev[1], d->stream);
   const int L = d->max_len_staged;
-  if (L <= 8 * 13) launch_sw < 13 > (d, ix, b, prm);
-  else if (L <= 8 * 19) launch_sw < 19 > (d, ix, b, prm);
-  else if (L <= 8 * 26) launch_sw < 26 > (d, ix, b, prm);
-  else if (L <= 8 * 32) launch_sw < 32 > (d, ix, b, prm);
-  else launch_sw < 38 > (d, ix, b, prm);
+  const bool uni = d->max_len_staged == d->min_len_staged;
+  if (uni)
+    dispatch_sw < true > (d, false, L, ix, b, prm, L);
+  else
+    dispatch_sw < false > (d, false, L, ix, b, prm, 0);
   hipEventRecord (d->ev[2], d->stream);
   hipLaunchKernelGGL (pm_select_kernel, dim3 ((n + 255) / 256), dim3 (256), 0, d->stream, b, prm, d->hits, d->d_trace, d->d_ctr,
                       d->d_m1 + first, d->paired ? d->d_m2 + first : nullptr, d->d_mtype + first);
   hipEventRecord (d->ev[3], d->stream);
-  if (L <= 8 * 13) launch_trace < 13 > (d, ix, b, prm);
-  else if (L <= 8 * 19) launch_trace < 19 > (d, ix, b, prm);
-  else if (L <= 8 * 26) launch_trace < 26 > (d, ix, b, prm);
-  else if (L <= 8 * 32) launch_trace < 32 > (d, ix, b, prm);
-  else launch_trace < 38 > (d, ix, b, prm);
+  if (uni)
+    dispatch_sw < true > (d, true, L, ix, b, prm, L);
+  else
+    dispatch_sw < false > (d, true, L, ix, b, prm, 0);
   hipEventRecord (d->ev[4], d->stream);
   HIPCHK (d, hipGetLastError ());
   d->run_first = first;

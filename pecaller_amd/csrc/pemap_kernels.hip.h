@@ -18,6 +18,8 @@
 #define PM_SEG_LIST_MAX 4851       // 48*99 + 99 positions per segment at most (every bucket < too_many_spots)
 #define PM_LPA 8                   // lanes per alignment in the SW kernels
 #define PM_TMAX 308                // SW steps: window rows (<= 299) + PM_LPA - 1, rounded up
+// register budget of the SW kernels: 4 VGPRs of state per owned column (two doubles) plus temporaries
+#define PM_WAVES_PER_EU(W) ((W) <= 19 ? 4 : (W) <= 26 ? 3 : 2)
 
 struct PmIndex
 {
@@ -499,7 +501,9 @@ __device__ __forceinline__ double pm_border (int j)     // S[k][0][j], j >= 1, p
 
 __device__ __forceinline__ double pm_max (double a, double b)   // maxim(a,b), pemapper.c:36
 {
-  return (a > b) ? a : b;
+  // (a > b) ? a : b.  No NaN and no negative zero can arise in this recurrence (finite constants, add/sub only), so the
+  // IEEE maximum is the same double; it is one v_max_f64 instead of a compare and two selects.
+  return __builtin_fmax (a, b);
 }
 
 // init_bonus_matrices, pemapper.c:2006-2035, as a predicate.  The row fill of iteration i precedes that iteration's
@@ -507,22 +511,12 @@ __device__ __forceinline__ double pm_max (double a, double b)   // maxim(a,b), p
 // but not read A/C/G; a read N matches everything.
 __device__ __forceinline__ bool pm_match (uint8_t r, uint8_t q, int bis)
 {
-  if (r == q || q == 'N' || q == 'n')
-    return true;
-  if (r == 'N' && q >= 'N')
-    return true;
-  if (r == 'n' && q >= 'n')
-    return true;
-  if (bis && (r == 'C' || r == 'c') && (q == 'T' || q == 't'))
-    return true;
-  return false;
+  bool m = (r == q) | (q == 'N') | (q == 'n');
+  m |= (r == 'N') & (q >= 'N');
+  m |= (r == 'n') & (q >= 'n');
+  m |= (bis != 0) & ((r == 'C') | (r == 'c')) & ((q == 'T') | (q == 't'));
+  return m;
 }
-
-template < int W > struct PmSwState
-{
-  double U1[W];
-  double D[W];
-};
 
 struct PmSwTask
 {
@@ -533,48 +527,87 @@ struct PmSwTask
   bool valid;
 };
 
-// returns through best/bk/bi on the lane with g == 0
-template < int W, bool DIRS >
+__device__ __forceinline__ uint8_t pm_oriented (const PmSwTask & tk, int jz)
+{
+  return tk.orient ? pm_rc (tk.read[tk.mm - 1 - jz]) : tk.read[jz];
+}
+
+// one DP cell; everything by value/reference so that after unrolling all state lives in registers
+template < bool DIRS > __device__ __forceinline__ void pm_cell (double &dg, double &s2, double &U1c, double &Dc, uint32_t mword, int bit,
+                                                                uint32_t & dword, int nibpos, double &o0, double &o1, double &o2)
+{
+  // bump = match ? 1.0 : -1/3 assembled from the mask bit without a branch (v_bfe_i32 + 2 x v_bfi_b32)
+  const int t = __builtin_amdgcn_sbfe ((int) mword, bit, 1);            // 0 or -1
+  const uint32_t hi = ((uint32_t) t & 0x3FF00000u) | (~(uint32_t) t & 0xBFD55555u);
+  const uint32_t lo = ~(uint32_t) t & 0x55555555u;
+  const double bump = __hiloint2double ((int) hi, (int) lo);
+  const double s1 = U1c;
+  const double s0 = dg + bump;
+  dg = Dc;
+  const double a0 = s0 - PM_GO;
+  const double x1 = s1 - PM_GE;
+  const double x2 = s2 - PM_GE;
+  const double m01 = pm_max (s0, s1);
+  U1c = pm_max (a0, x1);
+  Dc = pm_max (m01, s2);
+  if (DIRS)
+    {
+      uint32_t nib = (s1 > s0 ? 1u : 0u) | (s2 > m01 ? 2u : 0u) | (x1 > a0 ? 4u : 0u) | (x2 > a0 ? 8u : 0u);
+      dword |= nib << nibpos;
+    }
+  o0 = s0;
+  o1 = s1;
+  o2 = s2;
+  s2 = pm_max (a0, x2);
+}
+
+// UNI: every alignment of the wave has the same read length, so the last-column tracker's position is wave-uniform and
+// the test `c == c_last` is a scalar branch.  Otherwise it is a per-lane predicate (mixed read lengths; slower).
+template < int W, bool DIRS, bool UNI >
 __device__ __forceinline__ void pm_sw_forward (const PmSwTask & tk, int bis, int lane, int nn_max, uint32_t * dirbuf,
                                                double &best, int &bk, int &bi)
 {
   constexpr int DW = (W * 4 + 31) / 32;
-  const int g = lane & (PM_LPA - 1);
+  int g = lane & (PM_LPA - 1);
+  // opaque to the optimiser: otherwise the 2 W border doubles below are computed once per kernel, kept live across the
+  // persistent task loop and double the register footprint
+  asm volatile ("":"+v" (g));
   const int mm = tk.mm, nn = tk.valid ? tk.nn : 0;
-  // ---- this lane's read bytes and match masks against A, C, G, T, N
-  uint32_t mk[5][2];
-#pragma unroll
-  for (int a = 0; a < 5; a++)
-    mk[a][0] = mk[a][1] = 0;
-  uint32_t qpack[(W + 3) / 4];
-#pragma unroll
-  for (int c = 0; c < (W + 3) / 4; c++)
-    qpack[c] = 0;
-#pragma unroll
+  // ---- match masks of this lane's W read bytes against reference A, C, G, T, N (bit c = column c of the lane)
+  uint64_t mk[5] = { 0, 0, 0, 0, 0 };
+#pragma unroll 1
   for (int c = 0; c < W; c++)
     {
-      int jz = g * W + c;          // 0-based read position
+      const int jz = g * W + c;    // 0-based read position
       uint8_t q = 0;
       if (tk.valid && jz < mm)
-        q = tk.orient ? pm_rc (tk.read[mm - 1 - jz]) : tk.read[jz];
-      qpack[c >> 2] |= (uint32_t) q << ((c & 3) * 8);
-      const uint8_t rs[5] = { 'A', 'C', 'G', 'T', 'N' };
-#pragma unroll
-      for (int a = 0; a < 5; a++)
-        if (q != 0 && pm_match (rs[a], q, bis))
-          mk[a][c >> 5] |= 1u << (c & 31);
+        q = pm_oriented (tk, jz);
+      const uint64_t bitc = 1ull << c;
+      if (q != 0)
+        {
+          mk[0] |= pm_match ('A', q, bis) ? bitc : 0ull;
+          mk[1] |= pm_match ('C', q, bis) ? bitc : 0ull;
+          mk[2] |= pm_match ('G', q, bis) ? bitc : 0ull;
+          mk[3] |= pm_match ('T', q, bis) ? bitc : 0ull;
+          mk[4] |= pm_match ('N', q, bis) ? bitc : 0ull;
+        }
     }
-  PmSwState < W > st;
+  double U1[W], D[W];
 #pragma unroll
   for (int c = 0; c < W; c++)
     {
-      double bj = pm_border (g * W + c + 1);
-      st.D[c] = bj;
-      st.U1[c] = pm_max (bj - PM_GO, bj - PM_GE);
+      const double bj = pm_border (g * W + c + 1);
+      D[c] = bj;
+      U1[c] = pm_max (bj - PM_GO, bj - PM_GE);
     }
   double Dprev = (g == 0) ? 0.0 : pm_border (g * W);   // max3 of cell (0, j0-1)
   double R2out = 0.0, Dout = 0.0;
-  const int g_last = (mm - 1) / W, c_last = (mm - 1) - g_last * W;
+  int g_last = (mm - 1) / W, c_last = (mm - 1) - g_last * W;
+  if (UNI)
+    {
+      g_last = __builtin_amdgcn_readfirstlane (g_last);
+      c_last = __builtin_amdgcn_readfirstlane (c_last);
+    }
   double bst = pm_border (mm);     // S[0][0][mm], pemapper.c:1701-1703
   int k_b = 0, i_b = 0;
   uint8_t r_next = (tk.valid && g == 0 && nn >= 1) ? tk.ref[0] : 0;
@@ -590,70 +623,65 @@ __device__ __forceinline__ void pm_sw_forward (const PmSwTask & tk, int bis, int
           Dimp = 0.0;
         }
       const bool act = (i >= 1) && (i <= nn);
-      uint8_t r = r_next;
-      // prefetch next step's reference byte
+      const uint8_t r = r_next;
       if (tk.valid && (i + 1 >= 1) && (i + 1 <= nn))
-        r_next = tk.ref[i];
+        r_next = tk.ref[i];        // next step's reference byte
       if (act)
         {
-          uint32_t m0, m1;
-          if (r == 'A') { m0 = mk[0][0]; m1 = mk[0][1]; }
-          else if (r == 'C') { m0 = mk[1][0]; m1 = mk[1][1]; }
-          else if (r == 'G') { m0 = mk[2][0]; m1 = mk[2][1]; }
-          else if (r == 'T') { m0 = mk[3][0]; m1 = mk[3][1]; }
-          else if (r == 'N') { m0 = mk[4][0]; m1 = mk[4][1]; }
-          else
+          uint64_t msel = (r == 'A') ? mk[0] : (r == 'C') ? mk[1] : (r == 'G') ? mk[2] : (r == 'T') ? mk[3] : mk[4];
+          if (r != 'A' && r != 'C' && r != 'G' && r != 'T' && r != 'N')
             {
-              m0 = m1 = 0;
-#pragma unroll
+              // any other reference byte (IUPAC codes, lower case): evaluate the predicate column by column
+              msel = 0;
+#pragma unroll 1
               for (int c = 0; c < W; c++)
                 {
-                  uint8_t q = (uint8_t) (qpack[c >> 2] >> ((c & 3) * 8));
-                  if (q != 0 && pm_match (r, q, bis))
-                    {
-                      if (c < 32)
-                        m0 |= 1u << (c & 31);
-                      else
-                        m1 |= 1u << (c & 31);
-                    }
+                  const int jz = g * W + c;
+                  if (jz < mm && pm_match (r, pm_oriented (tk, jz), bis))
+                    msel |= 1ull << c;
                 }
             }
+          const uint32_t m0 = (uint32_t) msel, m1 = (uint32_t) (msel >> 32);
           double dg = Dprev;
           double s2 = R2in;
           uint32_t dw[DW];
 #pragma unroll
           for (int d = 0; d < DW; d++)
             dw[d] = 0;
+          double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+          bool have = false;
 #pragma unroll
           for (int c = 0; c < W; c++)
             {
-              const uint32_t mbit = ((c < 32 ? m0 : m1) >> (c & 31)) & 1u;
-              const double bump = mbit ? 1.0 : PM_MISS;
-              const double s1 = st.U1[c];
-              const double s0 = dg + bump;
-              dg = st.D[c];
-              const double a0 = s0 - PM_GO;
-              const double x1 = s1 - PM_GE;
-              const double x2 = s2 - PM_GE;
-              const double m01 = pm_max (s0, s1);
-              st.U1[c] = pm_max (a0, x1);
-              st.D[c] = pm_max (m01, s2);
-              if (DIRS)
+              double o0, o1, o2;
+              pm_cell < DIRS > (dg, s2, U1[c], D[c], (c < 32) ? m0 : m1, c & 31, dw[c >> 3], (c & 7) * 4, o0, o1, o2);
+              if (UNI)
                 {
-                  uint32_t nib = (s1 > s0 ? 1u : 0u) | (s2 > m01 ? 2u : 0u) | (x1 > a0 ? 4u : 0u) | (x2 > a0 ? 8u : 0u);
-                  dw[c >> 3] |= nib << ((c & 7) * 4);
+                  if (c == c_last)
+                    {
+                      t0 = o0;
+                      t1 = o1;
+                      t2 = o2;
+                      have = true;
+                    }
                 }
-              if (c == c_last && g == g_last)
+              else if (c == c_last)
                 {
-                  // last read column, rows ascending, planes 0,1,2, strict '>' (pemapper.c:1724-1741)
-                  if (s0 > bst) { bst = s0; k_b = 0; i_b = i; }
-                  if (s1 > bst) { bst = s1; k_b = 1; i_b = i; }
-                  if (s2 > bst) { bst = s2; k_b = 2; i_b = i; }
+                  t0 = o0;
+                  t1 = o1;
+                  t2 = o2;
+                  have = true;
                 }
-              s2 = pm_max (a0, x2);
+            }
+          if (have && g == g_last)
+            {
+              // last read column, rows ascending, planes 0,1,2, strict '>' (pemapper.c:1724-1741)
+              if (t0 > bst) { bst = t0; k_b = 0; i_b = i; }
+              if (t1 > bst) { bst = t1; k_b = 1; i_b = i; }
+              if (t2 > bst) { bst = t2; k_b = 2; i_b = i; }
             }
           R2out = s2;
-          Dout = st.D[W - 1];
+          Dout = D[W - 1];
           Dprev = Dimp;
           if (DIRS)
             {
@@ -665,7 +693,7 @@ __device__ __forceinline__ void pm_sw_forward (const PmSwTask & tk, int bis, int
         }
     }
   // hand the tracker's result to lane g == 0 of the group
-  const int srcl = (lane & ~(PM_LPA - 1)) + g_last;
+  const int srcl = (lane & ~(PM_LPA - 1)) + ((mm - 1) / W);
   best = __shfl (bst, srcl);
   bk = __shfl (k_b, srcl);
   bi = __shfl (i_b, srcl);
@@ -678,8 +706,9 @@ __device__ __forceinline__ int pm_wave_max (int v)
   return v;
 }
 
-template < int W > __global__ __launch_bounds__ (64) void pm_sw_score_kernel (PmIndex ix, PmBatch b, PmParams prm, PmHits h,
-                                                                               const uint32_t * tasks, PmCounters * ctr)
+template < int W, bool UNI > __global__ __launch_bounds__ (64, PM_WAVES_PER_EU (W)) void pm_sw_score_kernel (PmIndex ix, PmBatch b, PmParams prm, PmHits h,
+                                                                                         const uint32_t * tasks, PmCounters * ctr,
+                                                                                         int mm_uniform)
 {
   const int lane = threadIdx.x;
   const int q = lane >> 3;
@@ -689,7 +718,7 @@ template < int W > __global__ __launch_bounds__ (64) void pm_sw_score_kernel (Pm
       PmSwTask tk;
       tk.valid = (base + q) < n_tasks;
       size_t o = 0;
-      tk.mm = 16;
+      tk.mm = UNI ? mm_uniform : 16;
       tk.nn = 0;
       tk.orient = 0;
       tk.read = nullptr;
@@ -708,7 +737,7 @@ template < int W > __global__ __launch_bounds__ (64) void pm_sw_score_kernel (Pm
       int nn_max = pm_wave_max (tk.nn);
       double best;
       int bk, bi;
-      pm_sw_forward < W, false > (tk, prm.bisulfite, lane, nn_max, nullptr, best, bk, bi);
+      pm_sw_forward < W, false, UNI > (tk, prm.bisulfite, lane, nn_max, nullptr, best, bk, bi);
       if (tk.valid && (lane & 7) == 0)
         {
           h.score[o] = best;
@@ -901,10 +930,10 @@ __global__ void pm_select_kernel (PmBatch b, PmParams prm, PmHits h, uint32_t * 
 // Pileup counters are u32 in HBM updated with no-return atomics (the reference's u16 counters wrap; the fetch
 // truncates, which is the same arithmetic).  Insertions go to a byte log through an atomic cursor.
 // ============================================================================================================
-template < int W > __global__ __launch_bounds__ (64) void pm_sw_trace_kernel (PmIndex ix, PmBatch b, PmParams prm, PmHits h,
-                                                                               const uint32_t * trace, PmCounters * ctr,
-                                                                               uint32_t * dirbuf_all, uint32_t * counts,
-                                                                               uint8_t * ins_log, unsigned ins_cap)
+template < int W, bool UNI > __global__ __launch_bounds__ (64, PM_WAVES_PER_EU (W)) void pm_sw_trace_kernel (PmIndex ix, PmBatch b, PmParams prm, PmHits h,
+                                                                                         const uint32_t * trace, PmCounters * ctr,
+                                                                                         uint32_t * dirbuf_all, uint32_t * counts,
+                                                                                         uint8_t * ins_log, unsigned ins_cap, int mm_uniform)
 {
   constexpr int DW = (W * 4 + 31) / 32;
   const int lane = threadIdx.x;
@@ -916,7 +945,7 @@ template < int W > __global__ __launch_bounds__ (64) void pm_sw_trace_kernel (Pm
       PmSwTask tk;
       tk.valid = (base + q) < n_trace;
       size_t o = 0;
-      tk.mm = 16;
+      tk.mm = UNI ? mm_uniform : 16;
       tk.nn = 0;
       tk.orient = 0;
       tk.read = nullptr;
@@ -938,7 +967,7 @@ template < int W > __global__ __launch_bounds__ (64) void pm_sw_trace_kernel (Pm
       double best;
       int bk, bi;
       __syncthreads ();
-      pm_sw_forward < W, true > (tk, prm.bisulfite, lane, nn_max, dirbuf, best, bk, bi);
+      pm_sw_forward < W, true, UNI > (tk, prm.bisulfite, lane, nn_max, dirbuf, best, bk, bi);
       __threadfence ();
       __syncthreads ();
       if (tk.valid && (lane & 7) == 0)
