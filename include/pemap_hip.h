@@ -129,11 +129,13 @@ int pemap_dev_reset_pileup (pemap_dev * dev);
 /* out13: total_reads, total_bases, total_dist, no_dists, mate_counts[0..8] */
 int pemap_dev_summary (pemap_dev * dev, long *out13);
 
-/* Counters the reference does not have: per run of the staged batch --
- * stats[0] = read-ends, [1] = positions gathered from .mdx (P), [2] = SW score problems (H), [3] = SW trace problems,
- * [4] = DP cells scored, [5] = DP cells traced, [6] = pileup increments, [7] = insertions logged.
- * times_ms[0..3] = seed, score, select, trace kernel durations of the last run (HIP events on the object's stream). */
-int pemap_dev_run_stats (pemap_dev * dev, uint64_t * stats8, float *times_ms4);
+/* Counters the reference does not have, summed over the last run --
+ * stats[0] = read-ends, [1] = positions gathered from .mdx (P), [2] = SW problems scored (H), [3] = SW problems
+ * scored with direction nibbles (single-hit ends + re-scored winners), [4] = DP cells without nibbles, [5] = DP cells
+ * with nibbles, [6] = pileup increments, [7] = insertions logged, [8] = alignments walked back, [9] = winners re-scored.
+ * times_ms[0..5] = seed, SW single-hit (with nibbles), SW multi-hit, select, SW re-score, walk+pileup kernel
+ * durations (HIP events on the object's stream). */
+int pemap_dev_run_stats (pemap_dev * dev, uint64_t * stats10, float *times_ms6);
 
 /* Debug/parity taps: per read-end hit lists and per-hit SW results of the last run.
  * n_hits[n_ends]; the other arrays are [n_ends][PEMAP_MAX_HITS]. Any pointer may be NULL. end = 2*pair + mate in paired mode. */

@@ -39,21 +39,25 @@ struct pemap_dev
   // per-run work arrays (capacity cap_ends read-ends)
   int cap_ends;
   PmHits hits;
-  uint32_t *d_tasks, *d_trace;
+  uint32_t *d_tasks_s, *d_tasks_m, *d_redo, *d_wins;
   uint32_t *d_m1, *d_m2;
   int *d_mtype;
   int cap_out;
   PmCounters *d_ctr;
+  PmInsCursor *d_cur;
   uint32_t *d_seed_scratch;
   uint32_t *d_dirbuf;
+  size_t dirbuf_dwords;
   uint8_t *d_ins_log;
   unsigned ins_cap;
   int seed_grid, sw_grid;
   // run bookkeeping
   int run_first, run_n;
-  hipEvent_t ev[5];
-  PmCounters last_ctr;
-  float last_ms[4];
+  bool run_pending;             // kernels of the last chunk still in flight / not yet accounted
+  hipEvent_t ev[7];
+  PmCounters last_ctr;          // summed over the chunks of the last run
+  PmInsCursor last_cur;
+  float last_ms[6];
   std::vector < uint8_t > h_ins;        // host copy of all insertion-log bytes so far
   long summary[13];
 };
@@ -115,7 +119,10 @@ extern "C" int pemap_dev_create (pemap_dev ** out, int device_id)
   d->staged_paired = 0;
   d->cap_ends = 0;
   memset (&d->hits, 0, sizeof (d->hits));
-  d->d_tasks = d->d_trace = d->d_m1 = d->d_m2 = nullptr;
+  d->d_tasks_s = d->d_tasks_m = d->d_redo = d->d_wins = d->d_m1 = d->d_m2 = nullptr;
+  d->d_cur = nullptr;
+  d->dirbuf_dwords = 0;
+  memset (&d->last_cur, 0, sizeof (d->last_cur));
   d->d_mtype = nullptr;
   d->cap_out = 0;
   d->d_ctr = nullptr;
@@ -124,6 +131,7 @@ extern "C" int pemap_dev_create (pemap_dev ** out, int device_id)
   d->d_ins_log = nullptr;
   d->ins_cap = 0;
   d->run_first = d->run_n = 0;
+  d->run_pending = false;
   memset (&d->last_ctr, 0, sizeof (d->last_ctr));
   memset (d->last_ms, 0, sizeof (d->last_ms));
   memset (d->summary, 0, sizeof (d->summary));
@@ -152,14 +160,15 @@ extern "C" int pemap_dev_create (pemap_dev ** out, int device_id)
       delete d;
       return fail (nullptr, "hipStreamCreate failed");
     }
-  for (int i = 0; i < 5; i++)
+  for (int i = 0; i < 7; i++)
     hipEventCreate (&d->ev[i]);
-  if (hipMalloc ((void **) &d->d_ctr, sizeof (PmCounters)) != hipSuccess)
+  if (hipMalloc ((void **) &d->d_ctr, sizeof (PmCounters)) != hipSuccess || hipMalloc ((void **) &d->d_cur, sizeof (PmInsCursor)) != hipSuccess)
     {
       delete d;
       return fail (nullptr, "hipMalloc failed");
     }
   hipMemset (d->d_ctr, 0, sizeof (PmCounters));
+  hipMemset (d->d_cur, 0, sizeof (PmInsCursor));
   *out = d;
   return 0;
 }
@@ -188,10 +197,13 @@ static void free_work (pemap_dev * d)
   hipFree (d->hits.score);
   hipFree (d->hits.sti);
   hipFree (d->hits.stk);
+  hipFree (d->hits.slot);
   memset (&d->hits, 0, sizeof (d->hits));
-  hipFree (d->d_tasks);
-  hipFree (d->d_trace);
-  d->d_tasks = d->d_trace = nullptr;
+  hipFree (d->d_tasks_s);
+  hipFree (d->d_tasks_m);
+  hipFree (d->d_redo);
+  hipFree (d->d_wins);
+  d->d_tasks_s = d->d_tasks_m = d->d_redo = d->d_wins = nullptr;
   d->cap_ends = 0;
 }
 
@@ -211,10 +223,11 @@ extern "C" void pemap_dev_destroy (pemap_dev * d)
   hipFree (d->d_m2);
   hipFree (d->d_mtype);
   hipFree (d->d_ctr);
+  hipFree (d->d_cur);
   hipFree (d->d_seed_scratch);
   hipFree (d->d_dirbuf);
   hipFree (d->d_ins_log);
-  for (int i = 0; i < 5; i++)
+  for (int i = 0; i < 7; i++)
     hipEventDestroy (d->ev[i]);
   hipStreamDestroy (d->stream);
   delete d;
@@ -442,6 +455,28 @@ static int ensure_reads (pemap_dev * d, int n, int stride, int paired)
   return 0;
 }
 
+// W columns per lane: the smallest instantiation with 8 * W >= the longest staged read
+static int pick_w (int L)
+{
+  return L <= 8 * 13 ? 13 : L <= 8 * 19 ? 19 : L <= 8 * 26 ? 26 : L <= 8 * 32 ? 32 : 38;
+}
+
+static size_t slab_dwords_for (int L)
+{
+  int W = pick_w (L);
+  return (size_t) PM_LPA * (size_t) (L + 21 + PM_LPA) * (size_t) ((W * 4 + 31) / 32);
+}
+
+// device bytes the direction slabs of one chunk may take (one slab per read-end); PEMAP_DIR_BUDGET_GB overrides
+static size_t dir_budget_bytes ()
+{
+  const char *e = getenv ("PEMAP_DIR_BUDGET_GB");
+  double gb = e ? atof (e) : 40.0;
+  if (gb < 0.25)
+    gb = 0.25;
+  return (size_t) (gb * 1073741824.0);
+}
+
 static int ensure_work (pemap_dev * d, int n_ends)
 {
   if (n_ends > d->cap_ends)
@@ -449,6 +484,7 @@ static int ensure_work (pemap_dev * d, int n_ends)
       free_work (d);
       size_t nh = (size_t) n_ends * PM_MAX_HITS;
       TRY (dev_alloc (d, &d->hits.n_hits, (size_t) n_ends));
+      TRY (dev_alloc (d, &d->hits.slot, (size_t) n_ends));
       TRY (dev_alloc (d, &d->hits.spot, nh));
       TRY (dev_alloc (d, &d->hits.gpos, nh));
       TRY (dev_alloc (d, &d->hits.nn, nh));
@@ -456,21 +492,30 @@ static int ensure_work (pemap_dev * d, int n_ends)
       TRY (dev_alloc (d, &d->hits.score, nh));
       TRY (dev_alloc (d, &d->hits.sti, nh));
       TRY (dev_alloc (d, &d->hits.stk, nh));
-      TRY (dev_alloc (d, &d->d_tasks, nh));
-      TRY (dev_alloc (d, &d->d_trace, (size_t) n_ends));
+      TRY (dev_alloc (d, &d->d_tasks_s, (size_t) n_ends));
+      TRY (dev_alloc (d, &d->d_tasks_m, nh));
+      TRY (dev_alloc (d, &d->d_redo, (size_t) n_ends));
+      TRY (dev_alloc (d, &d->d_wins, (size_t) n_ends));
       d->cap_ends = n_ends;
     }
   if (!d->d_seed_scratch)
     TRY (dev_alloc (d, &d->d_seed_scratch, (size_t) d->seed_grid * 2 * PM_MAX_SEG * PM_SEG_LIST_MAX));
-  if (!d->d_dirbuf)
-    TRY (dev_alloc (d, &d->d_dirbuf, (size_t) d->sw_grid * PM_TMAX * 64 * 5));
-  // insertion log: one run cannot log more than 5 bytes per read base on average (8-byte header per >= 1 inserted base
-  // after at least one aligned base, padded to 4); 64 bytes per end is ample for real data and overflow is an error
+  size_t need = (size_t) n_ends * slab_dwords_for (d->max_len_staged);
+  if (need > d->dirbuf_dwords)
+    {
+      hipFree (d->d_dirbuf);
+      d->d_dirbuf = nullptr;
+      d->dirbuf_dwords = 0;
+      TRY (dev_alloc (d, &d->d_dirbuf, need));
+      d->dirbuf_dwords = need;
+    }
+  // insertion log: 64 bytes per read-end of a chunk is ample for real data; overflow is reported as an error
   size_t want = (size_t) n_ends * 64 + (1u << 20);
   if (want > 0xF0000000ull)
     want = 0xF0000000ull;
   if (want > d->ins_cap)
     {
+      TRY (drain_ins (d));
       hipFree (d->d_ins_log);
       TRY (dev_alloc (d, &d->d_ins_log, want));
       d->ins_cap = (unsigned) want;
@@ -527,29 +572,71 @@ extern "C" int pemap_dev_stage_reads (pemap_dev * d, const char *reads1, const i
   return 0;
 }
 
-template < int W, bool UNI > static void launch_sw (pemap_dev * d, const PmIndex & ix, const PmBatch & b, const PmParams & prm, int mmu)
+struct RunCtx
 {
-  hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_score_kernel < W, UNI >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, ix, b, prm, d->hits,
-                      d->d_tasks, d->d_ctr, mmu);
+  PmIndex ix;
+  PmBatch b;
+  PmParams prm;
+  int tstride, L;
+};
+
+template < int W > static void launch_chunk (pemap_dev * d, const RunCtx & c, uint32_t * m1, uint32_t * m2, int *mt)
+{
+  const int n_ends = c.b.n_ends;
+  hipEventRecord (d->ev[0], d->stream);
+  int sgrid = d->seed_grid < n_ends ? d->seed_grid : n_ends;
+  hipLaunchKernelGGL (pm_seed_kernel, dim3 (sgrid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, d->hits, d->d_tasks_s, d->d_tasks_m, d->d_ctr,
+                      d->d_seed_scratch);
+  hipEventRecord (d->ev[1], d->stream);
+  hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, true >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, d->hits,
+                      d->d_tasks_s, &d->d_ctr->n_tasks_s, d->d_ctr, d->d_dirbuf, c.tstride, c.L);
+  hipEventRecord (d->ev[2], d->stream);
+  hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, false >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, d->hits,
+                      d->d_tasks_m, &d->d_ctr->n_tasks_m, d->d_ctr, d->d_dirbuf, c.tstride, c.L);
+  hipEventRecord (d->ev[3], d->stream);
+  hipLaunchKernelGGL (pm_select_kernel, dim3 ((c.b.n + 255) / 256), dim3 (256), 0, d->stream, c.b, c.prm, d->hits, d->d_redo, d->d_wins, d->d_ctr,
+                      m1, m2, mt);
+  hipEventRecord (d->ev[4], d->stream);
+  hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, true >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, d->hits,
+                      d->d_redo, &d->d_ctr->n_redo, d->d_ctr, d->d_dirbuf, c.tstride, c.L);
+  hipEventRecord (d->ev[5], d->stream);
+  int wgrid = (n_ends + 255) / 256;
+  if (wgrid > d->sw_grid)
+    wgrid = d->sw_grid;
+  hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_walk_kernel < W >), dim3 (wgrid), dim3 (256), 0, d->stream, c.b, d->hits, d->d_wins, d->d_ctr, d->d_cur,
+                      d->d_dirbuf, c.tstride, d->d_counts, d->d_ins_log, d->ins_cap);
+  hipEventRecord (d->ev[6], d->stream);
 }
 
-template < int W, bool UNI > static void launch_trace (pemap_dev * d, const PmIndex & ix, const PmBatch & b, const PmParams & prm, int mmu)
+// fold the counters and kernel times of the chunk that just finished into the run's totals
+static int absorb_chunk (pemap_dev * d)
 {
-  hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_trace_kernel < W, UNI >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, ix, b, prm, d->hits,
-                      d->d_trace, d->d_ctr, d->d_dirbuf, d->d_counts, d->d_ins_log, d->ins_cap, mmu);
-}
-
-// W columns per lane: the smallest instantiation with 8 * W >= the longest staged read
-template < bool UNI > static void dispatch_sw (pemap_dev * d, bool trace, int L, const PmIndex & ix, const PmBatch & b, const PmParams & prm,
-                                               int mmu)
-{
-#define PM_CASE(Wv) do { if (trace) launch_trace < Wv, UNI > (d, ix, b, prm, mmu); else launch_sw < Wv, UNI > (d, ix, b, prm, mmu); } while (0)
-  if (L <= 8 * 13) PM_CASE (13);
-  else if (L <= 8 * 19) PM_CASE (19);
-  else if (L <= 8 * 26) PM_CASE (26);
-  else if (L <= 8 * 32) PM_CASE (32);
-  else PM_CASE (38);
-#undef PM_CASE
+  HIPCHK (d, hipStreamSynchronize (d->stream));
+  PmCounters c;
+  HIPCHK (d, hipMemcpy (&c, d->d_ctr, sizeof (PmCounters), hipMemcpyDeviceToHost));
+  HIPCHK (d, hipMemcpy (&d->last_cur, d->d_cur, sizeof (PmInsCursor), hipMemcpyDeviceToHost));
+  PmCounters & t = d->last_ctr;
+  t.n_tasks_s += c.n_tasks_s;
+  t.n_tasks_m += c.n_tasks_m;
+  t.n_slots += c.n_slots;
+  t.n_redo += c.n_redo;
+  t.n_wins += c.n_wins;
+  t.positions += c.positions;
+  t.cells_score += c.cells_score;
+  t.cells_dirs += c.cells_dirs;
+  t.pile_incs += c.pile_incs;
+  t.n_ins += c.n_ins;
+  for (int i = 0; i < 6; i++)
+    {
+      float ms = 0.f;
+      if (hipEventElapsedTime (&ms, d->ev[i], d->ev[i + 1]) == hipSuccess)
+        d->last_ms[i] += ms;
+    }
+  if (d->last_cur.ins_overflow)
+    return fail (d, "insertion log overflow (%u bytes per chunk): lower PEMAP_DIR_BUDGET_GB or map smaller slices", d->ins_cap);
+  if (d->last_cur.ins_bytes > d->ins_cap / 2)
+    return drain_ins (d);
+  return 0;
 }
 
 static int run_slice (pemap_dev * d, int first, int n, int sync)
@@ -563,61 +650,75 @@ static int run_slice (pemap_dev * d, int first, int n, int sync)
     return fail (d, "run: slice [%d, %d) outside the %d staged reads", first, first + n, d->n_staged);
   if (d->staged_paired != d->paired)
     return fail (d, "run: reads were staged in %s mode", d->staged_paired ? "paired" : "single");
-  const int n_ends = d->paired ? 2 * n : n;
-  if ((uint64_t) n_ends * PM_MAX_HITS >= 0xFFFFFFFFull)
-    return fail (d, "run: batch of %d read-ends is too large (limit 21 million)", n_ends);
-  TRY (ensure_work (d, n_ends));
-  PmIndex ix;
-  ix.pos_index = d->d_pos_index;
-  ix.mers = d->d_mers;
-  ix.genome = d->d_genome;
-  ix.contig_starts = d->d_contig_starts;
-  ix.n_mers = d->n_mers;
-  ix.gsize = d->gsize;
-  ix.n_contigs = d->n_contigs;
-  ix.idepth = d->idepth;
-  PmBatch b;
-  b.reads1 = d->d_reads1 + (size_t) first * d->stride;
-  b.reads2 = d->paired ? d->d_reads2 + (size_t) first * d->stride : nullptr;
-  b.len1 = d->d_len1 + first;
-  b.len2 = d->paired ? d->d_len2 + first : nullptr;
-  b.n = n;
-  b.stride = d->stride;
-  b.paired = d->paired;
-  b.n_ends = n_ends;
-  PmParams prm;
-  prm.min_dist = d->min_dist;
-  prm.max_dist = d->max_dist;
-  prm.min_align = d->min_align;
-  prm.bisulfite = d->bisulfite;
-  // the insertion log of the previous run is drained in collect(); a run without collect keeps appending
-  HIPCHK (d, hipMemsetAsync (d->d_ctr, 0, offsetof (PmCounters, ins_bytes), d->stream));
-  HIPCHK (d, hipMemsetAsync (&d->d_ctr->positions, 0, sizeof (PmCounters) - offsetof (PmCounters, positions), d->stream));
-  hipEventRecord (d->ev[0], d->stream);
-  int sgrid = d->seed_grid < n_ends ? d->seed_grid : n_ends;
-  hipLaunchKernelGGL (pm_seed_kernel, dim3 (sgrid), dim3 (64), 0, d->stream, ix, b, prm, d->hits, d->d_tasks, d->d_ctr,
-                      d->d_seed_scratch);
-  hipEventRecord (d->ev[1], d->stream);
+  // finish (and account for) an asynchronous previous run before its work arrays are reused
+  if (d->run_pending)
+    {
+      TRY (absorb_chunk (d));
+      d->run_pending = false;
+    }
   const int L = d->max_len_staged;
-  const bool uni = d->max_len_staged == d->min_len_staged;
-  if (uni)
-    dispatch_sw < true > (d, false, L, ix, b, prm, L);
-  else
-    dispatch_sw < false > (d, false, L, ix, b, prm, 0);
-  hipEventRecord (d->ev[2], d->stream);
-  hipLaunchKernelGGL (pm_select_kernel, dim3 ((n + 255) / 256), dim3 (256), 0, d->stream, b, prm, d->hits, d->d_trace, d->d_ctr,
-                      d->d_m1 + first, d->paired ? d->d_m2 + first : nullptr, d->d_mtype + first);
-  hipEventRecord (d->ev[3], d->stream);
-  if (uni)
-    dispatch_sw < true > (d, true, L, ix, b, prm, L);
-  else
-    dispatch_sw < false > (d, true, L, ix, b, prm, 0);
-  hipEventRecord (d->ev[4], d->stream);
-  HIPCHK (d, hipGetLastError ());
+  const int per = d->paired ? 2 : 1;
+  // chunk so that one direction slab per read-end fits the budget
+  size_t slab_bytes = slab_dwords_for (L) * 4;
+  long max_ends = (long) (dir_budget_bytes () / slab_bytes);
+  if (max_ends > 20000000)
+    max_ends = 20000000;        // task ids are end * 200 + hit in 32 bits
+  int chunk = (int) (max_ends / per);
+  if (chunk < 1)
+    chunk = 1;
+  if (chunk > n)
+    chunk = n;
+  TRY (ensure_work (d, chunk * per));
+  RunCtx c;
+  c.ix.pos_index = d->d_pos_index;
+  c.ix.mers = d->d_mers;
+  c.ix.genome = d->d_genome;
+  c.ix.contig_starts = d->d_contig_starts;
+  c.ix.n_mers = d->n_mers;
+  c.ix.gsize = d->gsize;
+  c.ix.n_contigs = d->n_contigs;
+  c.ix.idepth = d->idepth;
+  c.prm.min_dist = d->min_dist;
+  c.prm.max_dist = d->max_dist;
+  c.prm.min_align = d->min_align;
+  c.prm.bisulfite = d->bisulfite;
+  c.L = L;
+  c.tstride = L + 21 + PM_LPA;
+  memset (&d->last_ctr, 0, sizeof (d->last_ctr));
+  memset (d->last_ms, 0, sizeof (d->last_ms));
   d->run_first = first;
   d->run_n = n;
-  if (sync)
-    return pemap_dev_sync (d);
+  for (int off = 0; off < n; off += chunk)
+    {
+      const int m = (n - off < chunk) ? n - off : chunk;
+      const int f = first + off;
+      c.b.reads1 = d->d_reads1 + (size_t) f * d->stride;
+      c.b.reads2 = d->paired ? d->d_reads2 + (size_t) f * d->stride : nullptr;
+      c.b.len1 = d->d_len1 + f;
+      c.b.len2 = d->paired ? d->d_len2 + f : nullptr;
+      c.b.n = m;
+      c.b.stride = d->stride;
+      c.b.paired = d->paired;
+      c.b.n_ends = m * per;
+      HIPCHK (d, hipMemsetAsync (d->d_ctr, 0, sizeof (PmCounters), d->stream));
+      uint32_t *m1 = d->d_m1 + f, *m2 = d->paired ? d->d_m2 + f : nullptr;
+      int *mt = d->d_mtype + f;
+      switch (pick_w (L))
+        {
+        case 13: launch_chunk < 13 > (d, c, m1, m2, mt); break;
+        case 19: launch_chunk < 19 > (d, c, m1, m2, mt); break;
+        case 26: launch_chunk < 26 > (d, c, m1, m2, mt); break;
+        case 32: launch_chunk < 32 > (d, c, m1, m2, mt); break;
+        default: launch_chunk < 38 > (d, c, m1, m2, mt); break;
+        }
+      HIPCHK (d, hipGetLastError ());
+      d->run_pending = true;
+      if (off + m < n || sync)
+        {
+          TRY (absorb_chunk (d));
+          d->run_pending = false;
+        }
+    }
   return 0;
 }
 
@@ -634,30 +735,32 @@ extern "C" int pemap_dev_run_slice (pemap_dev * d, int first, int n, int sync)
 extern "C" int pemap_dev_sync (pemap_dev * d)
 {
   HIPCHK (d, hipSetDevice (d->device));
+  if (d->run_pending)
+    {
+      TRY (absorb_chunk (d));
+      d->run_pending = false;
+    }
   HIPCHK (d, hipStreamSynchronize (d->stream));
-  HIPCHK (d, hipMemcpy (&d->last_ctr, d->d_ctr, sizeof (PmCounters), hipMemcpyDeviceToHost));
-  for (int i = 0; i < 4; i++)
-    if (hipEventElapsedTime (&d->last_ms[i], d->ev[i], d->ev[i + 1]) != hipSuccess)
-      d->last_ms[i] = 0.f;
-  if (d->last_ctr.ins_overflow)
-    return fail (d, "insertion log overflow (%u bytes): collect() more often or use smaller slices", d->ins_cap);
-  if (d->last_ctr.ins_bytes > d->ins_cap / 2)
-    return drain_ins (d);
   return 0;
 }
 
-// drain the device insertion log into the host copy and reset the cursor
+// drain the device insertion log into the host copy and reset the cursor (stream must be idle)
 static int drain_ins (pemap_dev * d)
 {
-  unsigned nb = d->last_ctr.ins_bytes;
+  HIPCHK (d, hipStreamSynchronize (d->stream));
+  PmInsCursor cur;
+  HIPCHK (d, hipMemcpy (&cur, d->d_cur, sizeof (cur), hipMemcpyDeviceToHost));
+  unsigned nb = cur.ins_bytes;
+  if (nb > d->ins_cap)
+    nb = d->ins_cap;
   if (nb)
     {
       size_t at = d->h_ins.size ();
       d->h_ins.resize (at + nb);
       HIPCHK (d, hipMemcpy (d->h_ins.data () + at, d->d_ins_log, nb, hipMemcpyDeviceToHost));
-      HIPCHK (d, hipMemset (&d->d_ctr->ins_bytes, 0, sizeof (unsigned)));
-      d->last_ctr.ins_bytes = 0;
     }
+  HIPCHK (d, hipMemset (d->d_cur, 0, sizeof (PmInsCursor)));
+  d->last_cur.ins_bytes = 0;
   return 0;
 }
 
@@ -725,12 +828,14 @@ extern "C" int pemap_dev_run_stats (pemap_dev * d, uint64_t * s, float *t)
     {
       s[0] = (uint64_t) (d->paired ? 2 * d->run_n : d->run_n);
       s[1] = c.positions;
-      s[2] = c.n_tasks;
-      s[3] = c.n_trace;
+      s[2] = (uint64_t) c.n_tasks_s + c.n_tasks_m;
+      s[3] = (uint64_t) c.n_tasks_s + c.n_redo;
       s[4] = c.cells_score;
-      s[5] = c.cells_trace;
+      s[5] = c.cells_dirs;
       s[6] = c.pile_incs;
       s[7] = c.n_ins;
+      s[8] = c.n_wins;
+      s[9] = c.n_redo;
     }
   if (t)
     memcpy (t, d->last_ms, sizeof (d->last_ms));
@@ -788,7 +893,7 @@ extern "C" int pemap_dev_reset_pileup (pemap_dev * d)
     return fail (d, "reset_pileup: no index");
   HIPCHK (d, hipStreamSynchronize (d->stream));
   HIPCHK (d, hipMemset (d->d_counts, 0, (d->gsize * 6 + 6) * sizeof (uint32_t)));
-  HIPCHK (d, hipMemset (&d->d_ctr->ins_bytes, 0, sizeof (unsigned)));
+  HIPCHK (d, hipMemset (d->d_cur, 0, sizeof (PmInsCursor)));
   d->h_ins.clear ();
   memset (d->summary, 0, sizeof (d->summary));
   return 0;

@@ -17,7 +17,6 @@
 #define PM_SEED_CAP 1024           // positions per strand kept in LDS; larger lists go to the per-block global scratch
 #define PM_SEG_LIST_MAX 4851       // 48*99 + 99 positions per segment at most (every bucket < too_many_spots)
 #define PM_LPA 8                   // lanes per alignment in the SW kernels
-#define PM_TMAX 308                // SW steps: window rows (<= 299) + PM_LPA - 1, rounded up
 // register budget of the SW kernels: 4 VGPRs of state per owned column (two doubles) plus temporaries
 #define PM_WAVES_PER_EU(W) ((W) <= 19 ? 4 : (W) <= 26 ? 3 : 2)
 
@@ -33,18 +32,27 @@ struct PmIndex
   int idepth;
 };
 
-// counters shared by the kernels of one run
+// counters shared by the kernels of one run (zeroed at the start of every run)
 struct PmCounters
 {
-  unsigned int n_tasks;            // SW score problems (H)
-  unsigned int n_trace;            // SW trace problems
-  unsigned int ins_bytes;          // insertion log cursor
-  unsigned int ins_overflow;
+  unsigned int n_tasks_s;          // SW problems of read-ends with exactly one hit (scored WITH direction nibbles)
+  unsigned int n_tasks_m;          // SW problems of read-ends with several hits (score only)
+  unsigned int n_slots;            // direction slabs handed out
+  unsigned int n_redo;             // winners of multi-hit ends: scored again with direction nibbles
+  unsigned int n_wins;             // alignments to walk back
+  unsigned int pad0;
   unsigned long long positions;    // P: entries copied out of .mdx
-  unsigned long long cells_score;
-  unsigned long long cells_trace;
+  unsigned long long cells_score;  // DP cells computed without / with direction nibbles
+  unsigned long long cells_dirs;
   unsigned long long pile_incs;
   unsigned long long n_ins;
+};
+
+// insertion log cursor: survives runs until the host drains the log
+struct PmInsCursor
+{
+  unsigned int ins_bytes;
+  unsigned int ins_overflow;
 };
 
 // per read-end hit record arrays, all [n_ends][PM_MAX_HITS]
@@ -58,6 +66,7 @@ struct PmHits
   double *score;
   int16_t *sti;                    // start[1]
   uint8_t *stk;                    // start[0]
+  int *slot;                       // [n_ends] direction slab of the end's traceable alignment, -1 = none
 };
 
 struct PmBatch
@@ -293,8 +302,8 @@ __device__ bool pm_find_matches (PmSeedShared & sh, const uint32_t * lists, int 
   return true;
 }
 
-__global__ __launch_bounds__ (64) void pm_seed_kernel (PmIndex ix, PmBatch b, PmParams prm, PmHits h, uint32_t * tasks,
-                                                      PmCounters * ctr, uint32_t * gscratch)
+__global__ __launch_bounds__ (64) void pm_seed_kernel (PmIndex ix, PmBatch b, PmParams prm, PmHits h, uint32_t * tasks_s,
+                                                      uint32_t * tasks_m, PmCounters * ctr, uint32_t * gscratch)
 {
   __shared__ PmSeedShared sh;
   const int lane = threadIdx.x;
@@ -442,12 +451,18 @@ __global__ __launch_bounds__ (64) void pm_seed_kernel (PmIndex ix, PmBatch b, Pm
             }
         }
       // ---- hits -> spots and SW windows (pemapper.c:1664-1669, 1047-1081)
+      // an end with one hit is scored once, with direction nibbles, into its own slab; ends with several hits are
+      // scored without, and only the winner is scored again (pm_select_kernel)
       unsigned tbase = 0;
+      uint32_t *tasks = (tot == 1) ? tasks_s : tasks_m;
       if (lane == 0)
         {
           h.n_hits[e] = tot;
-          if (tot > 0)
-            tbase = atomicAdd (&ctr->n_tasks, (unsigned) tot);
+          h.slot[e] = (tot == 1) ? (int) atomicAdd (&ctr->n_slots, 1u) : -1;
+          if (tot == 1)
+            tbase = atomicAdd (&ctr->n_tasks_s, 1u);
+          else if (tot > 1)
+            tbase = atomicAdd (&ctr->n_tasks_m, (unsigned) tot);
         }
       tbase = __shfl (tbase, 0);
       for (int t = lane; t < tot; t += 64)
@@ -475,604 +490,5 @@ __global__ __launch_bounds__ (64) void pm_seed_kernel (PmIndex ix, PmBatch b, Pm
     }
 }
 
-// ============================================================================================================
-// K3: Smith-Waterman forward (smith_waterman_align, pemapper.c:1694-1748).
-//
-// PM_LPA = 8 lanes share one alignment, 8 alignments per wave.  Lane g owns read columns j = g*W+1 .. g*W+W and
-// walks the reference rows skewed by g (row i = step - g), so that the only lane-to-lane traffic per step is two
-// doubles from lane g-1: S2 of the cell to the left and max3 of that cell (next row's diagonal).  Per own column a lane
-// keeps two doubles in registers: U1 = S1 of the row below and D = max(S0,S1,S2) of the cell.
-//
-//   S2[i][j] = max (S0[i][j-1]-go, S2[i][j-1]-ge)      S1[i][j] = max (S0[i-1][j]-go, S1[i-1][j]-ge)
-//   S0[i][j] = max3 (S.[i-1][j-1]) + match             (the reference adds the bonus to each plane before the max;
-//                                                        rounding is monotone, so max-then-add gives the same double)
-//
-// With DIRS the four comparisons the traceback will make at a cell (pemapper.c:1799-1831) are stored as one nibble:
-//   bit0 S1>S0   bit1 S2>max(S0,S1)   bit2 S1-ge > S0-go   bit3 S2-ge > S0-go
-// ============================================================================================================
-#define PM_GO 2.0
-#define PM_GE (1.0 / 36.0)
-#define PM_MISS (-1.0 / 3.0)
 
-__device__ __forceinline__ double pm_border (int j)     // S[k][0][j], j >= 1, pemapper.c:2077-2078
-{
-  return -(PM_GO + (double) (j - 1) * PM_GE);
-}
-
-__device__ __forceinline__ double pm_max (double a, double b)   // maxim(a,b), pemapper.c:36
-{
-  // (a > b) ? a : b.  No NaN and no negative zero can arise in this recurrence (finite constants, add/sub only), so the
-  // IEEE maximum is the same double; it is one v_max_f64 instead of a compare and two selects.
-  return __builtin_fmax (a, b);
-}
-
-// init_bonus_matrices, pemapper.c:2006-2035, as a predicate.  The row fill of iteration i precedes that iteration's
-// 'N'/'n' assignments, so row 'N' keeps 1.0 only for columns >= 'N': a reference N matches read N, T and lower case
-// but not read A/C/G; a read N matches everything.
-__device__ __forceinline__ bool pm_match (uint8_t r, uint8_t q, int bis)
-{
-  bool m = (r == q) | (q == 'N') | (q == 'n');
-  m |= (r == 'N') & (q >= 'N');
-  m |= (r == 'n') & (q >= 'n');
-  m |= (bis != 0) & ((r == 'C') | (r == 'c')) & ((q == 'T') | (q == 't'));
-  return m;
-}
-
-struct PmSwTask
-{
-  const uint8_t *read;             // forward read bytes
-  const uint8_t *ref;              // genome + window start
-  int mm, nn;
-  int orient;
-  bool valid;
-};
-
-__device__ __forceinline__ uint8_t pm_oriented (const PmSwTask & tk, int jz)
-{
-  return tk.orient ? pm_rc (tk.read[tk.mm - 1 - jz]) : tk.read[jz];
-}
-
-// one DP cell; everything by value/reference so that after unrolling all state lives in registers
-template < bool DIRS > __device__ __forceinline__ void pm_cell (double &dg, double &s2, double &U1c, double &Dc, uint32_t mword, int bit,
-                                                                uint32_t & dword, int nibpos, double &o0, double &o1, double &o2)
-{
-  // bump = match ? 1.0 : -1/3 assembled from the mask bit without a branch (v_bfe_i32 + 2 x v_bfi_b32)
-  const int t = __builtin_amdgcn_sbfe ((int) mword, bit, 1);            // 0 or -1
-  const uint32_t hi = ((uint32_t) t & 0x3FF00000u) | (~(uint32_t) t & 0xBFD55555u);
-  const uint32_t lo = ~(uint32_t) t & 0x55555555u;
-  const double bump = __hiloint2double ((int) hi, (int) lo);
-  const double s1 = U1c;
-  const double s0 = dg + bump;
-  dg = Dc;
-  const double a0 = s0 - PM_GO;
-  const double x1 = s1 - PM_GE;
-  const double x2 = s2 - PM_GE;
-  const double m01 = pm_max (s0, s1);
-  U1c = pm_max (a0, x1);
-  Dc = pm_max (m01, s2);
-  if (DIRS)
-    {
-      uint32_t nib = (s1 > s0 ? 1u : 0u) | (s2 > m01 ? 2u : 0u) | (x1 > a0 ? 4u : 0u) | (x2 > a0 ? 8u : 0u);
-      dword |= nib << nibpos;
-    }
-  o0 = s0;
-  o1 = s1;
-  o2 = s2;
-  s2 = pm_max (a0, x2);
-}
-
-// UNI: every alignment of the wave has the same read length, so the last-column tracker's position is wave-uniform and
-// the test `c == c_last` is a scalar branch.  Otherwise it is a per-lane predicate (mixed read lengths; slower).
-template < int W, bool DIRS, bool UNI >
-__device__ __forceinline__ void pm_sw_forward (const PmSwTask & tk, int bis, int lane, int nn_max, uint32_t * dirbuf,
-                                               double &best, int &bk, int &bi)
-{
-  constexpr int DW = (W * 4 + 31) / 32;
-  int g = lane & (PM_LPA - 1);
-  // opaque to the optimiser: otherwise the 2 W border doubles below are computed once per kernel, kept live across the
-  // persistent task loop and double the register footprint
-  asm volatile ("":"+v" (g));
-  const int mm = tk.mm, nn = tk.valid ? tk.nn : 0;
-  // ---- match masks of this lane's W read bytes against reference A, C, G, T, N (bit c = column c of the lane)
-  uint64_t mk[5] = { 0, 0, 0, 0, 0 };
-#pragma unroll 1
-  for (int c = 0; c < W; c++)
-    {
-      const int jz = g * W + c;    // 0-based read position
-      uint8_t q = 0;
-      if (tk.valid && jz < mm)
-        q = pm_oriented (tk, jz);
-      const uint64_t bitc = 1ull << c;
-      if (q != 0)
-        {
-          mk[0] |= pm_match ('A', q, bis) ? bitc : 0ull;
-          mk[1] |= pm_match ('C', q, bis) ? bitc : 0ull;
-          mk[2] |= pm_match ('G', q, bis) ? bitc : 0ull;
-          mk[3] |= pm_match ('T', q, bis) ? bitc : 0ull;
-          mk[4] |= pm_match ('N', q, bis) ? bitc : 0ull;
-        }
-    }
-  double U1[W], D[W];
-#pragma unroll
-  for (int c = 0; c < W; c++)
-    {
-      const double bj = pm_border (g * W + c + 1);
-      D[c] = bj;
-      U1[c] = pm_max (bj - PM_GO, bj - PM_GE);
-    }
-  double Dprev = (g == 0) ? 0.0 : pm_border (g * W);   // max3 of cell (0, j0-1)
-  double R2out = 0.0, Dout = 0.0;
-  int g_last = (mm - 1) / W, c_last = (mm - 1) - g_last * W;
-  if (UNI)
-    {
-      g_last = __builtin_amdgcn_readfirstlane (g_last);
-      c_last = __builtin_amdgcn_readfirstlane (c_last);
-    }
-  double bst = pm_border (mm);     // S[0][0][mm], pemapper.c:1701-1703
-  int k_b = 0, i_b = 0;
-  uint8_t r_next = (tk.valid && g == 0 && nn >= 1) ? tk.ref[0] : 0;
-
-  for (int t = 1; t <= nn_max + PM_LPA - 1; t++)
-    {
-      const int i = t - g;
-      double R2in = __shfl_up (R2out, 1, PM_LPA);
-      double Dimp = __shfl_up (Dout, 1, PM_LPA);
-      if (g == 0)
-        {
-          R2in = pm_max (0.0 - PM_GO, -PM_GO - PM_GE);      // S2[i][1] from the column-0 border (pemapper.c:2079-2081)
-          Dimp = 0.0;
-        }
-      const bool act = (i >= 1) && (i <= nn);
-      const uint8_t r = r_next;
-      if (tk.valid && (i + 1 >= 1) && (i + 1 <= nn))
-        r_next = tk.ref[i];        // next step's reference byte
-      if (act)
-        {
-          uint64_t msel = (r == 'A') ? mk[0] : (r == 'C') ? mk[1] : (r == 'G') ? mk[2] : (r == 'T') ? mk[3] : mk[4];
-          if (r != 'A' && r != 'C' && r != 'G' && r != 'T' && r != 'N')
-            {
-              // any other reference byte (IUPAC codes, lower case): evaluate the predicate column by column
-              msel = 0;
-#pragma unroll 1
-              for (int c = 0; c < W; c++)
-                {
-                  const int jz = g * W + c;
-                  if (jz < mm && pm_match (r, pm_oriented (tk, jz), bis))
-                    msel |= 1ull << c;
-                }
-            }
-          const uint32_t m0 = (uint32_t) msel, m1 = (uint32_t) (msel >> 32);
-          double dg = Dprev;
-          double s2 = R2in;
-          uint32_t dw[DW];
-#pragma unroll
-          for (int d = 0; d < DW; d++)
-            dw[d] = 0;
-          double t0 = 0.0, t1 = 0.0, t2 = 0.0;
-          bool have = false;
-#pragma unroll
-          for (int c = 0; c < W; c++)
-            {
-              double o0, o1, o2;
-              pm_cell < DIRS > (dg, s2, U1[c], D[c], (c < 32) ? m0 : m1, c & 31, dw[c >> 3], (c & 7) * 4, o0, o1, o2);
-              if (UNI)
-                {
-                  if (c == c_last)
-                    {
-                      t0 = o0;
-                      t1 = o1;
-                      t2 = o2;
-                      have = true;
-                    }
-                }
-              else if (c == c_last)
-                {
-                  t0 = o0;
-                  t1 = o1;
-                  t2 = o2;
-                  have = true;
-                }
-            }
-          if (have && g == g_last)
-            {
-              // last read column, rows ascending, planes 0,1,2, strict '>' (pemapper.c:1724-1741)
-              if (t0 > bst) { bst = t0; k_b = 0; i_b = i; }
-              if (t1 > bst) { bst = t1; k_b = 1; i_b = i; }
-              if (t2 > bst) { bst = t2; k_b = 2; i_b = i; }
-            }
-          R2out = s2;
-          Dout = D[W - 1];
-          Dprev = Dimp;
-          if (DIRS)
-            {
-              uint32_t *dst = dirbuf + ((size_t) (t - 1) * 64 + lane) * DW;
-#pragma unroll
-              for (int d = 0; d < DW; d++)
-                dst[d] = dw[d];
-            }
-        }
-    }
-  // hand the tracker's result to lane g == 0 of the group
-  const int srcl = (lane & ~(PM_LPA - 1)) + ((mm - 1) / W);
-  best = __shfl (bst, srcl);
-  bk = __shfl (k_b, srcl);
-  bi = __shfl (i_b, srcl);
-}
-
-__device__ __forceinline__ int pm_wave_max (int v)
-{
-  for (int o = 32; o > 0; o >>= 1)
-    v = max (v, __shfl_xor (v, o));
-  return v;
-}
-
-template < int W, bool UNI > __global__ __launch_bounds__ (64, PM_WAVES_PER_EU (W)) void pm_sw_score_kernel (PmIndex ix, PmBatch b, PmParams prm, PmHits h,
-                                                                                         const uint32_t * tasks, PmCounters * ctr,
-                                                                                         int mm_uniform)
-{
-  const int lane = threadIdx.x;
-  const int q = lane >> 3;
-  const unsigned n_tasks = ctr->n_tasks;
-  for (unsigned base = blockIdx.x * 8u; base < n_tasks; base += gridDim.x * 8u)
-    {
-      PmSwTask tk;
-      tk.valid = (base + q) < n_tasks;
-      size_t o = 0;
-      tk.mm = UNI ? mm_uniform : 16;
-      tk.nn = 0;
-      tk.orient = 0;
-      tk.read = nullptr;
-      tk.ref = nullptr;
-      if (tk.valid)
-        {
-          o = tasks[base + q];
-          int end = (int) (o / PM_MAX_HITS);
-          tk.read = pm_read_ptr (b, end, &tk.mm);
-          tk.nn = h.nn[o];
-          if (tk.nn < 0)
-            tk.nn = 0;
-          tk.orient = h.orient[o];
-          tk.ref = ix.genome + h.gpos[o];
-        }
-      int nn_max = pm_wave_max (tk.nn);
-      double best;
-      int bk, bi;
-      pm_sw_forward < W, false, UNI > (tk, prm.bisulfite, lane, nn_max, nullptr, best, bk, bi);
-      if (tk.valid && (lane & 7) == 0)
-        {
-          h.score[o] = best;
-          h.stk[o] = (uint8_t) bk;
-          h.sti[o] = (int16_t) bi;
-          atomicAdd (&ctr->cells_score, (unsigned long long) tk.nn * tk.mm);
-        }
-    }
-}
-
-// ============================================================================================================
-// K4: pair / single-end selection (pemapper.c:1084-1185 and find_mate_pairs 1313-1536), one lane per read (pair).
-// Output: the hit to trace per end (or -1), the class, and m1/m2 = window start + start[1] + 1 (pemapper.c:1208, 1228).
-// ============================================================================================================
-__device__ int pm_single_select (const double *sc, int n, int len, double min_align, int *bsm)
-{
-  double good_score = len * min_align * 1.0;
-  double top_score = -PM_GO * len;
-  int top_score_count = 0;
-  for (int i = 0; i < n; i++)
-    {
-      double this_score = sc[i];
-      if (this_score > top_score && this_score >= good_score)
-        {
-          top_score = this_score;
-          top_score_count = 1;
-          *bsm = i;
-        }
-      else if ((fabs (this_score - top_score) < 0.0001) && (top_score_count > 0))
-        top_score_count++;
-    }
-  if (top_score_count == 0)
-    return 8;                   // NEITHER_MAP
-  if (top_score_count == 1)
-    return 2;                   // UNIQUE_SINGLE
-  return 7;                     // NON_NO
-}
-
-__global__ void pm_select_kernel (PmBatch b, PmParams prm, PmHits h, uint32_t * trace, PmCounters * ctr, uint32_t * m1,
-                                  uint32_t * m2, int *mtype)
-{
-  int it = blockIdx.x * blockDim.x + threadIdx.x;
-  if (it >= b.n)
-    return;
-  const int e1 = b.paired ? 2 * it : it;
-  const int n1 = h.n_hits[e1];
-  const int n2 = b.paired ? h.n_hits[e1 + 1] : 0;
-  const size_t o1 = (size_t) e1 * PM_MAX_HITS, o2 = o1 + PM_MAX_HITS;
-  const double *s1 = h.score + o1, *s2 = h.score + o2;
-  const int l1 = b.len1[it], l3 = b.paired ? b.len2[it] : 0;
-  int use1 = -1, use2 = -1, code;
-  if (n1 > 0 && n2 == 0)
-    {
-      int bsm = 0;
-      code = pm_single_select (s1, n1, l1, prm.min_align, &bsm);
-      if (code == 2)
-        use1 = bsm;
-    }
-  else if (n2 > 0 && n1 == 0)
-    {
-      int bsm = 0;
-      code = pm_single_select (s2, n2, l3, prm.min_align, &bsm);
-      if (code == 2)
-        use2 = bsm;
-    }
-  else if (n1 > 0 && n2 > 0)
-    {
-      const double good1 = l1 * prm.min_align * 1.0, good2 = l3 * prm.min_align * 1.0;
-      int perfect = 0, slip_count = 0;
-      unsigned sm1 = 0xFFFFFFFFu, sm2 = 0xFFFFFFFFu;
-      double tot_best = -1e5;
-      for (int w1 = 0; w1 < n1; w1++)
-        if (s1[w1] >= good1)
-          for (int w2 = 0; w2 < n2; w2++)
-            if (s2[w2] >= good2)
-              {
-                long p1 = (long) h.spot[o1 + w1], p2 = (long) h.spot[o2 + w2];
-                long temp_dist = labs (p1 - p2);
-                int or1 = h.orient[o1 + w1], or2 = h.orient[o2 + w2];
-                if ((temp_dist >= prm.min_dist) && (temp_dist <= prm.max_dist) && (or1 != or2))
-                  {
-                    double inc = s1[w1] + s2[w2] - tot_best;
-                    if (inc > 0.001)
-                      {
-                        perfect = 1;
-                        sm1 = w1;
-                        sm2 = w2;
-                        tot_best = s1[w1] + s2[w2];
-                        slip_count = 1;
-                      }
-                    else if (inc > -0.001)
-                      {
-                        if (sm1 == (unsigned) w1 || sm2 == (unsigned) w2)
-                          slip_count++;
-                        perfect++;
-                      }
-                  }
-              }
-      code = 8;
-      if (perfect > 0)
-        {
-          use1 = (int) sm1;
-          use2 = (int) sm2;
-          if (perfect == 1)
-            code = 0;
-          else if (slip_count == perfect)
-            code = 1;
-          else
-            {
-              code = 4;
-              use1 = use2 = -1;
-            }
-        }
-      else
-        {
-          int best1 = 0, best2 = 0, m1_c = 0, m2_c = 0;
-          for (int i = 1; i < n1; i++)
-            if (s1[i] > s1[best1])
-              {
-                best1 = i;
-                m1_c = 1;
-              }
-            else if (s1[i] - s1[best1] > -0.0001)
-              m1_c++;
-          // the reference indexes smax2 with best1 here (pemapper.c:1468); smax2[k] for k >= n2 reads its -1.0 fill (1348-1351)
-          const double s2b1 = (best1 < n2) ? s2[best1] : -1.0;
-          for (int i = 1; i < n2; i++)
-            if (s2[i] > s2[best2])
-              {
-                best2 = i;
-                m2_c = 1;
-              }
-            else if (s2[i] - s2b1 > -0.0001)
-              m2_c++;
-          const bool ok2 = (s2[best2] >= good2) && (m2_c < 2);
-          if (s1[best1] >= good1)
-            {
-              if (m1_c < 2)
-                {
-                  use1 = best1;
-                  if (ok2)
-                    {
-                      use2 = best2;
-                      code = 3;
-                    }
-                  else
-                    code = 2;
-                }
-              else if (ok2)
-                {
-                  use2 = best2;
-                  code = 2;
-                }
-              else
-                code = 5;
-            }
-          else if (ok2)
-            {
-              use2 = best2;
-              code = 2;
-            }
-          else
-            code = 5;
-        }
-    }
-  else
-    code = 8;
-  uint32_t r1 = 0, r2 = 0;
-  if (use1 >= 0)
-    {
-      size_t o = o1 + use1;
-      r1 = (uint32_t) (h.gpos[o] + (uint32_t) h.sti[o]) + 1u;
-      trace[atomicAdd (&ctr->n_trace, 1u)] = (uint32_t) o;
-    }
-  if (use2 >= 0)
-    {
-      size_t o = o2 + use2;
-      r2 = (uint32_t) (h.gpos[o] + (uint32_t) h.sti[o]) + 1u;
-      trace[atomicAdd (&ctr->n_trace, 1u)] = (uint32_t) o;
-    }
-  m1[it] = r1;
-  if (m2)
-    m2[it] = r2;
-  mtype[it] = code;
-}
-
-// ============================================================================================================
-// K5: traceback + pileup (smith_waterman_backtrack, pemapper.c:1752-1965).  The winning alignments are scored again
-// with DIRS (nibbles to the wave's slab of the direction buffer), then lane 0 of each 8-lane group walks its path.
-// Pileup counters are u32 in HBM updated with no-return atomics (the reference's u16 counters wrap; the fetch
-// truncates, which is the same arithmetic).  Insertions go to a byte log through an atomic cursor.
-// ============================================================================================================
-template < int W, bool UNI > __global__ __launch_bounds__ (64, PM_WAVES_PER_EU (W)) void pm_sw_trace_kernel (PmIndex ix, PmBatch b, PmParams prm, PmHits h,
-                                                                                         const uint32_t * trace, PmCounters * ctr,
-                                                                                         uint32_t * dirbuf_all, uint32_t * counts,
-                                                                                         uint8_t * ins_log, unsigned ins_cap, int mm_uniform)
-{
-  constexpr int DW = (W * 4 + 31) / 32;
-  const int lane = threadIdx.x;
-  const int q = lane >> 3;
-  const unsigned n_trace = ctr->n_trace;
-  uint32_t *dirbuf = dirbuf_all + (size_t) blockIdx.x * PM_TMAX * 64 * DW;
-  for (unsigned base = blockIdx.x * 8u; base < n_trace; base += gridDim.x * 8u)
-    {
-      PmSwTask tk;
-      tk.valid = (base + q) < n_trace;
-      size_t o = 0;
-      tk.mm = UNI ? mm_uniform : 16;
-      tk.nn = 0;
-      tk.orient = 0;
-      tk.read = nullptr;
-      tk.ref = nullptr;
-      uint32_t gpos = 0;
-      if (tk.valid)
-        {
-          o = trace[base + q];
-          int end = (int) (o / PM_MAX_HITS);
-          tk.read = pm_read_ptr (b, end, &tk.mm);
-          tk.nn = h.nn[o];
-          if (tk.nn < 0)
-            tk.nn = 0;
-          tk.orient = h.orient[o];
-          gpos = h.gpos[o];
-          tk.ref = ix.genome + gpos;
-        }
-      int nn_max = pm_wave_max (tk.nn);
-      double best;
-      int bk, bi;
-      __syncthreads ();
-      pm_sw_forward < W, true, UNI > (tk, prm.bisulfite, lane, nn_max, dirbuf, best, bk, bi);
-      __threadfence ();
-      __syncthreads ();
-      if (tk.valid && (lane & 7) == 0)
-        {
-          const int mm = tk.mm;
-          int k = bk, i = bi, j = mm;
-          int i1 = 0, j1 = 0, ins_len = 0;
-          unsigned long long incs = 0, nins = 0;
-          const int gl = lane;      // lane of group member 0
-          while (i > 0 && j > 0)
-            {
-              i1 = i - 1;
-              j1 = j - 1;
-              int maxi, maxj, maxk;
-              // cell whose comparisons decide the predecessor plane
-              int ci, cj;
-              if (k == 0) { maxi = i1; maxj = j1; ci = i1; cj = j1; }
-              else if (k == 2) { maxi = i; maxj = j1; ci = i; cj = j1; }
-              else { maxi = i1; maxj = j; ci = i1; cj = j; }
-              maxk = 0;
-              if (ci >= 1 && cj >= 1)
-                {
-                  int gg = (cj - 1) / W, c = (cj - 1) - gg * W;
-                  uint32_t wv = dirbuf[((size_t) (ci + gg - 1) * 64 + (gl + gg)) * DW + (c >> 3)];
-                  uint32_t nib = (wv >> ((c & 7) * 4)) & 0xFu;
-                  if (k == 0)
-                    maxk = (nib & 2u) ? 2 : ((nib & 1u) ? 1 : 0);
-                  else if (k == 2)
-                    maxk = (nib & 8u) ? 2 : 0;
-                  else
-                    maxk = (nib & 4u) ? 1 : 0;
-                }
-              // border cells: the walk ends after this step (i or j becomes 0), maxk is never used
-              uint32_t *cnt = counts + ((size_t) gpos + (size_t) i1) * 6;
-              if (maxi != i)
-                {
-                  if (maxj != j)
-                    {
-                      uint8_t ch = tk.orient ? pm_rc (tk.read[mm - 1 - j1]) : tk.read[j1];
-                      int slot = (ch == 'A') ? 0 : (ch == 'C') ? 1 : (ch == 'G') ? 2 : (ch == 'T') ? 3 : -1;
-                      if (slot >= 0)
-                        {
-                          atomicAdd (&cnt[slot], 1u);
-                          incs++;
-                        }
-                    }
-                  else
-                    {
-                      atomicAdd (&cnt[4], 1u);
-                      incs++;
-                    }
-                  if (ins_len > 0)
-                    {
-                      // inserted bases = oriented read [j, j + ins_len) (collected right to left, stored back in read order, 1892-1893)
-                      unsigned need = 8u + (((unsigned) ins_len + 3u) & ~3u);
-                      unsigned at = atomicAdd (&ctr->ins_bytes, need);
-                      if (at + need <= ins_cap)
-                        {
-                          *(uint32_t *) (ins_log + at) = gpos + (uint32_t) i1;
-                          *(uint32_t *) (ins_log + at + 4) = (uint32_t) ins_len;
-                          for (int m = 0; m < ins_len; m++)
-                            {
-                              int jz = j + m;
-                              ins_log[at + 8 + m] = tk.orient ? pm_rc (tk.read[mm - 1 - jz]) : tk.read[jz];
-                            }
-                        }
-                      else
-                        atomicExch (&ctr->ins_overflow, 1u);
-                      atomicAdd (&cnt[5], 1u);
-                      incs++;
-                      nins++;
-                    }
-                  ins_len = 0;
-                }
-              else
-                ins_len++;
-              i = maxi;
-              j = maxj;
-              k = maxk;
-            }
-          if (ins_len > 0 && i >= 1)        // pemapper.c:1918-1958: attached to base[i1] of the last step
-            {
-              uint32_t *cnt = counts + ((size_t) gpos + (size_t) i1) * 6;
-              unsigned need = 8u + (((unsigned) ins_len + 3u) & ~3u);
-              unsigned at = atomicAdd (&ctr->ins_bytes, need);
-              if (at + need <= ins_cap)
-                {
-                  *(uint32_t *) (ins_log + at) = gpos + (uint32_t) i1;
-                  *(uint32_t *) (ins_log + at + 4) = (uint32_t) ins_len;
-                  for (int m = 0; m < ins_len; m++)
-                    {
-                      int jz = j + m;
-                      ins_log[at + 8 + m] = tk.orient ? pm_rc (tk.read[mm - 1 - jz]) : tk.read[jz];
-                    }
-                }
-              else
-                atomicExch (&ctr->ins_overflow, 1u);
-              atomicAdd (&cnt[5], 1u);
-              incs++;
-              nins++;
-            }
-          atomicAdd (&ctr->cells_trace, (unsigned long long) tk.nn * tk.mm);
-          atomicAdd (&ctr->pile_incs, incs);
-          if (nins)
-            atomicAdd (&ctr->n_ins, nins);
-        }
-    }
-}
+#include "pemap_sw.hip.h"

@@ -1,0 +1,586 @@
+// pemap_sw.hip.h -- Smith-Waterman scoring, pair selection and traceback/pileup kernels (gfx950, wave64).
+// Included at the end of pemap_kernels.hip.h.
+#pragma once
+
+// ============================================================================================================
+// K3: Smith-Waterman forward (smith_waterman_align, pemapper.c:1694-1748).
+//
+// PM_LPA = 8 lanes share one alignment, 8 alignments per wave.  The read is RIGHT-aligned on the 8 x W columns of
+// the lane group: read column j (1-based) sits at global column J = j - 1 + pad, pad = 8 W - mm; lane g owns
+// J = g W .. g W + W - 1 and walks the reference rows skewed by g (row i = step - g).  The only lane-to-lane traffic
+// per step is two doubles from lane g-1: S2 of the cell to the left and max3 of that cell (next row's diagonal).
+// Per owned column a lane keeps two doubles in registers: U1 = S1 of the row below and D = max(S0,S1,S2) of the cell.
+//
+//   S2[i][j] = max (S0[i][j-1]-go, S2[i][j-1]-ge)      S1[i][j] = max (S0[i-1][j]-go, S1[i-1][j]-ge)
+//   S0[i][j] = max3 (S.[i-1][j-1]) + match             (the reference adds the bonus to each plane before the max;
+//                                                        rounding is monotone, so max-then-add gives the same double)
+//
+// Right alignment puts the last read column -- the only one whose cells compete for the best score
+// (pemapper.c:1717-1742) -- at lane 7, column W-1 for every read length, so the tracker costs nothing per cell.  The
+// pad columns to the left of read column 1 are made to reproduce the column-0 border (S0 = 0, S1 = 0, S2 = -go,
+// pemapper.c:2062-2081) exactly: they hold a wildcard (bonus +1 against every reference byte), the pad column k to the
+// left of column 0 starts at D = -k, U1 = -1e30, and lane 0 is fed D = -pad, S2 = -1e30.  By induction S0 = -k there,
+// so column 0 presents max3 = 0 and hands S2 = max (0-go, .) = -go to column 1: small integers, exact in fp64.
+//
+// With DIRS the four comparisons the traceback will make at a cell (pemapper.c:1799-1831) are stored as one nibble:
+//   bit0 S1>S0   bit1 S2>max(S0,S1)   bit2 S1-ge > S0-go   bit3 S2-ge > S0-go
+// in the alignment's direction slab: dword ((g * tstride + step-1) * DW + c/8), nibble c%8 -- lane-major, so that the
+// diagonal walk of the traceback reads consecutive addresses.
+// ============================================================================================================
+#define PM_GO 2.0
+#define PM_GE (1.0 / 36.0)
+#define PM_NEGBIG (-1.0e30)
+
+__device__ __forceinline__ double pm_border (int j)     // S[k][0][j], j >= 1, pemapper.c:2077-2078
+{
+  return -(PM_GO + (double) (j - 1) * PM_GE);
+}
+
+// max3 of row 0 at read column j, extended to the pad columns j <= 0 (see above)
+__device__ __forceinline__ double pm_top (int j)
+{
+  return (j >= 1) ? pm_border (j) : (double) j;
+}
+
+__device__ __forceinline__ double pm_max (double a, double b)   // maxim(a,b), pemapper.c:36
+{
+  // (a > b) ? a : b.  No NaN and no negative zero can arise in this recurrence (finite constants, add/sub only), so the
+  // IEEE maximum is the same double: one v_max_f64 (built with -fno-honor-nans -mno-amdgpu-ieee: no canonicalising copy).
+  return __builtin_fmax (a, b);
+}
+
+// init_bonus_matrices, pemapper.c:2006-2035, as a predicate.  The row fill of iteration i precedes that iteration's
+// 'N'/'n' assignments, so row 'N' keeps 1.0 only for columns >= 'N': a reference N matches read N, T and lower case
+// but not read A/C/G; a read N matches everything.
+__device__ __forceinline__ bool pm_match (uint8_t r, uint8_t q, int bis)
+{
+  bool m = (r == q) | (q == 'N') | (q == 'n');
+  m |= (r == 'N') & (q >= 'N');
+  m |= (r == 'n') & (q >= 'n');
+  m |= (bis != 0) & ((r == 'C') | (r == 'c')) & ((q == 'T') | (q == 't'));
+  return m;
+}
+
+struct PmSwTask
+{
+  const uint8_t *read;             // forward read bytes
+  const uint8_t *ref;              // genome + window start
+  int mm, nn;
+  int orient;
+  bool valid;
+};
+
+__device__ __forceinline__ uint8_t pm_oriented (const uint8_t * read, int mm, int orient, int jz)
+{
+  return orient ? pm_rc (read[mm - 1 - jz]) : read[jz];
+}
+
+// one DP cell; after unrolling all state lives in registers
+template < bool DIRS > __device__ __forceinline__ void pm_cell (double &dg, double &s2, double &U1c, double &Dc, uint32_t mword, int bit,
+                                                                uint32_t & dword, int nibpos, double &o0, double &o1, double &o2)
+{
+  // bonus = match ? 1.0 : -1/3 (pemapper.c:2011-2019), assembled from the mask bit without a branch
+  const int t = __builtin_amdgcn_sbfe ((int) mword, bit, 1);            // 0 or -1
+  const uint32_t hi = ((uint32_t) t & 0x3FF00000u) | (~(uint32_t) t & 0xBFD55555u);
+  const uint32_t lo = ~(uint32_t) t & 0x55555555u;
+  const double bump = __hiloint2double ((int) hi, (int) lo);
+  const double s1 = U1c;
+  const double s0 = dg + bump;
+  dg = Dc;
+  const double a0 = s0 - PM_GO;
+  const double x1 = s1 - PM_GE;
+  const double x2 = s2 - PM_GE;
+  const double m01 = pm_max (s0, s1);
+  U1c = pm_max (a0, x1);
+  Dc = pm_max (m01, s2);
+  if (DIRS)
+    {
+      uint32_t nib = (s1 > s0 ? 1u : 0u) | (s2 > m01 ? 2u : 0u) | (x1 > a0 ? 4u : 0u) | (x2 > a0 ? 8u : 0u);
+      dword |= nib << nibpos;
+    }
+  o0 = s0;
+  o1 = s1;
+  o2 = s2;
+  s2 = pm_max (a0, x2);
+}
+
+template < int W > struct PmSwGeom
+{
+  static constexpr int DW = (W * 4 + 31) / 32;   // dwords of direction nibbles per lane per row
+};
+
+// match mask of one lane's columns against an arbitrary reference byte (IUPAC codes, lower case): rare, kept out of line
+template < int W > __device__ __noinline__ uint64_t pm_slow_mask (const uint8_t * read, int mm, int orient, int g, int pad, uint8_t r, int bis)
+{
+  uint64_t msel = 0;
+  for (int c = 0; c < W; c++)
+    {
+      const int jz = g * W + c - pad;
+      if (jz < 0 || pm_match (r, pm_oriented (read, mm, orient, jz), bis))
+        msel |= 1ull << c;
+    }
+  return msel;
+}
+
+template < int W, bool DIRS >
+__device__ __forceinline__ void pm_sw_forward (const PmSwTask & tk, int bis, int lane, int nn_max, uint32_t * slab, int tstride,
+                                               double &best, int &bk, int &bi)
+{
+  constexpr int DW = PmSwGeom < W >::DW;
+  int g = lane & (PM_LPA - 1);
+  // opaque to the optimiser: otherwise the 2 W border doubles below are computed once per kernel, kept live across the
+  // persistent task loop and double the register footprint
+  asm volatile ("":"+v" (g));
+  const int mm = tk.mm, nn = tk.valid ? tk.nn : 0;
+  const int pad = PM_LPA * W - mm;
+  // ---- match masks of this lane's W columns against reference A, C, G, T, N (bit c = column c of the lane)
+  uint64_t mk[5] = { 0, 0, 0, 0, 0 };
+#pragma unroll 1
+  for (int c = 0; c < W; c++)
+    {
+      const int jz = g * W + c - pad;      // 0-based read position, negative in the pad
+      const uint64_t bitc = 1ull << c;
+      if (jz < 0)
+        {
+          mk[0] |= bitc;
+          mk[1] |= bitc;
+          mk[2] |= bitc;
+          mk[3] |= bitc;
+          mk[4] |= bitc;
+        }
+      else if (tk.valid)
+        {
+          const uint8_t q = pm_oriented (tk.read, mm, tk.orient, jz);
+          mk[0] |= pm_match ('A', q, bis) ? bitc : 0ull;
+          mk[1] |= pm_match ('C', q, bis) ? bitc : 0ull;
+          mk[2] |= pm_match ('G', q, bis) ? bitc : 0ull;
+          mk[3] |= pm_match ('T', q, bis) ? bitc : 0ull;
+          mk[4] |= pm_match ('N', q, bis) ? bitc : 0ull;
+        }
+    }
+  double U1[W], D[W];
+#pragma unroll
+  for (int c = 0; c < W; c++)
+    {
+      const int j = g * W + c - pad + 1;   // 1-based read column, <= 0 in the pad
+      const double bj = pm_top (j);
+      D[c] = bj;
+      U1[c] = (j >= 1) ? pm_max (bj - PM_GO, bj - PM_GE) : PM_NEGBIG;
+    }
+  double Dprev = pm_top (g * W - pad);     // max3 of the cell left of this lane's first column, row 0
+  const double R2in0 = (pad > 0) ? PM_NEGBIG : pm_max (0.0 - PM_GO, -PM_GO - PM_GE);        // S2[i][1] from the border (2079-2081)
+  const double Dimp0 = pm_top (-pad);
+  double R2out = 0.0, Dout = 0.0;
+  double bst = pm_border (mm);     // S[0][0][mm], pemapper.c:1701-1703
+  int k_b = 0, i_b = 0;
+  const int nn1 = nn > 0 ? nn - 1 : 0;
+  uint8_t r_next = tk.ref[0];
+
+  for (int t = 1; t <= nn_max + PM_LPA - 1; t++)
+    {
+      const int i = t - g;
+      double R2in = __shfl_up (R2out, 1, PM_LPA);
+      double Dimp = __shfl_up (Dout, 1, PM_LPA);
+      R2in = (g == 0) ? R2in0 : R2in;
+      Dimp = (g == 0) ? Dimp0 : Dimp;
+      const bool act = (i >= 1) && (i <= nn);
+      const uint8_t r = r_next;
+      r_next = tk.ref[min (max (i, 0), nn1)];      // next step's reference byte (row i + 1), clamped into the window
+      if (act)
+        {
+          uint64_t msel = (r == 'A') ? mk[0] : (r == 'C') ? mk[1] : (r == 'G') ? mk[2] : (r == 'T') ? mk[3] : mk[4];
+          if (__builtin_expect (r != 'A' && r != 'C' && r != 'G' && r != 'T' && r != 'N', 0))
+            msel = pm_slow_mask < W > (tk.read, mm, tk.orient, g, pad, r, bis);
+          const uint32_t m0 = (uint32_t) msel, m1 = (uint32_t) (msel >> 32);
+          double dg = Dprev;
+          double s2 = R2in;
+          uint32_t dw[DW];
+#pragma unroll
+          for (int d = 0; d < DW; d++)
+            dw[d] = 0;
+          double o0 = 0.0, o1 = 0.0, o2 = 0.0;
+#pragma unroll
+          for (int c = 0; c < W; c++)
+            pm_cell < DIRS > (dg, s2, U1[c], D[c], (c < 32) ? m0 : m1, c & 31, dw[c >> 3], (c & 7) * 4, o0, o1, o2);
+          // The last column of lane 7 is read column mm: rows ascending, planes 0,1,2, strict '>' (pemapper.c:1724-1741).
+          // Every lane runs the selects (no branch); only lane 7's result is read.
+          const bool u0 = o0 > bst;
+          bst = u0 ? o0 : bst;
+          const bool u1 = o1 > bst;
+          bst = u1 ? o1 : bst;
+          const bool u2 = o2 > bst;
+          bst = u2 ? o2 : bst;
+          k_b = u2 ? 2 : (u1 ? 1 : (u0 ? 0 : k_b));
+          i_b = (u0 | u1 | u2) ? i : i_b;
+          R2out = s2;
+          Dout = D[W - 1];
+          Dprev = Dimp;
+          if (DIRS)
+            {
+              uint32_t *dst = slab + ((size_t) g * tstride + (t - 1)) * DW;
+#pragma unroll
+              for (int d = 0; d < DW; d++)
+                dst[d] = dw[d];
+            }
+        }
+    }
+  // hand the tracker's result to lane g == 0 of the group
+  const int srcl = lane | (PM_LPA - 1);
+  best = __shfl (bst, srcl);
+  bk = __shfl (k_b, srcl);
+  bi = __shfl (i_b, srcl);
+}
+
+__device__ __forceinline__ int pm_wave_max (int v)
+{
+  for (int o = 32; o > 0; o >>= 1)
+    v = max (v, __shfl_xor (v, o));
+  return v;
+}
+
+// One persistent wave per 8 problems.  DIRS: the problems are traceable alignments (the only hit of an end, or the winner
+// of a multi-hit end) and write their nibbles to the end's slab.
+template < int W, bool DIRS > __global__ __launch_bounds__ (64, PM_WAVES_PER_EU (W)) void pm_sw_kernel (PmIndex ix, PmBatch b, PmParams prm, PmHits h,
+                                                                                              const uint32_t * tasks,
+                                                                                              const unsigned *n_tasks_p, PmCounters * ctr,
+                                                                                              uint32_t * dirbuf, int tstride, int mm_fill)
+{
+  const int lane = threadIdx.x;
+  const int q = lane >> 3;
+  const unsigned n_tasks = *n_tasks_p;
+  const size_t slab_dwords = (size_t) PM_LPA * tstride * PmSwGeom < W >::DW;
+  for (unsigned base = blockIdx.x * 8u; base < n_tasks; base += gridDim.x * 8u)
+    {
+      PmSwTask tk;
+      tk.valid = (base + q) < n_tasks;
+      size_t o = 0;
+      tk.mm = mm_fill;
+      tk.nn = 0;
+      tk.orient = 0;
+      tk.read = b.reads1;
+      tk.ref = ix.genome;
+      uint32_t *slab = nullptr;
+      if (tk.valid)
+        {
+          o = tasks[base + q];
+          int end = (int) (o / PM_MAX_HITS);
+          tk.read = pm_read_ptr (b, end, &tk.mm);
+          tk.nn = h.nn[o];
+          if (tk.nn < 0)
+            tk.nn = 0;
+          tk.orient = h.orient[o];
+          tk.ref = ix.genome + h.gpos[o];
+          if (DIRS)
+            slab = dirbuf + (size_t) h.slot[end] * slab_dwords;
+        }
+      int nn_max = pm_wave_max (tk.nn);
+      double best;
+      int bk, bi;
+      pm_sw_forward < W, DIRS > (tk, prm.bisulfite, lane, nn_max, slab, tstride, best, bk, bi);
+      if (tk.valid && (lane & 7) == 0)
+        {
+          h.score[o] = best;
+          h.stk[o] = (uint8_t) bk;
+          h.sti[o] = (int16_t) bi;
+          atomicAdd (DIRS ? &ctr->cells_dirs : &ctr->cells_score, (unsigned long long) tk.nn * tk.mm);
+        }
+    }
+}
+
+// ============================================================================================================
+// K4: pair / single-end selection (pemapper.c:1084-1185 and find_mate_pairs 1313-1536), one lane per read (pair).
+// Output: the hit to trace per end (or none), the class, and m1/m2 = window start + start[1] + 1 (pemapper.c:1208, 1228).
+// ============================================================================================================
+__device__ int pm_single_select (const double *sc, int n, int len, double min_align, int *bsm)
+{
+  double good_score = len * min_align * 1.0;
+  double top_score = -PM_GO * len;
+  int top_score_count = 0;
+  for (int i = 0; i < n; i++)
+    {
+      double this_score = sc[i];
+      if (this_score > top_score && this_score >= good_score)
+        {
+          top_score = this_score;
+          top_score_count = 1;
+          *bsm = i;
+        }
+      else if ((fabs (this_score - top_score) < 0.0001) && (top_score_count > 0))
+        top_score_count++;
+    }
+  if (top_score_count == 0)
+    return 8;                   // NEITHER_MAP
+  if (top_score_count == 1)
+    return 2;                   // UNIQUE_SINGLE
+  return 7;                     // NON_NO
+}
+
+__global__ void pm_select_kernel (PmBatch b, PmParams prm, PmHits h, uint32_t * redo, uint32_t * wins, PmCounters * ctr, uint32_t * m1,
+                                  uint32_t * m2, int *mtype)
+{
+  int it = blockIdx.x * blockDim.x + threadIdx.x;
+  if (it >= b.n)
+    return;
+  const int e1 = b.paired ? 2 * it : it;
+  const int n1 = h.n_hits[e1];
+  const int n2 = b.paired ? h.n_hits[e1 + 1] : 0;
+  const size_t o1 = (size_t) e1 * PM_MAX_HITS, o2 = o1 + PM_MAX_HITS;
+  const double *s1 = h.score + o1, *s2 = h.score + o2;
+  const int l1 = b.len1[it], l3 = b.paired ? b.len2[it] : 0;
+  int use1 = -1, use2 = -1, code;
+  if (n1 > 0 && n2 == 0)
+    {
+      int bsm = 0;
+      code = pm_single_select (s1, n1, l1, prm.min_align, &bsm);
+      if (code == 2)
+        use1 = bsm;
+    }
+  else if (n2 > 0 && n1 == 0)
+    {
+      int bsm = 0;
+      code = pm_single_select (s2, n2, l3, prm.min_align, &bsm);
+      if (code == 2)
+        use2 = bsm;
+    }
+  else if (n1 > 0 && n2 > 0)
+    {
+      const double good1 = l1 * prm.min_align * 1.0, good2 = l3 * prm.min_align * 1.0;
+      int perfect = 0, slip_count = 0;
+      unsigned sm1 = 0xFFFFFFFFu, sm2 = 0xFFFFFFFFu;
+      double tot_best = -1e5;
+      for (int w1 = 0; w1 < n1; w1++)
+        if (s1[w1] >= good1)
+          for (int w2 = 0; w2 < n2; w2++)
+            if (s2[w2] >= good2)
+              {
+                long p1 = (long) h.spot[o1 + w1], p2 = (long) h.spot[o2 + w2];
+                long temp_dist = p1 > p2 ? p1 - p2 : p2 - p1;
+                int or1 = h.orient[o1 + w1], or2 = h.orient[o2 + w2];
+                if ((temp_dist >= prm.min_dist) && (temp_dist <= prm.max_dist) && (or1 != or2))
+                  {
+                    double inc = s1[w1] + s2[w2] - tot_best;
+                    if (inc > 0.001)
+                      {
+                        perfect = 1;
+                        sm1 = w1;
+                        sm2 = w2;
+                        tot_best = s1[w1] + s2[w2];
+                        slip_count = 1;
+                      }
+                    else if (inc > -0.001)
+                      {
+                        if (sm1 == (unsigned) w1 || sm2 == (unsigned) w2)
+                          slip_count++;
+                        perfect++;
+                      }
+                  }
+              }
+      code = 8;
+      if (perfect > 0)
+        {
+          use1 = (int) sm1;
+          use2 = (int) sm2;
+          if (perfect == 1)
+            code = 0;
+          else if (slip_count == perfect)
+            code = 1;
+          else
+            {
+              code = 4;
+              use1 = use2 = -1;
+            }
+        }
+      else
+        {
+          int best1 = 0, best2 = 0, m1_c = 0, m2_c = 0;
+          for (int i = 1; i < n1; i++)
+            if (s1[i] > s1[best1])
+              {
+                best1 = i;
+                m1_c = 1;
+              }
+            else if (s1[i] - s1[best1] > -0.0001)
+              m1_c++;
+          // the reference indexes smax2 with best1 here (pemapper.c:1468); smax2[k] for k >= n2 reads its -1.0 fill (1348-1351)
+          const double s2b1 = (best1 < n2) ? s2[best1] : -1.0;
+          for (int i = 1; i < n2; i++)
+            if (s2[i] > s2[best2])
+              {
+                best2 = i;
+                m2_c = 1;
+              }
+            else if (s2[i] - s2b1 > -0.0001)
+              m2_c++;
+          const bool ok2 = (s2[best2] >= good2) && (m2_c < 2);
+          if (s1[best1] >= good1)
+            {
+              if (m1_c < 2)
+                {
+                  use1 = best1;
+                  if (ok2)
+                    {
+                      use2 = best2;
+                      code = 3;
+                    }
+                  else
+                    code = 2;
+                }
+              else if (ok2)
+                {
+                  use2 = best2;
+                  code = 2;
+                }
+              else
+                code = 5;
+            }
+          else if (ok2)
+            {
+              use2 = best2;
+              code = 2;
+            }
+          else
+            code = 5;
+        }
+    }
+  else
+    code = 8;
+  uint32_t r1 = 0, r2 = 0;
+  for (int which = 0; which < 2; which++)
+    {
+      const int use = which ? use2 : use1;
+      if (use < 0)
+        continue;
+      const int e = e1 + which;
+      const size_t o = (which ? o2 : o1) + use;
+      const uint32_t r = (uint32_t) (h.gpos[o] + (uint32_t) h.sti[o]) + 1u;
+      if (which)
+        r2 = r;
+      else
+        r1 = r;
+      if (h.slot[e] < 0)
+        {
+          // winner of a multi-hit end: give it a slab and have it scored again with direction nibbles
+          h.slot[e] = (int) atomicAdd (&ctr->n_slots, 1u);
+          redo[atomicAdd (&ctr->n_redo, 1u)] = (uint32_t) o;
+        }
+      wins[atomicAdd (&ctr->n_wins, 1u)] = (uint32_t) o;
+    }
+  m1[it] = r1;
+  if (m2)
+    m2[it] = r2;
+  mtype[it] = code;
+}
+
+// ============================================================================================================
+// K5: traceback + pileup (smith_waterman_backtrack, pemapper.c:1752-1965).  One lane per winning alignment walks the
+// nibbles of its slab from the start cell to the first row or column.  Pileup counters are u32 in HBM updated with
+// no-return atomics (the reference's u16 counters wrap; the fetch truncates, which is the same arithmetic).
+// Insertions go to a byte log through an atomic cursor.
+// ============================================================================================================
+__device__ __forceinline__ void pm_log_insertion (uint8_t * ins_log, unsigned ins_cap, PmInsCursor * cur, uint32_t pos, const uint8_t * read,
+                                                  int mm, int orient, int j, int ins_len)
+{
+  // inserted bases = oriented read [j, j + ins_len): collected right to left, stored back in read order (pemapper.c:1892-1893)
+  unsigned need = 8u + (((unsigned) ins_len + 3u) & ~3u);
+  unsigned at = atomicAdd (&cur->ins_bytes, need);
+  if (at + need <= ins_cap)
+    {
+      *(uint32_t *) (ins_log + at) = pos;
+      *(uint32_t *) (ins_log + at + 4) = (uint32_t) ins_len;
+      for (int m = 0; m < ins_len; m++)
+        ins_log[at + 8 + m] = pm_oriented (read, mm, orient, j + m);
+    }
+  else
+    atomicExch (&cur->ins_overflow, 1u);
+}
+
+template < int W > __global__ __launch_bounds__ (256) void pm_walk_kernel (PmBatch b, PmHits h, const uint32_t * wins, PmCounters * ctr,
+                                                                           PmInsCursor * cur, const uint32_t * dirbuf, int tstride,
+                                                                           uint32_t * counts, uint8_t * ins_log, unsigned ins_cap)
+{
+  constexpr int DW = PmSwGeom < W >::DW;
+  const unsigned n_wins = ctr->n_wins;
+  const size_t slab_dwords = (size_t) PM_LPA * tstride * DW;
+  unsigned long long incs = 0, nins = 0;
+  for (unsigned w = blockIdx.x * blockDim.x + threadIdx.x; w < n_wins; w += gridDim.x * blockDim.x)
+    {
+      const size_t o = wins[w];
+      const int end = (int) (o / PM_MAX_HITS);
+      int mm;
+      const uint8_t *read = pm_read_ptr (b, end, &mm);
+      const int orient = h.orient[o];
+      const uint32_t gpos = h.gpos[o];
+      const uint32_t *slab = dirbuf + (size_t) h.slot[end] * slab_dwords;
+      const int pad = PM_LPA * W - mm;
+      int k = h.stk[o], i = h.sti[o], j = mm;
+      int i1 = 0, ins_len = 0;
+      while (i > 0 && j > 0)
+        {
+          i1 = i - 1;
+          const int j1 = j - 1;
+          int maxi, maxj, ci, cj;
+          // (ci, cj): the cell whose comparisons decide the predecessor plane
+          if (k == 0) { maxi = i1; maxj = j1; ci = i1; cj = j1; }
+          else if (k == 2) { maxi = i; maxj = j1; ci = i; cj = j1; }
+          else { maxi = i1; maxj = j; ci = i1; cj = j; }
+          int maxk = 0;
+          if (ci >= 1 && cj >= 1)
+            {
+              const int J = cj - 1 + pad, gg = J / W, c = J - gg * W;
+              const uint32_t wv = slab[((size_t) gg * tstride + (ci + gg - 1)) * DW + (c >> 3)];
+              const uint32_t nib = (wv >> ((c & 7) * 4)) & 0xFu;
+              if (k == 0)
+                maxk = (nib & 2u) ? 2 : ((nib & 1u) ? 1 : 0);
+              else if (k == 2)
+                maxk = (nib & 8u) ? 2 : 0;
+              else
+                maxk = (nib & 4u) ? 1 : 0;
+            }
+          // on the borders the walk ends after this step (i or j becomes 0) and maxk is never used
+          uint32_t *cnt = counts + ((size_t) gpos + (size_t) i1) * 6;
+          if (maxi != i)
+            {
+              if (maxj != j)
+                {
+                  const uint8_t ch = pm_oriented (read, mm, orient, j1);
+                  const int slot = (ch == 'A') ? 0 : (ch == 'C') ? 1 : (ch == 'G') ? 2 : (ch == 'T') ? 3 : -1;   // pemapper.c:1850-1857
+                  if (slot >= 0)
+                    {
+                      atomicAdd (&cnt[slot], 1u);
+                      incs++;
+                    }
+                }
+              else
+                {
+                  atomicAdd (&cnt[4], 1u);
+                  incs++;
+                }
+              if (ins_len > 0)
+                {
+                  pm_log_insertion (ins_log, ins_cap, cur, gpos + (uint32_t) i1, read, mm, orient, j, ins_len);
+                  atomicAdd (&cnt[5], 1u);
+                  incs++;
+                  nins++;
+                }
+              ins_len = 0;
+            }
+          else
+            ins_len++;
+          i = maxi;
+          j = maxj;
+          k = maxk;
+        }
+      if (ins_len > 0 && i >= 1)    // pemapper.c:1918-1958: attached to base[i1] of the last step
+        {
+          uint32_t *cnt = counts + ((size_t) gpos + (size_t) i1) * 6;
+          pm_log_insertion (ins_log, ins_cap, cur, gpos + (uint32_t) i1, read, mm, orient, j, ins_len);
+          atomicAdd (&cnt[5], 1u);
+          incs++;
+          nins++;
+        }
+    }
+  if (incs)
+    atomicAdd (&ctr->pile_incs, incs);
+  if (nins)
+    atomicAdd (&ctr->n_ins, nins);
+}

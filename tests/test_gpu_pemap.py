@@ -107,6 +107,7 @@ def test_hits_and_scores_match_oracle(dev):
     assert multi > 10
     stats, times = dev.run_stats()
     assert stats["ends"] == 2 * n and stats["sw_score"] == int(dbg["n_hits"].sum())
+    assert stats["walks"] == int((m1 > 0).sum() + (m2 > 0).sum())
 
 
 def test_rerun_is_additive_and_slices_compose(dev):
