@@ -499,7 +499,7 @@ static int ensure_work (pemap_dev * d, int n_ends)
       d->cap_ends = n_ends;
     }
   if (!d->d_seed_scratch)
-    TRY (dev_alloc (d, &d->d_seed_scratch, (size_t) d->seed_grid * 2 * PM_MAX_SEG * PM_SEG_LIST_MAX));
+    TRY (dev_alloc (d, &d->d_seed_scratch, (size_t) d->seed_grid * 4 * PM_MAX_SEG * PM_SEG_LIST_MAX));
   size_t need = (size_t) n_ends * slab_dwords_for (d->max_len_staged);
   if (need > d->dirbuf_dwords)
     {
@@ -585,8 +585,18 @@ template < int W > static void launch_chunk (pemap_dev * d, const RunCtx & c, ui
   const int n_ends = c.b.n_ends;
   hipEventRecord (d->ev[0], d->stream);
   int sgrid = d->seed_grid < n_ends ? d->seed_grid : n_ends;
-  hipLaunchKernelGGL (pm_seed_kernel, dim3 (sgrid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, d->hits, d->d_tasks_s, d->d_tasks_m, d->d_ctr,
-                      d->d_seed_scratch);
+  // segments of the longest read: len/16 (+1 unless divisible), pemapper.c:1573-1587
+  const int segs = c.L / 16 + ((c.L % 16) ? 1 : 0);
+  const char *pl = getenv ("PEMAP_SEED_PHASE");      // timing probe only: results are meaningless when set
+  const int phase_limit = pl ? atoi (pl) : 0;
+#define PM_SEED(SM) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_seed_kernel < SM >), dim3 (sgrid), dim3 (PM_SEED_THREADS), 0, d->stream, c.ix, c.b, c.prm, \
+                                        d->hits, d->d_tasks_s, d->d_tasks_m, d->d_ctr, d->d_seed_scratch, phase_limit)
+  if (segs <= 7) PM_SEED (7);
+  else if (segs <= 10) PM_SEED (10);
+  else if (segs <= 13) PM_SEED (13);
+  else if (segs <= 16) PM_SEED (16);
+  else PM_SEED (19);
+#undef PM_SEED
   hipEventRecord (d->ev[1], d->stream);
   hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, true >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, d->hits,
                       d->d_tasks_s, &d->d_ctr->n_tasks_s, d->d_ctr, d->d_dirbuf, c.tstride, c.L);

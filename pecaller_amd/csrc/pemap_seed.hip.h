@@ -1,0 +1,484 @@
+// pemap_seed.hip.h -- K1/K2: seed gather and diagonal vote (initial_map / find_matches) on gfx950.
+// Included from pemap_kernels.hip.h.
+#pragma once
+
+// One 256-thread workgroup per read-end, persistent over ends.  Template SMAX bounds the number of 16-base segments
+// and sizes the LDS arrays.
+//
+// Phases per read-end:
+//   1. both strands' 2 x S x 49 bucket look-ups in pos_index, all in flight at once (the HBM-random phase);
+//   2. per segment: emptied if any bucket >= too_many_spots, else offsets of its 49 slices;
+//   3. both strands' bucket slices copied from .mdx, one position per thread and round; every position is stored as its
+//      DIAGONAL key  m + 300 - offset(segment)  (read start implied by that seed) together with its segment number;
+//   4. per strand, find_matches (pemapper.c:2189-2289) WITHOUT sorting the lists: the reference counts, per anchor, the
+//      later segments that hold a position within max_off of the anchor's diagonal (tot_found) and only acts on anchors
+//      whose count reaches the running best.  A 2048-bin LDS table of segment masks over diagonal/16 discards the
+//      anchors that cannot reach it (random bucket hits: almost all), the survivors get their exact count by scanning
+//      the strand's positions, are put in the walk's order (segment, position) and ONE wave replays the walk's state
+//      machine on them -- reset on '>', append on '==' if the diagonal is new, stop at max_hits tied hits.
+#define PM_SEED_THREADS 256
+#define PM_SEED_TABLE 2048
+#define PM_DIAG_BIAS 300
+
+template < int SMAX > struct __align__ (8) PmSeedShared
+{
+  static constexpr int NITEMS = 2 * SMAX * 49;            // both strands
+  struct Items
+  {
+    uint32_t it_start[NITEMS];          // pos_index[k-mer]
+    uint16_t it_len[NITEMS];            // 0xFFFF = bucket >= too_many_spots
+    uint16_t it_off[NITEMS];            // exclusive prefix of the lengths inside the segment
+  };
+  union
+  {
+    Items it;                           // phases 1-3
+    uint32_t table[PM_SEED_TABLE];      // phase 4: segment masks per diagonal bin
+  } u;
+  uint32_t ekey[2][PM_SEED_CAP];        // diagonal keys of the gathered positions, per strand
+  uint32_t hits[PM_MAX_HITS];
+  uint32_t kmer[2 * SMAX];
+  int seg_cnt[2 * SMAX];
+  int seg_base[2][SMAX + 1];
+  int offsets[SMAX + 1];
+  int state[4];                         // min_match, tot_hits, go_on, task base
+  unsigned n_surv;
+  uint16_t surv[PM_SEED_CAP];           // surviving anchors (indices into ekey), then the same in walk order
+  uint16_t order[PM_SEED_CAP];
+  uint16_t hits_off[PM_MAX_HITS];
+  uint8_t eseg[2][PM_SEED_CAP];
+  uint8_t tfs[PM_SEED_CAP];             // exact tot_found of the survivors
+  uint8_t hits_or[PM_MAX_HITS];
+  uint8_t seq[2][320];
+};
+
+__device__ __forceinline__ unsigned pm_bin_hash (uint32_t bin)
+{
+  return (bin * 2654435761u) >> 21;     // 11 bits
+}
+
+// find_matches for one strand on unsorted diagonal keys; see the header comment.  All 256 threads enter; returns through
+// sh.state.  IdxT = uint16_t (LDS arrays) or uint32_t (global spill arrays of a strand with more than PM_SEED_CAP positions).
+template < class SH, class IdxT >
+__device__ void pm_vote_strand (SH & sh, const uint32_t * ekey, const uint8_t * eseg, IdxT * surv, IdxT * order, uint8_t * tfs, int T,
+                                const int *seg_cnt, int total_cuts, int max_off, int &min_match, int &tot, bool & go_on, uint8_t strand)
+{
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // pemapper.c:2200-2207: nothing is searched (and earlier hits are dropped) when every segment holds more than max_hits positions
+  unsigned min_spots = 10000;
+  for (int s = 0; s <= total_cuts; s++)
+    min_spots = min (min_spots, (unsigned) seg_cnt[s]);
+  if (min_spots > PM_MAX_HITS)
+    {
+      tot = 0;
+      return;
+    }
+  for (int i = tid; i < PM_SEED_TABLE; i += PM_SEED_THREADS)
+    sh.u.table[i] = 0;
+  if (tid == 0)
+    sh.n_surv = 0;
+  __syncthreads ();
+  for (int p = tid; p < T; p += PM_SEED_THREADS)
+    atomicOr (&sh.u.table[pm_bin_hash (ekey[p] >> 4)], 1u << eseg[p]);
+  __syncthreads ();
+  // an anchor of segment `loop` is only visited while loop <= 1 + max_depth - min_match (pemapper.c:2216; the bound only shrinks)
+  const int loop_max = 1 + total_cuts - min_match;
+  for (int p = tid; p < T; p += PM_SEED_THREADS)
+    {
+      const uint32_t bin = ekey[p] >> 4;
+      const uint32_t mask = sh.u.table[pm_bin_hash (bin - 1u)] | sh.u.table[pm_bin_hash (bin)] | sh.u.table[pm_bin_hash (bin + 1u)];
+      if ((int) eseg[p] <= loop_max && __popc (mask) >= min_match)
+        surv[atomicAdd (&sh.n_surv, 1u)] = (IdxT) p;
+    }
+  __syncthreads ();
+  const int ns = (int) sh.n_surv;
+  // exact tot_found (pemapper.c:2241-2249): 1 + number of LATER segments with a position whose diagonal differs by less than max_off
+  for (int sv = wv; sv < ns; sv += PM_SEED_THREADS / 64)
+    {
+      const int a = (int) surv[sv];
+      const int64_t ka = (int64_t) ekey[a];
+      const int sa = eseg[a];
+      uint32_t bits = 0;
+      for (int x = lane; x < T; x += 64)
+        {
+          const int64_t d = (int64_t) ekey[x] - ka;
+          if ((int) eseg[x] > sa && d > -(int64_t) max_off && d < (int64_t) max_off)
+            bits |= 1u << eseg[x];
+        }
+      for (int o = 32; o > 0; o >>= 1)
+        bits |= __shfl_xor (bits, o);
+      if (lane == 0)
+        tfs[sv] = (uint8_t) (1 + __popc (bits));
+    }
+  __syncthreads ();
+  // walk order: segment ascending, position ascending inside a segment (same offset, so diagonal ascending)
+  for (int sv = tid; sv < ns; sv += PM_SEED_THREADS)
+    {
+      const int a = (int) surv[sv];
+      const uint64_t ck = ((uint64_t) eseg[a] << 32) | ekey[a];
+      int rank = 0;
+      for (int y = 0; y < ns; y++)
+        {
+          const int bq = (int) surv[y];
+          rank += ((((uint64_t) eseg[bq] << 32) | ekey[bq]) < ck);
+        }
+      order[rank] = (IdxT) sv;
+    }
+  __syncthreads ();
+  if (tid < 64)
+    {
+      bool more = true, done = false;
+      int cur_loop = -1;
+      for (int i0 = 0; i0 < ns && !done; i0 += 64)
+        {
+          const int i = i0 + lane;
+          const bool act = i < ns;
+          const int sv = act ? (int) order[i] : 0;
+          const int tf = act ? (int) tfs[sv] : 0;
+          const int a = act ? (int) surv[sv] : 0;
+          unsigned long long cand = __ballot (act && tf >= min_match);
+          while (cand)
+            {
+              const int l = __ffsll ((long long) cand) - 1;
+              cand &= cand - 1;
+              const int tfl = __shfl (tf, l);
+              const int al = __shfl (a, l);
+              const int loop = eseg[al];
+              if (loop != cur_loop)
+                {
+                  // the walk's loop bound is tested when a segment is entered, not inside it (pemapper.c:2216)
+                  if (loop > 1 + total_cuts - min_match)
+                    {
+                      done = true;
+                      break;
+                    }
+                  cur_loop = loop;
+                }
+              const int off_a = sh.offsets[loop];
+              const uint32_t ml = ekey[al] - (uint32_t) (PM_DIAG_BIAS - off_a);      // the position itself
+              if (tfl > min_match)
+                {
+                  min_match = tfl;
+                  if (lane == 0)
+                    {
+                      sh.hits[0] = ml;
+                      sh.hits_off[0] = (uint16_t) off_a;
+                      sh.hits_or[0] = strand;
+                    }
+                  tot = 1;
+                  __builtin_amdgcn_fence (__ATOMIC_SEQ_CST, "wavefront");
+                  __builtin_amdgcn_wave_barrier ();
+                }
+              else if (tfl == min_match)
+                {
+                  if (tot < PM_MAX_HITS)
+                    {
+                      const uint32_t diag = ml - (uint32_t) off_a;        // unsigned, pemapper.c:2268
+                      bool dup = false;
+                      for (int k = lane; k < tot; k += 64)
+                        if (sh.hits[k] - (uint32_t) sh.hits_off[k] == diag)
+                          dup = true;
+                      if (!__any (dup))
+                        {
+                          if (lane == 0)
+                            {
+                              sh.hits[tot] = ml;
+                              sh.hits_off[tot] = (uint16_t) off_a;
+                              sh.hits_or[tot] = strand;
+                            }
+                          tot++;
+                          __builtin_amdgcn_fence (__ATOMIC_SEQ_CST, "wavefront");
+                          __builtin_amdgcn_wave_barrier ();
+                        }
+                    }
+                  else
+                    {
+                      more = false; // the reference returns with a full list (pemapper.c:2283-2284)
+                      done = true;
+                      break;
+                    }
+                }
+            }
+        }
+      if (tot >= PM_MAX_HITS)
+        more = false;
+      if (lane == 0)
+        {
+          sh.state[0] = min_match;
+          sh.state[1] = tot;
+          sh.state[2] = more ? 1 : 0;
+        }
+    }
+  __syncthreads ();
+  min_match = sh.state[0];
+  tot = sh.state[1];
+  go_on = sh.state[2] != 0;
+}
+
+template < int SMAX > __global__ __launch_bounds__ (PM_SEED_THREADS) void pm_seed_kernel (PmIndex ix, PmBatch b, PmParams prm, PmHits h,
+                                                                                          uint32_t * tasks_s, uint32_t * tasks_m,
+                                                                                          PmCounters * ctr, uint32_t * gscratch, int phase_limit)
+{
+  typedef PmSeedShared < SMAX > SH;
+  __shared__ SH sh;
+  constexpr int NI = (SH::NITEMS + PM_SEED_THREADS - 1) / PM_SEED_THREADS;   // look-ups per thread
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int idepth = ix.idepth;
+  const int max_off = max (2, idepth - 4);
+  // per-workgroup spill area for the rare strand whose positions exceed the LDS capacity: keys, survivors, order (u32 each),
+  // segment numbers and counts (u8 each), PM_MAX_SEG * PM_SEG_LIST_MAX entries each
+  constexpr size_t GN = (size_t) PM_MAX_SEG * PM_SEG_LIST_MAX;
+  uint32_t *g_key = gscratch + (size_t) blockIdx.x * 4 * GN;
+  uint32_t *g_surv = g_key + GN;
+  uint32_t *g_order = g_surv + GN;
+  uint8_t *g_seg = (uint8_t *) (g_order + GN);
+  uint8_t *g_tfs = g_seg + GN;
+
+  for (int e = blockIdx.x; e < b.n_ends; e += gridDim.x)
+    {
+      __syncthreads ();
+      int len;
+      const uint8_t *src = pm_read_ptr (b, e, &len);
+      // ---- read + reverse complement into LDS; N filter (pemapper.c:1552-1559: upper-case 'N' only)
+      int isn = 0;
+      for (int i = tid; i < len; i += PM_SEED_THREADS)
+        {
+          uint8_t c = src[i];
+          sh.seq[0][i] = c;
+          sh.seq[1][len - 1 - i] = pm_rc (c);
+          isn += (c == 'N');
+        }
+      // ---- segment offsets (pemapper.c:1573-1587)
+      int total_cuts = len / idepth;
+      if (len % idepth == 0)
+        total_cuts--;
+      if (total_cuts > SMAX - 1)
+        total_cuts = SMAX - 1;      // cannot happen: the host picks SMAX from the longest staged read
+      const int S = total_cuts + 1;
+      if (tid <= total_cuts)
+        sh.offsets[tid] = (tid < total_cuts || total_cuts == 0) ? tid * idepth : len - idepth;
+      int n_count = __syncthreads_count (isn);
+      // __syncthreads_count counts threads, a thread can hold several N only for reads longer than 256: add the exact sum
+      if (len > PM_SEED_THREADS)
+        {
+          n_count = 0;
+          for (int i = 0; i < len; i++)
+            n_count += (sh.seq[0][i] == 'N');
+        }
+      int tot = 0;
+      if (n_count < 1 + len / 10)
+        {
+          // ---- 16-mers of the segments of both strands (convert_seq_int, pemapper.c:2408-2423)
+          if (tid < 2 * S)
+            {
+              const int strand = tid / S, seg = tid - strand * S;
+              const uint8_t *p = &sh.seq[strand][sh.offsets[seg]];
+              uint32_t k = 0;
+              for (int i = 0; i < 16; i++)
+                k = (k << 2) + pm_code (p[i], prm.bisulfite);
+              sh.kmer[tid] = k;
+            }
+          __syncthreads ();
+          // ---- 49 bucket look-ups per segment, both strands, all in flight at once (get_mers, pemapper.c:2158-2165;
+          //      `which + 1` wraps in 32 bits)
+          {
+            uint32_t v0[NI], v1[NI];
+#pragma unroll
+            for (int r = 0; r < NI; r++)
+              {
+                const int x = tid + r * PM_SEED_THREADS;
+                v0[r] = v1[r] = 0;
+                if (x < 2 * S * 49)
+                  {
+                    const int sg = x / 49, j = x - sg * 49;
+                    const uint32_t nb = pm_neighbour (sh.kmer[sg], j);
+                    v0[r] = ix.pos_index[nb];
+                    v1[r] = ix.pos_index[(uint32_t) (nb + 1u)];
+                  }
+              }
+#pragma unroll
+            for (int r = 0; r < NI; r++)
+              {
+                const int x = tid + r * PM_SEED_THREADS;
+                if (x < 2 * S * 49)
+                  {
+                    const uint32_t ln = v1[r] - v0[r];
+                    sh.u.it.it_start[x] = v0[r];
+                    sh.u.it.it_len[x] = (ln >= PM_TOO_MANY) ? 0xFFFF : (uint16_t) ln;
+                  }
+              }
+          }
+          __syncthreads ();
+          if (phase_limit == 1)
+            continue;           // timing probe (PEMAP_SEED_PHASE): stop after the look-ups
+          // ---- a segment with any bucket >= too_many_spots is emptied (pemapper.c:1602-1606)
+          if (tid < 2 * S)
+            {
+              int sum = 0;
+              bool bad = false;
+              for (int j = 0; j < 49; j++)
+                {
+                  const uint16_t ln = sh.u.it.it_len[tid * 49 + j];
+                  sh.u.it.it_off[tid * 49 + j] = (uint16_t) sum;
+                  if (ln == 0xFFFF)
+                    bad = true;
+                  else
+                    sum += ln;
+                }
+              sh.seg_cnt[tid] = bad ? 0 : sum;
+            }
+          int min_match = max (1, total_cuts);       // pemapper.c:1642-1645
+          if (total_cuts > 4)
+            min_match = (4 * total_cuts) / 5;
+          min_match = min (min_match, 4);
+          __syncthreads ();
+          // ---- both strands' bucket slices, one position per thread and round (each slice is ascending in .mdx)
+          if (tid < 2)
+            {
+              int acc = 0;
+              for (int s = 0; s < S; s++)
+                {
+                  sh.seg_base[tid][s] = acc;
+                  acc += sh.seg_cnt[tid * S + s];
+                }
+              sh.seg_base[tid][S] = acc;
+              atomicAdd (&ctr->positions, (unsigned long long) acc);
+            }
+          __syncthreads ();
+          const int T0 = sh.seg_base[0][S], T1 = sh.seg_base[1][S];
+          // a strand with more positions than the LDS arrays hold goes to the workgroup's global spill area (the two
+          // strands are then gathered one after the other, just before each is voted on)
+          const bool lds0 = T0 <= PM_SEED_CAP, lds1 = T1 <= PM_SEED_CAP;
+          for (int pp = tid; pp < (lds0 ? T0 : 0) + (lds1 ? T1 : 0); pp += PM_SEED_THREADS)
+            {
+              const int strand = (lds0 && pp < T0) ? 0 : 1;
+              const int p = (strand == 1 && lds0) ? pp - T0 : pp;
+              int seg = 0;
+              while (p >= sh.seg_base[strand][seg + 1])
+                seg++;
+              const int q = p - sh.seg_base[strand][seg];
+              const int x0 = (strand * S + seg) * 49;
+              int lo = 0, hi = 48;          // largest j with it_off[j] <= q: that slice holds position q
+              while (lo < hi)
+                {
+                  const int mid = (lo + hi + 1) >> 1;
+                  if ((int) sh.u.it.it_off[x0 + mid] <= q)
+                    lo = mid;
+                  else
+                    hi = mid - 1;
+                }
+              const uint32_t m = ix.mers[sh.u.it.it_start[x0 + lo] + (uint32_t) (q - (int) sh.u.it.it_off[x0 + lo])];
+              sh.ekey[strand][p] = m + (uint32_t) (PM_DIAG_BIAS - sh.offsets[seg]);
+              sh.eseg[strand][p] = (uint8_t) seg;
+            }
+          if (phase_limit == 2)
+            continue;
+          bool go_on = true;
+          for (int strand = 0; strand < 2 && go_on; strand++)
+            {
+              const int T = strand ? T1 : T0;
+              const bool in_lds = strand ? lds1 : lds0;
+              if (!in_lds)
+                {
+                  // spill path: the items are still needed, so this strand is gathered now and the table (which aliases the
+                  // items) is rebuilt from scratch afterwards; strand 1's items survive strand 0's vote only if strand 0 did
+                  // not use the table, so an oversized strand 1 after a voted strand 0 re-does its look-ups
+                  if (strand == 1)
+                    {
+                      __syncthreads ();
+                      for (int x = tid; x < S * 49; x += PM_SEED_THREADS)
+                        {
+                          const int sg = S + x / 49, j = x % 49;
+                          const uint32_t nb = pm_neighbour (sh.kmer[sg], j);
+                          const uint32_t i0 = ix.pos_index[nb];
+                          const uint32_t ln = ix.pos_index[(uint32_t) (nb + 1u)] - i0;
+                          sh.u.it.it_start[S * 49 + x] = i0;
+                          sh.u.it.it_len[S * 49 + x] = (ln >= PM_TOO_MANY) ? 0xFFFF : (uint16_t) ln;
+                        }
+                      __syncthreads ();
+                      if (tid < S)
+                        {
+                          int sum = 0;
+                          for (int j = 0; j < 49; j++)
+                            {
+                              const uint16_t ln = sh.u.it.it_len[(S + tid) * 49 + j];
+                              sh.u.it.it_off[(S + tid) * 49 + j] = (uint16_t) sum;
+                              if (ln != 0xFFFF)
+                                sum += ln;
+                            }
+                        }
+                    }
+                  __syncthreads ();
+                  for (int p = tid; p < T; p += PM_SEED_THREADS)
+                    {
+                      int seg = 0;
+                      while (p >= sh.seg_base[strand][seg + 1])
+                        seg++;
+                      const int q = p - sh.seg_base[strand][seg];
+                      const int x0 = (strand * S + seg) * 49;
+                      int lo = 0, hi = 48;
+                      while (lo < hi)
+                        {
+                          const int mid = (lo + hi + 1) >> 1;
+                          if ((int) sh.u.it.it_off[x0 + mid] <= q)
+                            lo = mid;
+                          else
+                            hi = mid - 1;
+                        }
+                      const uint32_t m = ix.mers[sh.u.it.it_start[x0 + lo] + (uint32_t) (q - (int) sh.u.it.it_off[x0 + lo])];
+                      g_key[p] = m + (uint32_t) (PM_DIAG_BIAS - sh.offsets[seg]);
+                      g_seg[p] = (uint8_t) seg;
+                    }
+                }
+              __syncthreads ();
+              if (in_lds)
+                pm_vote_strand < SH, uint16_t > (sh, sh.ekey[strand], sh.eseg[strand], sh.surv, sh.order, sh.tfs, T, &sh.seg_cnt[strand * S],
+                                                 total_cuts, max_off, min_match, tot, go_on, (uint8_t) strand);
+              else
+                pm_vote_strand < SH, uint32_t > (sh, g_key, g_seg, g_surv, g_order, g_tfs, T, &sh.seg_cnt[strand * S], total_cuts, max_off,
+                                                 min_match, tot, go_on, (uint8_t) strand);
+              if (tot >= PM_MAX_HITS)
+                go_on = false;
+            }
+        }
+      // ---- hits -> spots and SW windows (pemapper.c:1664-1669, 1047-1081)
+      // an end with one hit is scored once, with direction nibbles, into its own slab; ends with several hits are
+      // scored without, and only the winner is scored again (pm_select_kernel)
+      if (tid == 0)
+        {
+          unsigned tb = 0;
+          h.n_hits[e] = tot;
+          h.slot[e] = (tot == 1) ? (int) atomicAdd (&ctr->n_slots, 1u) : -1;
+          if (tot == 1)
+            tb = atomicAdd (&ctr->n_tasks_s, 1u);
+          else if (tot > 1)
+            tb = atomicAdd (&ctr->n_tasks_m, (unsigned) tot);
+          sh.state[3] = (int) tb;
+        }
+      __syncthreads ();
+      const unsigned tbase = (unsigned) sh.state[3];
+      uint32_t *tasks = (tot == 1) ? tasks_s : tasks_m;
+      for (int t = tid; t < tot; t += PM_SEED_THREADS)
+        {
+          long temp = (long) sh.hits[t] - (long) sh.hits_off[t];
+          uint32_t spot = (uint32_t) (temp > 0 ? temp : 0);
+          int chrom = pm_find_chrom (ix.contig_starts, ix.n_contigs, spot);
+          unsigned extra = 15u * (unsigned) chrom;
+          long tt = (long) extra + (long) spot - (long) PM_SLOP;
+          if (tt < 0)
+            tt = 0;
+          unsigned cs0 = ix.contig_starts[chrom] + extra;
+          unsigned start_match = ((long) cs0 > tt) ? cs0 : (unsigned) tt;
+          unsigned e1 = ix.contig_starts[chrom + 1] + extra;
+          unsigned e2 = extra + spot + (unsigned) len + PM_SLOP;
+          unsigned end_match = e1 < e2 ? e1 : e2;
+          int blen = (int) (1u + end_match - start_match);
+          size_t o = (size_t) e * PM_MAX_HITS + t;
+          h.spot[o] = spot;
+          h.orient[o] = sh.hits_or[t];
+          h.gpos[o] = start_match;
+          h.nn[o] = (int16_t) blen;
+          tasks[tbase + t] = (uint32_t) o;
+        }
+    }
+}
