@@ -176,7 +176,8 @@ def main():
         S = L // 16 + (0 if L % 16 == 0 else 1)
         n_single = (agg["sw_dirs"] - agg["redo"]) / ends      # problems scored once, with nibbles
         n_multi = (agg["sw_score"] - (agg["sw_dirs"] - agg["redo"])) / ends
-        slab = 8 * (L + 29) * ((((L + 7) // 8) * 4 + 31) // 32) * 4
+        W = 13 if L <= 104 else 19 if L <= 152 else 26 if L <= 208 else 32 if L <= 256 else 38
+        slab = 8 * ((L + 29 + 15) // 16 * 16) * ((W * 4 + 31) // 32) * 4
         per_end = {
             "seed": S * 49 * 2 * 8 + 4.0 * P_e + L,                     # pos_index pairs + bucket payload + the read
             "sw_single": n_single * (L + 21 + L + slab),                # window + read in, direction nibbles out

@@ -154,7 +154,7 @@ extern "C" int pemap_dev_create (pemap_dev ** out, int device_id)
     }
   int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   d->seed_grid = cus * 8;
-  d->sw_grid = cus * 8;
+  d->sw_grid = cus * 16;
   if (hipStreamCreateWithFlags (&d->stream, hipStreamNonBlocking) != hipSuccess)
     {
       delete d;
@@ -461,10 +461,16 @@ static int pick_w (int L)
   return L <= 8 * 13 ? 13 : L <= 8 * 19 ? 19 : L <= 8 * 26 ? 26 : L <= 8 * 32 ? 32 : 38;
 }
 
+// rows of one lane's region in a direction slab: window rows + the 7 skew steps, rounded up to the 16-step flush unit
+static int tstride_for (int L)
+{
+  return (L + 21 + PM_LPA + 15) & ~15;
+}
+
 static size_t slab_dwords_for (int L)
 {
   int W = pick_w (L);
-  return (size_t) PM_LPA * (size_t) (L + 21 + PM_LPA) * (size_t) ((W * 4 + 31) / 32);
+  return (size_t) PM_LPA * (size_t) tstride_for (L) * (size_t) ((W * 4 + 31) / 32);
 }
 
 // device bytes the direction slabs of one chunk may take (one slab per read-end); PEMAP_DIR_BUDGET_GB overrides
@@ -500,7 +506,7 @@ static int ensure_work (pemap_dev * d, int n_ends)
     }
   if (!d->d_seed_scratch)
     TRY (dev_alloc (d, &d->d_seed_scratch, (size_t) d->seed_grid * 4 * PM_MAX_SEG * PM_SEG_LIST_MAX));
-  size_t need = (size_t) n_ends * slab_dwords_for (d->max_len_staged);
+  size_t need = ((size_t) n_ends + 1) * slab_dwords_for (d->max_len_staged);       // + 1: dump slab for task-less lane groups
   if (need > d->dirbuf_dwords)
     {
       hipFree (d->d_dirbuf);
@@ -578,6 +584,7 @@ struct RunCtx
   PmBatch b;
   PmParams prm;
   int tstride, L;
+  uint32_t *dump_slab;
 };
 
 template < int W > static void launch_chunk (pemap_dev * d, const RunCtx & c, uint32_t * m1, uint32_t * m2, int *mt)
@@ -599,16 +606,16 @@ template < int W > static void launch_chunk (pemap_dev * d, const RunCtx & c, ui
 #undef PM_SEED
   hipEventRecord (d->ev[1], d->stream);
   hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, true >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, d->hits,
-                      d->d_tasks_s, &d->d_ctr->n_tasks_s, d->d_ctr, d->d_dirbuf, c.tstride, c.L);
+                      d->d_tasks_s, &d->d_ctr->n_tasks_s, d->d_ctr, d->d_dirbuf, c.dump_slab, c.tstride, c.L);
   hipEventRecord (d->ev[2], d->stream);
   hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, false >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, d->hits,
-                      d->d_tasks_m, &d->d_ctr->n_tasks_m, d->d_ctr, d->d_dirbuf, c.tstride, c.L);
+                      d->d_tasks_m, &d->d_ctr->n_tasks_m, d->d_ctr, d->d_dirbuf, c.dump_slab, c.tstride, c.L);
   hipEventRecord (d->ev[3], d->stream);
   hipLaunchKernelGGL (pm_select_kernel, dim3 ((c.b.n + 255) / 256), dim3 (256), 0, d->stream, c.b, c.prm, d->hits, d->d_redo, d->d_wins, d->d_ctr,
                       m1, m2, mt);
   hipEventRecord (d->ev[4], d->stream);
   hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, true >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, d->hits,
-                      d->d_redo, &d->d_ctr->n_redo, d->d_ctr, d->d_dirbuf, c.tstride, c.L);
+                      d->d_redo, &d->d_ctr->n_redo, d->d_ctr, d->d_dirbuf, c.dump_slab, c.tstride, c.L);
   hipEventRecord (d->ev[5], d->stream);
   int wgrid = (n_ends + 255) / 256;
   if (wgrid > d->sw_grid)
@@ -693,7 +700,8 @@ static int run_slice (pemap_dev * d, int first, int n, int sync)
   c.prm.min_align = d->min_align;
   c.prm.bisulfite = d->bisulfite;
   c.L = L;
-  c.tstride = L + 21 + PM_LPA;
+  c.tstride = tstride_for (L);
+  c.dump_slab = d->d_dirbuf + (size_t) (chunk * per) * slab_dwords_for (L);
   memset (&d->last_ctr, 0, sizeof (d->last_ctr));
   memset (d->last_ms, 0, sizeof (d->last_ms));
   d->run_first = first;

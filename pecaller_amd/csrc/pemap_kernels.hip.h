@@ -18,7 +18,7 @@
 #define PM_SEG_LIST_MAX 4851       // 48*99 + 99 positions per segment at most (every bucket < too_many_spots)
 #define PM_LPA 8                   // lanes per alignment in the SW kernels
 // register budget of the SW kernels: 4 VGPRs of state per owned column (two doubles) plus temporaries
-#define PM_WAVES_PER_EU(W) ((W) <= 19 ? 4 : (W) <= 26 ? 3 : 2)
+#define PM_WAVES_PER_EU(W) ((W) <= 13 ? 4 : (W) <= 19 ? 3 : (W) <= 32 ? 2 : 1)
 
 struct PmIndex
 {

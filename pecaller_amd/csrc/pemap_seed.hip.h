@@ -17,6 +17,7 @@
 //      the strand's positions, are put in the walk's order (segment, position) and ONE wave replays the walk's state
 //      machine on them -- reset on '>', append on '==' if the diagonal is new, stop at max_hits tied hits.
 #define PM_SEED_THREADS 256
+typedef uint32_t pm_u32x2 __attribute__ ((ext_vector_type (2), aligned (4)));
 #define PM_SEED_TABLE 2048
 #define PM_DIAG_BIAS 300
 
@@ -292,8 +293,10 @@ template < int SMAX > __global__ __launch_bounds__ (PM_SEED_THREADS) void pm_see
                   {
                     const int sg = x / 49, j = x - sg * 49;
                     const uint32_t nb = pm_neighbour (sh.kmer[sg], j);
-                    v0[r] = ix.pos_index[nb];
-                    v1[r] = ix.pos_index[(uint32_t) (nb + 1u)];
+                    // one 8-byte gather for the pair (dword aligned); the all-T k-mer's successor wraps to entry 0
+                    const pm_u32x2 pr = *(const pm_u32x2 *) (ix.pos_index + nb);
+                    v0[r] = pr.x;
+                    v1[r] = (nb == 0xFFFFFFFFu) ? ix.pos_index[0] : pr.y;
                   }
               }
 #pragma unroll

@@ -122,9 +122,33 @@ template < int W > __device__ __noinline__ uint64_t pm_slow_mask (const uint8_t 
   return msel;
 }
 
+// Direction nibbles leave the wave through LDS: a lane produces DW dwords per step, which in HBM are consecutive for
+// consecutive steps of that lane.  Written directly, every store instruction would touch 64 different lines with 8-20
+// bytes each and each of them reaches HBM as its own partial-line write.  Instead PM_STAGE steps are collected in LDS
+// ([lane][step][DW]) and flushed with 16-byte-per-lane stores in which 4 (or more) adjacent lanes cover one lane's
+// chunk, i.e. whole 64-byte lines (chunks are 64-byte multiples because tstride is a multiple of 16).
+#define PM_STAGE 16
+
+template < int W > __device__ __forceinline__ void pm_flush_dirs (const uint32_t * stage, uint32_t * const *slab_of_group, int lane, int tstride,
+                                                                  int t0)
+{
+  constexpr int DW = PmSwGeom < W >::DW;
+  constexpr int CHUNK = PM_STAGE * DW;            // dwords one lane owns per flush
+  constexpr int NINSTR = (64 * CHUNK) / (64 * 4);   // 16-byte stores per lane
+#pragma unroll 2
+  for (int k = 0; k < NINSTR; k++)
+    {
+      const int o = (k * 64 + lane) * 4;          // dword offset in the staged [64][CHUNK] image
+      const int L = o / CHUNK, within = o - L * CHUNK;
+      const uint4 v = *(const uint4 *) (stage + o);
+      uint32_t *dst = slab_of_group[L >> 3] + ((size_t) (L & 7) * tstride + t0) * DW + within;
+      *(uint4 *) dst = v;
+    }
+}
+
 template < int W, bool DIRS >
-__device__ __forceinline__ void pm_sw_forward (const PmSwTask & tk, int bis, int lane, int nn_max, uint32_t * slab, int tstride,
-                                               double &best, int &bk, int &bi)
+__device__ __forceinline__ void pm_sw_forward (const PmSwTask & tk, int bis, int lane, int nn_max, uint32_t * stage,
+                                               uint32_t * const *slab_of_group, int tstride, double &best, int &bk, int &bi)
 {
   constexpr int DW = PmSwGeom < W >::DW;
   int g = lane & (PM_LPA - 1);
@@ -135,7 +159,16 @@ __device__ __forceinline__ void pm_sw_forward (const PmSwTask & tk, int bis, int
   const int pad = PM_LPA * W - mm;
   // ---- match masks of this lane's W columns against reference A, C, G, T, N (bit c = column c of the lane)
   uint64_t mk[5] = { 0, 0, 0, 0, 0 };
-#pragma unroll 1
+  // the lane's W read bytes: all loads issued before the first is used
+  uint8_t qraw[W];
+#pragma unroll
+  for (int c = 0; c < W; c++)
+    {
+      const int jz = g * W + c - pad;
+      const int src = tk.orient ? (mm - 1 - jz) : jz;
+      qraw[c] = (jz >= 0 && tk.valid) ? tk.read[src] : (uint8_t) 0;
+    }
+#pragma unroll
   for (int c = 0; c < W; c++)
     {
       const int jz = g * W + c - pad;      // 0-based read position, negative in the pad
@@ -150,7 +183,7 @@ __device__ __forceinline__ void pm_sw_forward (const PmSwTask & tk, int bis, int
         }
       else if (tk.valid)
         {
-          const uint8_t q = pm_oriented (tk.read, mm, tk.orient, jz);
+          const uint8_t q = tk.orient ? pm_rc (qraw[c]) : qraw[c];
           mk[0] |= pm_match ('A', q, bis) ? bitc : 0ull;
           mk[1] |= pm_match ('C', q, bis) ? bitc : 0ull;
           mk[2] |= pm_match ('G', q, bis) ? bitc : 0ull;
@@ -217,11 +250,31 @@ __device__ __forceinline__ void pm_sw_forward (const PmSwTask & tk, int bis, int
           Dprev = Dimp;
           if (DIRS)
             {
-              uint32_t *dst = slab + ((size_t) g * tstride + (t - 1)) * DW;
+              uint32_t *dst = stage + (lane * PM_STAGE + ((t - 1) & (PM_STAGE - 1))) * DW;
 #pragma unroll
               for (int d = 0; d < DW; d++)
                 dst[d] = dw[d];
             }
+        }
+      if (DIRS && (t & (PM_STAGE - 1)) == 0)
+        {
+          __builtin_amdgcn_fence (__ATOMIC_SEQ_CST, "wavefront");
+          __builtin_amdgcn_wave_barrier ();
+          pm_flush_dirs < W > (stage, slab_of_group, lane, tstride, t - PM_STAGE);
+          __builtin_amdgcn_fence (__ATOMIC_SEQ_CST, "wavefront");
+          __builtin_amdgcn_wave_barrier ();
+        }
+    }
+  if (DIRS)
+    {
+      const int t_end = nn_max + PM_LPA - 1;
+      if (t_end & (PM_STAGE - 1))
+        {
+          __builtin_amdgcn_fence (__ATOMIC_SEQ_CST, "wavefront");
+          __builtin_amdgcn_wave_barrier ();
+          pm_flush_dirs < W > (stage, slab_of_group, lane, tstride, t_end & ~(PM_STAGE - 1));
+          __builtin_amdgcn_fence (__ATOMIC_SEQ_CST, "wavefront");
+          __builtin_amdgcn_wave_barrier ();
         }
     }
   // hand the tracker's result to lane g == 0 of the group
@@ -243,14 +296,19 @@ __device__ __forceinline__ int pm_wave_max (int v)
 template < int W, bool DIRS > __global__ __launch_bounds__ (64, PM_WAVES_PER_EU (W)) void pm_sw_kernel (PmIndex ix, PmBatch b, PmParams prm, PmHits h,
                                                                                               const uint32_t * tasks,
                                                                                               const unsigned *n_tasks_p, PmCounters * ctr,
-                                                                                              uint32_t * dirbuf, int tstride, int mm_fill)
+                                                                                              uint32_t * dirbuf, uint32_t * dump_slab, int tstride,
+                                                                                              int mm_fill)
 {
+  __shared__ uint32_t stage[DIRS ? 64 * PM_STAGE * PmSwGeom < W >::DW : 4];
+  __shared__ uint32_t *slab_of_group[8];
   const int lane = threadIdx.x;
   const int q = lane >> 3;
   const unsigned n_tasks = *n_tasks_p;
   const size_t slab_dwords = (size_t) PM_LPA * tstride * PmSwGeom < W >::DW;
   for (unsigned base = blockIdx.x * 8u; base < n_tasks; base += gridDim.x * 8u)
     {
+      __builtin_amdgcn_fence (__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier ();
       PmSwTask tk;
       tk.valid = (base + q) < n_tasks;
       size_t o = 0;
@@ -273,10 +331,19 @@ template < int W, bool DIRS > __global__ __launch_bounds__ (64, PM_WAVES_PER_EU 
           if (DIRS)
             slab = dirbuf + (size_t) h.slot[end] * slab_dwords;
         }
+      if (DIRS)
+        {
+          // groups without a task flush into the wave's last slab region that is valid: point them at group 0's slab
+          // rows beyond the window (never read); simpler: give them the dump slab at the end of the direction buffer
+          if ((lane & 7) == 0)
+            slab_of_group[q] = tk.valid ? slab : dump_slab;
+          __builtin_amdgcn_fence (__ATOMIC_SEQ_CST, "wavefront");
+          __builtin_amdgcn_wave_barrier ();
+        }
       int nn_max = pm_wave_max (tk.nn);
       double best;
       int bk, bi;
-      pm_sw_forward < W, DIRS > (tk, prm.bisulfite, lane, nn_max, slab, tstride, best, bk, bi);
+      pm_sw_forward < W, DIRS > (tk, prm.bisulfite, lane, nn_max, stage, slab_of_group, tstride, best, bk, bi);
       if (tk.valid && (lane & 7) == 0)
         {
           h.score[o] = best;
