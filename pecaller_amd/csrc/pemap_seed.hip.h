@@ -37,10 +37,12 @@ template < int SMAX > struct __align__ (8) PmSeedShared
   } u;
   uint32_t ekey[2][PM_SEED_CAP];        // diagonal keys of the gathered positions, per strand
   uint32_t hits[PM_MAX_HITS];
-  uint32_t kmer[2 * SMAX];
+  uint32_t kmer[2][2 * SMAX];           // [pipeline buffer][strand * S + segment]
   int seg_cnt[2 * SMAX];
   int seg_base[2][SMAX + 1];
-  int offsets[SMAX + 1];
+  int offsets[2][SMAX + 1];             // [pipeline buffer][segment]
+  int skip[2];                          // N filter verdict of the buffered read
+  int ncount[2];
   int state[4];                         // min_match, tot_hits, go_on, task base
   unsigned n_surv;
   uint16_t surv[PM_SEED_CAP];           // surviving anchors (indices into ekey), then the same in walk order
@@ -49,8 +51,23 @@ template < int SMAX > struct __align__ (8) PmSeedShared
   uint8_t eseg[2][PM_SEED_CAP];
   uint8_t tfs[PM_SEED_CAP];             // exact tot_found of the survivors
   uint8_t hits_or[PM_MAX_HITS];
-  uint8_t seq[2][320];
+  uint8_t seq[2][2][320];               // [pipeline buffer][strand]
 };
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, which would make the look-ups
+// that were issued for the workgroup's NEXT read-end (software pipeline) complete at the first barrier of the vote.
+__device__ __forceinline__ void pm_lds_barrier ()
+{
+  asm volatile ("s_waitcnt lgkmcnt(0)\n\ts_barrier":::"memory");
+}
+
+template < bool LDS_ONLY > __device__ __forceinline__ void pm_barrier ()
+{
+  if (LDS_ONLY)
+    pm_lds_barrier ();
+  else
+    __syncthreads ();
+}
 
 __device__ __forceinline__ unsigned pm_bin_hash (uint32_t bin)
 {
@@ -61,7 +78,8 @@ __device__ __forceinline__ unsigned pm_bin_hash (uint32_t bin)
 // sh.state.  IdxT = uint16_t (LDS arrays) or uint32_t (global spill arrays of a strand with more than PM_SEED_CAP positions).
 template < class SH, class IdxT >
 __device__ void pm_vote_strand (SH & sh, const uint32_t * ekey, const uint8_t * eseg, IdxT * surv, IdxT * order, uint8_t * tfs, int T,
-                                const int *seg_cnt, int total_cuts, int max_off, int &min_match, int &tot, bool & go_on, uint8_t strand)
+                                const int *seg_cnt, const int *offsets, int total_cuts, int max_off, int &min_match, int &tot, bool & go_on,
+                                uint8_t strand)
 {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   // pemapper.c:2200-2207: nothing is searched (and earlier hits are dropped) when every segment holds more than max_hits positions
@@ -77,10 +95,10 @@ __device__ void pm_vote_strand (SH & sh, const uint32_t * ekey, const uint8_t * 
     sh.u.table[i] = 0;
   if (tid == 0)
     sh.n_surv = 0;
-  __syncthreads ();
+  pm_barrier < sizeof (IdxT) == 2 > ();
   for (int p = tid; p < T; p += PM_SEED_THREADS)
     atomicOr (&sh.u.table[pm_bin_hash (ekey[p] >> 4)], 1u << eseg[p]);
-  __syncthreads ();
+  pm_barrier < sizeof (IdxT) == 2 > ();
   // an anchor of segment `loop` is only visited while loop <= 1 + max_depth - min_match (pemapper.c:2216; the bound only shrinks)
   const int loop_max = 1 + total_cuts - min_match;
   for (int p = tid; p < T; p += PM_SEED_THREADS)
@@ -90,7 +108,7 @@ __device__ void pm_vote_strand (SH & sh, const uint32_t * ekey, const uint8_t * 
       if ((int) eseg[p] <= loop_max && __popc (mask) >= min_match)
         surv[atomicAdd (&sh.n_surv, 1u)] = (IdxT) p;
     }
-  __syncthreads ();
+  pm_barrier < sizeof (IdxT) == 2 > ();
   const int ns = (int) sh.n_surv;
   // exact tot_found (pemapper.c:2241-2249): 1 + number of LATER segments with a position whose diagonal differs by less than max_off
   for (int sv = wv; sv < ns; sv += PM_SEED_THREADS / 64)
@@ -110,7 +128,7 @@ __device__ void pm_vote_strand (SH & sh, const uint32_t * ekey, const uint8_t * 
       if (lane == 0)
         tfs[sv] = (uint8_t) (1 + __popc (bits));
     }
-  __syncthreads ();
+  pm_barrier < sizeof (IdxT) == 2 > ();
   // walk order: segment ascending, position ascending inside a segment (same offset, so diagonal ascending)
   for (int sv = tid; sv < ns; sv += PM_SEED_THREADS)
     {
@@ -124,7 +142,7 @@ __device__ void pm_vote_strand (SH & sh, const uint32_t * ekey, const uint8_t * 
         }
       order[rank] = (IdxT) sv;
     }
-  __syncthreads ();
+  pm_barrier < sizeof (IdxT) == 2 > ();
   if (tid < 64)
     {
       bool more = true, done = false;
@@ -154,7 +172,7 @@ __device__ void pm_vote_strand (SH & sh, const uint32_t * ekey, const uint8_t * 
                     }
                   cur_loop = loop;
                 }
-              const int off_a = sh.offsets[loop];
+              const int off_a = offsets[loop];
               const uint32_t ml = ekey[al] - (uint32_t) (PM_DIAG_BIAS - off_a);      // the position itself
               if (tfl > min_match)
                 {
@@ -209,10 +227,75 @@ __device__ void pm_vote_strand (SH & sh, const uint32_t * ekey, const uint8_t * 
           sh.state[2] = more ? 1 : 0;
         }
     }
-  __syncthreads ();
+  pm_barrier < sizeof (IdxT) == 2 > ();
   min_match = sh.state[0];
   tot = sh.state[1];
   go_on = sh.state[2] != 0;
+}
+
+// Stage A of a read-end (software-pipelined one end ahead of the vote): the read and its reverse complement into LDS
+// buffer `buf`, the N filter, the segment offsets and 16-mers, and the 2 x S x 49 look-ups ISSUED into registers.
+// They complete while the workgroup votes on the previous end.
+template < int SMAX, int NI, class SH >
+__device__ __forceinline__ void pm_seed_stage_a (SH & sh, const PmIndex & ix, const PmBatch & b, int bis, int e, int buf, uint32_t (&v0)[NI],
+                                                 uint32_t (&v1)[NI])
+{
+  const int tid = threadIdx.x;
+  const int idepth = ix.idepth;
+  int len;
+  const uint8_t *src = pm_read_ptr (b, e, &len);
+  // ---- read + reverse complement; N filter (pemapper.c:1552-1559: upper-case 'N' only)
+  int isn = 0;
+  for (int i = tid; i < len; i += PM_SEED_THREADS)
+    {
+      uint8_t c = src[i];
+      sh.seq[buf][0][i] = c;
+      sh.seq[buf][1][len - 1 - i] = pm_rc (c);
+      isn += (c == 'N');
+    }
+  // ---- segment offsets (pemapper.c:1573-1587)
+  int total_cuts = len / idepth;
+  if (len % idepth == 0)
+    total_cuts--;
+  if (total_cuts > SMAX - 1)
+    total_cuts = SMAX - 1;      // cannot happen: the host picks SMAX from the longest staged read
+  const int S = total_cuts + 1;
+  if (tid <= total_cuts)
+    sh.offsets[buf][tid] = (tid < total_cuts || total_cuts == 0) ? tid * idepth : len - idepth;
+  if (isn)
+    atomicAdd (&sh.ncount[buf], isn);
+  pm_lds_barrier ();
+  const int n_count = sh.ncount[buf];
+  const bool skip = n_count >= 1 + len / 10;
+  if (tid == 0)
+    sh.skip[buf] = skip ? 1 : 0;
+  // ---- 16-mers of the segments of both strands (convert_seq_int, pemapper.c:2408-2423)
+  if (tid < 2 * S)
+    {
+      const int strand = tid / S, seg = tid - strand * S;
+      const uint8_t *p = &sh.seq[buf][strand][sh.offsets[buf][seg]];
+      uint32_t k = 0;
+      for (int i = 0; i < 16; i++)
+        k = (k << 2) + pm_code (p[i], bis);
+      sh.kmer[buf][tid] = k;
+    }
+  pm_lds_barrier ();
+  // ---- 49 bucket look-ups per segment, both strands, all in flight at once (get_mers, pemapper.c:2158-2165)
+#pragma unroll
+  for (int r = 0; r < NI; r++)
+    {
+      const int x = tid + r * PM_SEED_THREADS;
+      v0[r] = v1[r] = 0;
+      if (!skip && x < 2 * S * 49)
+        {
+          const int sg = x / 49, j = x - sg * 49;
+          const uint32_t nb = pm_neighbour (sh.kmer[buf][sg], j);
+          // one 8-byte gather for the pair (dword aligned), nothing depends on it until the commit one iteration later
+          const pm_u32x2 pr = *(const pm_u32x2 *) (ix.pos_index + nb);
+          v0[r] = pr.x;
+          v1[r] = pr.y;
+        }
+    }
 }
 
 template < int SMAX > __global__ __launch_bounds__ (PM_SEED_THREADS) void pm_seed_kernel (PmIndex ix, PmBatch b, PmParams prm, PmHits h,
@@ -223,7 +306,6 @@ template < int SMAX > __global__ __launch_bounds__ (PM_SEED_THREADS) void pm_see
   __shared__ SH sh;
   constexpr int NI = (SH::NITEMS + PM_SEED_THREADS - 1) / PM_SEED_THREADS;   // look-ups per thread
   const int tid = threadIdx.x;
-  const int lane = tid & 63;
   const int idepth = ix.idepth;
   const int max_off = max (2, idepth - 4);
   // per-workgroup spill area for the rare strand whose positions exceed the LDS capacity: keys, survivors, order (u32 each),
@@ -235,85 +317,49 @@ template < int SMAX > __global__ __launch_bounds__ (PM_SEED_THREADS) void pm_see
   uint8_t *g_seg = (uint8_t *) (g_order + GN);
   uint8_t *g_tfs = g_seg + GN;
 
-  for (int e = blockIdx.x; e < b.n_ends; e += gridDim.x)
+  uint32_t v0[NI], v1[NI];
+  const uint32_t pos_index_0 = ix.pos_index[0];
+  int e = blockIdx.x;
+  int buf = 0;
+  if (tid < 2)
+    sh.ncount[tid] = 0;
+  __syncthreads ();
+  if (e < b.n_ends)
+    pm_seed_stage_a < SMAX, NI > (sh, ix, b, prm.bisulfite, e, 0, v0, v1);
+  for (; e < b.n_ends; e += gridDim.x, buf ^= 1)
     {
-      __syncthreads ();
       int len;
-      const uint8_t *src = pm_read_ptr (b, e, &len);
-      // ---- read + reverse complement into LDS; N filter (pemapper.c:1552-1559: upper-case 'N' only)
-      int isn = 0;
-      for (int i = tid; i < len; i += PM_SEED_THREADS)
-        {
-          uint8_t c = src[i];
-          sh.seq[0][i] = c;
-          sh.seq[1][len - 1 - i] = pm_rc (c);
-          isn += (c == 'N');
-        }
-      // ---- segment offsets (pemapper.c:1573-1587)
+      (void) pm_read_ptr (b, e, &len);
       int total_cuts = len / idepth;
       if (len % idepth == 0)
         total_cuts--;
       if (total_cuts > SMAX - 1)
-        total_cuts = SMAX - 1;      // cannot happen: the host picks SMAX from the longest staged read
+        total_cuts = SMAX - 1;
       const int S = total_cuts + 1;
-      if (tid <= total_cuts)
-        sh.offsets[tid] = (tid < total_cuts || total_cuts == 0) ? tid * idepth : len - idepth;
-      int n_count = __syncthreads_count (isn);
-      // __syncthreads_count counts threads, a thread can hold several N only for reads longer than 256: add the exact sum
-      if (len > PM_SEED_THREADS)
+      pm_lds_barrier ();        // the previous end's vote is done with the table that aliases the items
+      const bool skip = sh.skip[buf] != 0;
+      if (tid == 0)
+        sh.ncount[buf ^ 1] = 0; // N counter of the buffer the next stage A fills
+      // ---- commit this end's look-ups (issued one iteration ago) to LDS
+#pragma unroll
+      for (int r = 0; r < NI; r++)
         {
-          n_count = 0;
-          for (int i = 0; i < len; i++)
-            n_count += (sh.seq[0][i] == 'N');
-        }
-      int tot = 0;
-      if (n_count < 1 + len / 10)
-        {
-          // ---- 16-mers of the segments of both strands (convert_seq_int, pemapper.c:2408-2423)
-          if (tid < 2 * S)
+          const int x = tid + r * PM_SEED_THREADS;
+          if (x < 2 * S * 49)
             {
-              const int strand = tid / S, seg = tid - strand * S;
-              const uint8_t *p = &sh.seq[strand][sh.offsets[seg]];
-              uint32_t k = 0;
-              for (int i = 0; i < 16; i++)
-                k = (k << 2) + pm_code (p[i], prm.bisulfite);
-              sh.kmer[tid] = k;
+              // the all-T k-mer's successor is entry 0: `which + 1` is evaluated in 32 bits (pemapper.c:2163)
+              const int sg = x / 49, j = x - sg * 49;
+              const uint32_t nb = pm_neighbour (sh.kmer[buf][sg], j);
+              const uint32_t ln = ((nb == 0xFFFFFFFFu) ? pos_index_0 : v1[r]) - v0[r];
+              sh.u.it.it_start[x] = v0[r];
+              sh.u.it.it_len[x] = (ln >= PM_TOO_MANY) ? 0xFFFF : (uint16_t) ln;
             }
-          __syncthreads ();
-          // ---- 49 bucket look-ups per segment, both strands, all in flight at once (get_mers, pemapper.c:2158-2165;
-          //      `which + 1` wraps in 32 bits)
-          {
-            uint32_t v0[NI], v1[NI];
-#pragma unroll
-            for (int r = 0; r < NI; r++)
-              {
-                const int x = tid + r * PM_SEED_THREADS;
-                v0[r] = v1[r] = 0;
-                if (x < 2 * S * 49)
-                  {
-                    const int sg = x / 49, j = x - sg * 49;
-                    const uint32_t nb = pm_neighbour (sh.kmer[sg], j);
-                    // one 8-byte gather for the pair (dword aligned); the all-T k-mer's successor wraps to entry 0
-                    const pm_u32x2 pr = *(const pm_u32x2 *) (ix.pos_index + nb);
-                    v0[r] = pr.x;
-                    v1[r] = (nb == 0xFFFFFFFFu) ? ix.pos_index[0] : pr.y;
-                  }
-              }
-#pragma unroll
-            for (int r = 0; r < NI; r++)
-              {
-                const int x = tid + r * PM_SEED_THREADS;
-                if (x < 2 * S * 49)
-                  {
-                    const uint32_t ln = v1[r] - v0[r];
-                    sh.u.it.it_start[x] = v0[r];
-                    sh.u.it.it_len[x] = (ln >= PM_TOO_MANY) ? 0xFFFF : (uint16_t) ln;
-                  }
-              }
-          }
-          __syncthreads ();
-          if (phase_limit == 1)
-            continue;           // timing probe (PEMAP_SEED_PHASE): stop after the look-ups
+        }
+      pm_lds_barrier ();
+      int tot = 0;
+      int T0 = 0, T1 = 0;
+      if (!skip && phase_limit != 1)
+        {
           // ---- a segment with any bucket >= too_many_spots is emptied (pemapper.c:1602-1606)
           if (tid < 2 * S)
             {
@@ -330,12 +376,7 @@ template < int SMAX > __global__ __launch_bounds__ (PM_SEED_THREADS) void pm_see
                 }
               sh.seg_cnt[tid] = bad ? 0 : sum;
             }
-          int min_match = max (1, total_cuts);       // pemapper.c:1642-1645
-          if (total_cuts > 4)
-            min_match = (4 * total_cuts) / 5;
-          min_match = min (min_match, 4);
-          __syncthreads ();
-          // ---- both strands' bucket slices, one position per thread and round (each slice is ascending in .mdx)
+          pm_lds_barrier ();
           if (tid < 2)
             {
               int acc = 0;
@@ -347,35 +388,46 @@ template < int SMAX > __global__ __launch_bounds__ (PM_SEED_THREADS) void pm_see
               sh.seg_base[tid][S] = acc;
               atomicAdd (&ctr->positions, (unsigned long long) acc);
             }
-          __syncthreads ();
-          const int T0 = sh.seg_base[0][S], T1 = sh.seg_base[1][S];
-          // a strand with more positions than the LDS arrays hold goes to the workgroup's global spill area (the two
-          // strands are then gathered one after the other, just before each is voted on)
-          const bool lds0 = T0 <= PM_SEED_CAP, lds1 = T1 <= PM_SEED_CAP;
-          for (int pp = tid; pp < (lds0 ? T0 : 0) + (lds1 ? T1 : 0); pp += PM_SEED_THREADS)
+          pm_lds_barrier ();
+          T0 = sh.seg_base[0][S];
+          T1 = sh.seg_base[1][S];
+        }
+      // a strand with more positions than the LDS arrays hold goes to the workgroup's global spill area (gathered just
+      // before it is voted on)
+      const bool lds0 = T0 <= PM_SEED_CAP, lds1 = T1 <= PM_SEED_CAP;
+      // ---- both strands' bucket slices, one position per thread and round (each slice is ascending in .mdx)
+      for (int pp = tid; pp < (lds0 ? T0 : 0) + (lds1 ? T1 : 0); pp += PM_SEED_THREADS)
+        {
+          const int strand = (lds0 && pp < T0) ? 0 : 1;
+          const int p = (strand == 1 && lds0) ? pp - T0 : pp;
+          int seg = 0;
+          while (p >= sh.seg_base[strand][seg + 1])
+            seg++;
+          const int q = p - sh.seg_base[strand][seg];
+          const int x0 = (strand * S + seg) * 49;
+          int lo = 0, hi = 48;  // largest j with it_off[j] <= q: that slice holds position q
+          while (lo < hi)
             {
-              const int strand = (lds0 && pp < T0) ? 0 : 1;
-              const int p = (strand == 1 && lds0) ? pp - T0 : pp;
-              int seg = 0;
-              while (p >= sh.seg_base[strand][seg + 1])
-                seg++;
-              const int q = p - sh.seg_base[strand][seg];
-              const int x0 = (strand * S + seg) * 49;
-              int lo = 0, hi = 48;          // largest j with it_off[j] <= q: that slice holds position q
-              while (lo < hi)
-                {
-                  const int mid = (lo + hi + 1) >> 1;
-                  if ((int) sh.u.it.it_off[x0 + mid] <= q)
-                    lo = mid;
-                  else
-                    hi = mid - 1;
-                }
-              const uint32_t m = ix.mers[sh.u.it.it_start[x0 + lo] + (uint32_t) (q - (int) sh.u.it.it_off[x0 + lo])];
-              sh.ekey[strand][p] = m + (uint32_t) (PM_DIAG_BIAS - sh.offsets[seg]);
-              sh.eseg[strand][p] = (uint8_t) seg;
+              const int mid = (lo + hi + 1) >> 1;
+              if ((int) sh.u.it.it_off[x0 + mid] <= q)
+                lo = mid;
+              else
+                hi = mid - 1;
             }
-          if (phase_limit == 2)
-            continue;
+          const uint32_t m = ix.mers[sh.u.it.it_start[x0 + lo] + (uint32_t) (q - (int) sh.u.it.it_off[x0 + lo])];
+          sh.ekey[strand][p] = m + (uint32_t) (PM_DIAG_BIAS - sh.offsets[buf][seg]);
+          sh.eseg[strand][p] = (uint8_t) seg;
+        }
+      // ---- stage A of the workgroup's NEXT end: its look-ups fly while this end is voted on
+      const int e2 = e + gridDim.x;
+      if (e2 < b.n_ends)
+        pm_seed_stage_a < SMAX, NI > (sh, ix, b, prm.bisulfite, e2, buf ^ 1, v0, v1);
+      if (!skip && phase_limit != 1 && phase_limit != 2)
+        {
+          int min_match = max (1, total_cuts);       // pemapper.c:1642-1645
+          if (total_cuts > 4)
+            min_match = (4 * total_cuts) / 5;
+          min_match = min (min_match, 4);
           bool go_on = true;
           for (int strand = 0; strand < 2 && go_on; strand++)
             {
@@ -383,32 +435,28 @@ template < int SMAX > __global__ __launch_bounds__ (PM_SEED_THREADS) void pm_see
               const bool in_lds = strand ? lds1 : lds0;
               if (!in_lds)
                 {
-                  // spill path: the items are still needed, so this strand is gathered now and the table (which aliases the
-                  // items) is rebuilt from scratch afterwards; strand 1's items survive strand 0's vote only if strand 0 did
-                  // not use the table, so an oversized strand 1 after a voted strand 0 re-does its look-ups
-                  if (strand == 1)
+                  // spill path.  The items (look-up results) alias the vote table and the next end's look-ups are in
+                  // registers, so this strand's look-ups are simply done again before it is gathered.
+                  __syncthreads ();
+                  for (int x = tid; x < S * 49; x += PM_SEED_THREADS)
                     {
-                      __syncthreads ();
-                      for (int x = tid; x < S * 49; x += PM_SEED_THREADS)
+                      const int sg = strand * S + x / 49, j = x % 49;
+                      const uint32_t nb = pm_neighbour (sh.kmer[buf][sg], j);
+                      const uint32_t i0 = ix.pos_index[nb];
+                      const uint32_t ln = ix.pos_index[(uint32_t) (nb + 1u)] - i0;
+                      sh.u.it.it_start[strand * S * 49 + x] = i0;
+                      sh.u.it.it_len[strand * S * 49 + x] = (ln >= PM_TOO_MANY) ? 0xFFFF : (uint16_t) ln;
+                    }
+                  __syncthreads ();
+                  if (tid < S)
+                    {
+                      int sum = 0;
+                      for (int j = 0; j < 49; j++)
                         {
-                          const int sg = S + x / 49, j = x % 49;
-                          const uint32_t nb = pm_neighbour (sh.kmer[sg], j);
-                          const uint32_t i0 = ix.pos_index[nb];
-                          const uint32_t ln = ix.pos_index[(uint32_t) (nb + 1u)] - i0;
-                          sh.u.it.it_start[S * 49 + x] = i0;
-                          sh.u.it.it_len[S * 49 + x] = (ln >= PM_TOO_MANY) ? 0xFFFF : (uint16_t) ln;
-                        }
-                      __syncthreads ();
-                      if (tid < S)
-                        {
-                          int sum = 0;
-                          for (int j = 0; j < 49; j++)
-                            {
-                              const uint16_t ln = sh.u.it.it_len[(S + tid) * 49 + j];
-                              sh.u.it.it_off[(S + tid) * 49 + j] = (uint16_t) sum;
-                              if (ln != 0xFFFF)
-                                sum += ln;
-                            }
+                          const uint16_t ln = sh.u.it.it_len[(strand * S + tid) * 49 + j];
+                          sh.u.it.it_off[(strand * S + tid) * 49 + j] = (uint16_t) sum;
+                          if (ln != 0xFFFF)
+                            sum += ln;
                         }
                     }
                   __syncthreads ();
@@ -429,17 +477,19 @@ template < int SMAX > __global__ __launch_bounds__ (PM_SEED_THREADS) void pm_see
                             hi = mid - 1;
                         }
                       const uint32_t m = ix.mers[sh.u.it.it_start[x0 + lo] + (uint32_t) (q - (int) sh.u.it.it_off[x0 + lo])];
-                      g_key[p] = m + (uint32_t) (PM_DIAG_BIAS - sh.offsets[seg]);
+                      g_key[p] = m + (uint32_t) (PM_DIAG_BIAS - sh.offsets[buf][seg]);
                       g_seg[p] = (uint8_t) seg;
                     }
+                  __syncthreads ();
                 }
-              __syncthreads ();
+              else
+                pm_lds_barrier ();
               if (in_lds)
                 pm_vote_strand < SH, uint16_t > (sh, sh.ekey[strand], sh.eseg[strand], sh.surv, sh.order, sh.tfs, T, &sh.seg_cnt[strand * S],
-                                                 total_cuts, max_off, min_match, tot, go_on, (uint8_t) strand);
+                                                 sh.offsets[buf], total_cuts, max_off, min_match, tot, go_on, (uint8_t) strand);
               else
-                pm_vote_strand < SH, uint32_t > (sh, g_key, g_seg, g_surv, g_order, g_tfs, T, &sh.seg_cnt[strand * S], total_cuts, max_off,
-                                                 min_match, tot, go_on, (uint8_t) strand);
+                pm_vote_strand < SH, uint32_t > (sh, g_key, g_seg, g_surv, g_order, g_tfs, T, &sh.seg_cnt[strand * S], sh.offsets[buf], total_cuts,
+                                                 max_off, min_match, tot, go_on, (uint8_t) strand);
               if (tot >= PM_MAX_HITS)
                 go_on = false;
             }
@@ -458,7 +508,7 @@ template < int SMAX > __global__ __launch_bounds__ (PM_SEED_THREADS) void pm_see
             tb = atomicAdd (&ctr->n_tasks_m, (unsigned) tot);
           sh.state[3] = (int) tb;
         }
-      __syncthreads ();
+      pm_lds_barrier ();
       const unsigned tbase = (unsigned) sh.state[3];
       uint32_t *tasks = (tot == 1) ? tasks_s : tasks_m;
       for (int t = tid; t < tot; t += PM_SEED_THREADS)
@@ -473,8 +523,8 @@ template < int SMAX > __global__ __launch_bounds__ (PM_SEED_THREADS) void pm_see
           unsigned cs0 = ix.contig_starts[chrom] + extra;
           unsigned start_match = ((long) cs0 > tt) ? cs0 : (unsigned) tt;
           unsigned e1 = ix.contig_starts[chrom + 1] + extra;
-          unsigned e2 = extra + spot + (unsigned) len + PM_SLOP;
-          unsigned end_match = e1 < e2 ? e1 : e2;
+          unsigned e2w = extra + spot + (unsigned) len + PM_SLOP;
+          unsigned end_match = e1 < e2w ? e1 : e2w;
           int blen = (int) (1u + end_match - start_match);
           size_t o = (size_t) e * PM_MAX_HITS + t;
           h.spot[o] = spot;
