@@ -1,0 +1,680 @@
+/*
+ * pemapper_main.c -- host program (plain C) with the command line and on-disk formats of the reference's pemapper
+ * and pemapper_tsw, calling the MI355X hot path through the C-ABI of include/pemap_hip.h.
+ *
+ *   pemapper_hip out sdx s|sa file1 is_bisulfite min_match threads max_reads [trim_start trim_end]
+ *   pemapper_hip out sdx p|pa file1 file2 max_dist min_dist is_bisulfite min_match threads max_reads [trim_start trim_end]
+ *
+ * (src/pemapper.c:226-358; with the two trailing arguments it behaves as src/pemapper_tsw.c:234-311: reads are trimmed
+ * and array-file lines may carry an output base name in a second column, pemapper_tsw.c:266-280, 636-674.)
+ * Outputs: <out>.pileup.gz (16-byte records), <out>.indel.txt.gz, <out>.summary.txt, <fastq>.mfile -- the reference's
+ * formats (pemapper.c:775-781, 819-900).
+ *
+ * Differences from the reference, all outside the hot path: `threads` is validated but unused (the batch goes to the
+ * GPU); the index arrays are rebuilt on the GPU from <sdx>.seq instead of inflating the 16 GiB <sdx>.idx (the device
+ * builder is verified to produce the reference builder's arrays; set PEMAP_INDEX_FROM_FILES=1 to load .idx/.mdx);
+ * reads longer than PEMAP_MAX_READ or shorter than PEMAP_MIN_READ are an error instead of undefined behaviour.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ctype.h>
+#include <stdint.h>
+#include <zlib.h>
+#include "../../include/pemap_hip.h"
+
+#define MAX_FILES 2000
+#define BATCH_PAIRS (1 << 20)
+#define ROW_STRIDE 288
+
+static void
+die (const char *msg, const char *arg)
+{
+  printf (msg, arg);            /* the reference prints to stdout and exits with 1 (pemapper.c:2808-2816) */
+  printf ("\n");
+  exit (1);
+}
+
+static void
+ck (pemap_dev * dev, int rc)
+{
+  if (rc)
+    {
+      printf ("\n pemap_hip: %s\n", pemap_dev_last_error (dev));
+      exit (1);
+    }
+}
+
+/* ---- line reader over a gz stream: my_gzgets (pemapper.c:2447-2483) without its 1.2 GB slab */
+typedef struct
+{
+  gzFile f;
+  char *buf;
+  size_t cap, len, pos;
+  int eof;
+} lreader;
+
+static void
+lr_open (lreader * r, const char *path)
+{
+  r->f = gzopen (path, "r");
+  if (!r->f)
+    die ("\n Can not open file %s for reading", path);
+  gzbuffer (r->f, 1 << 22);
+  r->cap = 1 << 22;
+  r->buf = (char *) malloc (r->cap + 1);
+  r->len = r->pos = 0;
+  r->eof = 0;
+}
+
+static void
+lr_close (lreader * r)
+{
+  gzclose (r->f);
+  free (r->buf);
+}
+
+/* next line without its '\n' (a '\r' stays, as in the reference), NULL at end of data */
+static char *
+lr_gets (lreader * r)
+{
+  for (;;)
+    {
+      char *nl = (char *) memchr (r->buf + r->pos, '\n', r->len - r->pos);
+      if (nl)
+        {
+          char *s = r->buf + r->pos;
+          *nl = '\0';
+          r->pos = (size_t) (nl - r->buf) + 1;
+          return s;
+        }
+      if (r->eof)
+        return NULL;            /* an unterminated last line is dropped, pemapper.c:2466-2481 */
+      memmove (r->buf, r->buf + r->pos, r->len - r->pos);
+      r->len -= r->pos;
+      r->pos = 0;
+      if (r->len == r->cap)
+        {
+          r->cap *= 2;
+          r->buf = (char *) realloc (r->buf, r->cap + 1);
+        }
+      int got = gzread (r->f, r->buf + r->len, (unsigned) (r->cap - r->len));
+      if (got <= 0)
+        r->eof = 1;
+      else
+        r->len += (size_t) got;
+    }
+}
+
+/* find_chrom, pemapper.c:2168-2186, on the real (un-compressed) contig starts for the indel table (856) */
+static int
+find_chrom (const uint32_t * pos, int n, int first, int last, int try, uint32_t this)
+{
+  if (first == last)
+    return first;
+  uint32_t a = (try >= 0 && try <= n) ? pos[try] : 0xFFFFFFFFu;
+  uint32_t b = (try + 1 >= 0 && try + 1 <= n) ? pos[try + 1] : 0xFFFFFFFFu;
+  if (a <= this && b >= this)
+    return try;
+  if (a > this)
+    last = try - 1;
+  else
+    first = try + 1;
+  try = (last + first) / 2;
+  return find_chrom (pos, n, first, last, try, this);
+}
+
+/* ---- insertion strings collected from the device log */
+typedef struct
+{
+  uint32_t pos;
+  uint32_t off;
+  int len;
+} ins_rec;
+static ins_rec *g_ins;
+static size_t g_nins, g_capins;
+static char *g_inschars;
+static size_t g_nchars, g_capchars;
+
+static void
+ins_cb (void *user, uint32_t pos, const char *seq, int len)
+{
+  (void) user;
+  if (g_nins == g_capins)
+    {
+      g_capins = g_capins ? 2 * g_capins : 4096;
+      g_ins = (ins_rec *) realloc (g_ins, g_capins * sizeof (ins_rec));
+    }
+  if (g_nchars + (size_t) len + 1 > g_capchars)
+    {
+      g_capchars = g_capchars ? 2 * g_capchars + (size_t) len : 1 << 16;
+      g_inschars = (char *) realloc (g_inschars, g_capchars);
+    }
+  g_ins[g_nins].pos = pos;
+  g_ins[g_nins].off = (uint32_t) g_nchars;
+  g_ins[g_nins].len = len;
+  g_nins++;
+  memcpy (g_inschars + g_nchars, seq, (size_t) len);
+  g_inschars[g_nchars + len] = 0;
+  g_nchars += (size_t) len + 1;
+}
+
+static int
+cmp_ins (const void *a, const void *b)
+{
+  const ins_rec *x = (const ins_rec *) a, *y = (const ins_rec *) b;
+  if (x->pos != y->pos)
+    return x->pos < y->pos ? -1 : 1;
+  return x->off < y->off ? -1 : (x->off > y->off);
+}
+
+typedef struct
+{
+  pemap_dev *dev;
+  const char *genome;
+  uint64_t gsize;
+  uint32_t *real_starts;        /* contig starts in .seq coordinates */
+  char **contig_names;
+  int n_contigs;
+  int paired;
+  char mate_names[9][80];
+} ctx_t;
+
+#pragma pack(push, 1)
+typedef struct
+{
+  uint32_t pos;
+  uint16_t c[6];
+} pile_rec;
+#pragma pack(pop)
+
+/* the final genome walk and the three writers, pemapper.c:788-900 / pemapper_tsw.c dump_output 848-965 */
+static void
+dump_output (ctx_t * c, const char *basename, long tot_pairs)
+{
+  char path[4200];
+  long S[13];
+  ck (c->dev, pemap_dev_summary (c->dev, S));
+  const long total_reads = S[0], total_bases = S[1], total_dist = S[2], no_dists = S[3];
+  const long *mate_counts = &S[4];
+  snprintf (path, sizeof path, "%s.summary.txt", basename);
+  FILE *summaryfile = fopen (path, "w");
+  if (!summaryfile)
+    die ("\n Can not open file %s for writing", path);
+  snprintf (path, sizeof path, "%s.pileup.gz", basename);
+  gzFile pileupfile = gzopen (path, "wb");
+  if (!pileupfile)
+    die ("\n Can not open file %s for writing", path);
+  gzbuffer (pileupfile, 33554432);
+  snprintf (path, sizeof path, "%s.indel.txt.gz", basename);
+  gzFile indelfile = gzopen (path, "w");
+  if (!indelfile)
+    die ("\n Can not open file %s for writing", path);
+  gzbuffer (indelfile, 33554432);
+
+  if (total_bases <= 0)
+    {
+      fprintf (summaryfile, "\n================================================================");
+      fprintf (summaryfile, "\n================= Summary ======================================");
+      fprintf (summaryfile, "\n================================================================");
+      fprintf (summaryfile, "\n================================================================");
+      fprintf (summaryfile,
+               "\n\nTotal Number of Mapping reads of Any Kind\t0\tWith average Length\t0\tAverage Depth\t0\tAverage Insert Size\t0");
+      fprintf (summaryfile, "\n\nMapping Type\tCount\tFraction");
+      fprintf (summaryfile, "\nAll\t%ld\t1", tot_pairs);
+      for (int i = 0; i <= 8; i++)
+        if (strstr (c->mate_names[i], "Not Used") == NULL)
+          fprintf (summaryfile, "\n%s\t%ld\t%g", c->mate_names[i], mate_counts[i], (double) mate_counts[i] / (double) tot_pairs);
+      fprintf (summaryfile, "\n");
+      fclose (summaryfile);
+      gzclose (pileupfile);
+      gzclose (indelfile);
+      return;
+    }
+  double avg_readlen = (double) total_bases;
+  if (total_reads > 0)
+    avg_readlen /= (double) total_reads;
+  double avg_dist = (double) total_dist;
+  if (no_dists > 0)
+    avg_dist /= (double) no_dists;
+
+  /* insertion strings, grouped by site */
+  g_nins = 0;
+  g_nchars = 0;
+  ck (c->dev, pemap_dev_fetch_pileup (c->dev, NULL, ins_cb, NULL));
+  qsort (g_ins, g_nins, sizeof (ins_rec), cmp_ins);
+
+  gzprintf (indelfile,
+            "Fragment\tPositions\tReference Base\tTotal Coverage\tReference Reads\tNo Deletions\tNo Insertions\tInsertion Sequence");
+  const uint64_t chunk = 1ull << 26;
+  pile_rec *recs = (pile_rec *) malloc (chunk * sizeof (pile_rec));
+  size_t ip = 0;
+  for (uint64_t first = 0; first < c->gsize; first += chunk)
+    {
+      uint64_t cnt = c->gsize - first < chunk ? c->gsize - first : chunk, n = 0;
+      ck (c->dev, pemap_dev_fetch_records (c->dev, first, cnt, recs, chunk, &n));
+      if (n)
+        gzwrite (pileupfile, recs, (unsigned) (n * sizeof (pile_rec)));
+      for (uint64_t r = 0; r < n; r++)
+        if (recs[r].c[5] > 0)
+          {
+            const uint32_t pos = recs[r].pos;
+            const char ref = c->genome[pos];
+            int tot_c = 0;
+            for (int k = 0; k < 6; k++)
+              tot_c += recs[r].c[k];
+            int ref_reads = ref == 'A' ? recs[r].c[0] : ref == 'C' ? recs[r].c[1] : ref == 'G' ? recs[r].c[2] : recs[r].c[3];
+            int which = find_chrom (c->real_starts, c->n_contigs, 0, c->n_contigs - 1, 7, pos);
+            int contig_pos = 1 + (int) (pos - c->real_starts[which]);
+            gzprintf (indelfile, "\n%s\t%d\t%c\t%d\t%d\t%d\t%d", c->contig_names[which], contig_pos, ref, tot_c, ref_reads,
+                      recs[r].c[4], recs[r].c[5]);
+            while (ip < g_nins && g_ins[ip].pos < pos)
+              ip++;
+            /* the counter is a wrapping u16, the strings are all kept: print as many as the counter says */
+            for (int j = 0; j < recs[r].c[5] && ip < g_nins && g_ins[ip].pos == pos; j++, ip++)
+              gzprintf (indelfile, "\t%s", g_inschars + g_ins[ip].off);
+          }
+    }
+  free (recs);
+  gzclose (pileupfile);
+  gzclose (indelfile);
+  double avg_reads = (double) total_bases / (double) c->gsize;
+  fprintf (summaryfile, "\n================================================================");
+  fprintf (summaryfile, "\n================= Summary ======================================");
+  fprintf (summaryfile, "\n================================================================");
+  fprintf (summaryfile, "\n================================================================");
+  fprintf (summaryfile,
+           "\n\nTotal Number of Mapping reads of Any Kind\t%ld\tWith average Length\t%g\tAverage Depth\t%g\tAverage Insert Size\t%g",
+           total_reads, avg_readlen, avg_reads, avg_dist);
+  fprintf (summaryfile, "\n\nMapping Type\tCount\tFraction");
+  fprintf (summaryfile, "\nAll\t%ld\t1", tot_pairs);
+  for (int i = 0; i <= 8; i++)
+    if (strstr (c->mate_names[i], "Not Used") == NULL)
+      fprintf (summaryfile, "\n%s\t%ld\t%g", c->mate_names[i], mate_counts[i], (double) mate_counts[i] / (double) tot_pairs);
+  fprintf (summaryfile, "\n");
+  fclose (summaryfile);
+  ck (c->dev, pemap_dev_reset_pileup (c->dev));  /* counters and totals start over for the next output name (tsw 917, 948-954) */
+}
+
+static int
+read_name_list (const char *path, char **names, char **outs)
+{
+  FILE *f = fopen (path, "r");
+  if (!f)
+    die ("\n Can not open file %s for reading", path);
+  char line[1100];
+  int n = 0;
+  while (n < MAX_FILES && fgets (line, 1023, f))
+    {
+      char *tok = strtok (line, "\t \n");
+      if (!tok || strlen (tok) <= 2)
+        break;                  /* pemapper.c:258: a name of <= 2 characters ends the list */
+      names[n] = strdup (tok);
+      char *t2 = strtok (NULL, "\t \n");
+      outs[n] = t2 ? strdup (t2) : NULL;
+      n++;
+    }
+  fclose (f);
+  return n;
+}
+
+int
+main (int argc, char *argv[])
+{
+  if (argc < 4)
+    die ("\nUsage: %s out_file sdx_file paired_or_single_or_array[p,s,pa,ps] file1 [file2] [max_dist] [min_dist] is_bisulfite[y,n] min_match_percentage max_threads max_reads [trim_from_start trim_from_end]", argv[0]);
+  const char c_end = (char) toupper (argv[3][0]);
+  const char c_array = (char) toupper (argv[3][1]);
+  int paired, min_dist = 0, max_dist = 0, bis = 0, max_threads, trim_s = 0, trim_e = 0;
+  double min_align;
+  long max_reads;
+  const char *f1arg, *f2arg = NULL;
+  if (c_end == 'S')
+    {
+      if (argc != 9 && argc != 11)
+        die ("\nUsage: %s out_file sdx_file [s,sa] file1 is_bisulfite[y,n] min_match_percentage max_threads max_reads [trim_from_start trim_from_end]", argv[0]);
+      paired = 0;
+      f1arg = argv[4];
+      bis = (strchr (argv[5], 'Y') || strchr (argv[5], 'y'));
+      min_align = atof (argv[6]);
+      max_threads = atoi (argv[7]);
+      max_reads = (long) atoi (argv[8]);
+      if (argc == 11)
+        {
+          trim_s = atoi (argv[9]);
+          trim_e = atoi (argv[10]);
+        }
+    }
+  else if (c_end == 'P')
+    {
+      if (argc != 12 && argc != 14)
+        die ("\nUsage: %s out_file sdx_file [p,pa] file1 file2 max_dist min_dist is_bisulfite[y,n] min_match_percentage max_threads max_reads [trim_from_start trim_from_end]", argv[0]);
+      paired = 1;
+      f1arg = argv[4];
+      f2arg = argv[5];
+      max_dist = atoi (argv[6]);
+      min_dist = atoi (argv[7]);
+      bis = (strchr (argv[8], 'Y') || strchr (argv[8], 'y'));
+      min_align = atof (argv[9]);
+      max_threads = atoi (argv[10]);
+      max_reads = atol (argv[11]);
+      if (argc == 14)
+        {
+          trim_s = atoi (argv[12]);
+          trim_e = atoi (argv[13]);
+        }
+    }
+  else
+    die ("\nUsage: %s out_file sdx_file paired_or_single_or_array[p,s,pa,ps] file1 [file2] [max_dist] [min_dist] is_bisulfite[y,n] min_match_percentage max_threads max_reads", argv[0]);
+  if ((max_threads < 2) || (max_threads > 10000))
+    {
+      printf ("\n Max_threads is not a sensible number (2,10000).  You gave %d \n", max_threads);
+      exit (1);
+    }
+  char **names1 = (char **) calloc (MAX_FILES + 1, sizeof (char *));
+  char **names2 = (char **) calloc (MAX_FILES + 1, sizeof (char *));
+  char **outs = (char **) calloc (MAX_FILES + 1, sizeof (char *));
+  char **outs2 = (char **) calloc (MAX_FILES + 1, sizeof (char *));
+  int file_num = 1;
+  if (c_array == 'A')
+    {
+      file_num = read_name_list (f1arg, names1, outs);
+      if (paired && read_name_list (f2arg, names2, outs2) != file_num)
+        die ("\n Mismatch in number of files in the two arrays %s", "");
+      if (file_num >= MAX_FILES)
+        die ("\n Too many files found in array... 2000 is the limit %s", "");
+    }
+  else
+    {
+      names1[0] = strdup (f1arg);
+      if (paired)
+        names2[0] = strdup (f2arg);
+    }
+
+  /* ---- .sdx: count, then "len-15 <tab> name" per contig, then idepth (pemapper.c:394-448) */
+  char sdxname[1024], path[1100], line[1100];
+  strncpy (sdxname, argv[2], 1000);
+  sdxname[1000] = 0;
+  FILE *sfile = fopen (sdxname, "r");
+  if (!sfile)
+    die ("\n Can not open file %s", sdxname);
+  if (strstr (sdxname, ".sdx") != NULL)
+    for (int i = (int) strlen (sdxname) - 1; i > 0; i--)
+      if (sdxname[i] == '.')
+        {
+          sdxname[i] = '\0';
+          i = 0;
+        }
+  if (!fgets (line, 256, sfile))
+    die ("\n Empty file %s", argv[2]);
+  const int n_contigs = atoi (line);
+  if (n_contigs < 1)
+    die ("\n No contigs in %s", argv[2]);
+  ctx_t c;
+  memset (&c, 0, sizeof c);
+  c.n_contigs = n_contigs;
+  c.paired = paired;
+  c.contig_names = (char **) calloc ((size_t) n_contigs + 1, sizeof (char *));
+  uint32_t *contig_len = (uint32_t *) calloc ((size_t) n_contigs + 1, sizeof (uint32_t));
+  uint32_t *contig_starts = (uint32_t *) calloc ((size_t) n_contigs + 2, sizeof (uint32_t));
+  c.real_starts = (uint32_t *) calloc ((size_t) n_contigs + 2, sizeof (uint32_t));
+  for (int i = 0; i < n_contigs; i++)
+    {
+      if (!fgets (line, 1024, sfile))
+        die ("\n Truncated file %s", argv[2]);
+      char *tok = strtok (line, "\t \n");
+      contig_len[i] = (uint32_t) atoi (tok) + 15u;
+      tok = strtok (NULL, "\t \n");
+      c.contig_names[i] = strdup (tok ? tok : "");
+      contig_starts[i + 1] = contig_starts[i] + (contig_len[i] - 15u);
+      c.real_starts[i + 1] = c.real_starts[i] + contig_len[i];
+    }
+  int idepth = 16;
+  if (fgets (line, 1024, sfile))
+    idepth = atoi (line);
+  fclose (sfile);
+  c.gsize = c.real_starts[n_contigs];
+  printf ("\n Genome size is %ld \n\n", (long) c.gsize);
+
+  /* ---- genome letters */
+  snprintf (path, sizeof path, "%s.seq", sdxname);
+  gzFile reffile = gzopen (path, "r");
+  if (!reffile)
+    die ("\n Can not open file %s for reading", path);
+  gzbuffer (reffile, 33554432);
+  char *genome = (char *) malloc (c.gsize + 1);
+  printf ("\n About to read genome \n\n");
+  for (uint64_t got = 0; got < c.gsize;)
+    {
+      unsigned want = (unsigned) ((c.gsize - got) < (1u << 30) ? (c.gsize - got) : (1u << 30));
+      int r = gzread (reffile, genome + got, want);
+      if (r <= 0)
+        die ("\n Short read on %s", path);
+      got += (uint64_t) r;
+    }
+  gzclose (reffile);
+  c.genome = genome;
+
+  pemap_dev *dev = NULL;
+  const char *devs = getenv ("PEMAP_DEVICE");
+  if (pemap_dev_create (&dev, devs ? atoi (devs) : 0))
+    {
+      printf ("\n pemap_hip: %s\n", pemap_dev_last_error (NULL));
+      exit (1);
+    }
+  c.dev = dev;
+  printf ("\n About to read kmers index \n\n");
+  const char *from_files = getenv ("PEMAP_INDEX_FROM_FILES");
+  if (from_files && atoi (from_files))
+    {
+      /* init_index_buffer, pemapper.c:2129-2155 */
+      const uint64_t NI = (1ull << 32) + 1ull;
+      uint32_t *pos_index = (uint32_t *) malloc (NI * sizeof (uint32_t));
+      snprintf (path, sizeof path, "%s.idx", sdxname);
+      gzFile ifile = gzopen (path, "r");
+      if (!pos_index || !ifile)
+        die ("\nCould Not Open file %s", path);
+      gzbuffer (ifile, 33554432);
+      for (uint64_t got = 0; got < NI * 4;)
+        {
+          unsigned want = (unsigned) ((NI * 4 - got) < (1u << 30) ? (NI * 4 - got) : (1u << 30));
+          int r = gzread (ifile, (char *) pos_index + got, want);
+          if (r <= 0)
+            die ("\n Short read on %s", path);
+          got += (uint64_t) r;
+        }
+      gzclose (ifile);
+      uint64_t n_mers = pos_index[NI - 1];
+      uint32_t *mers = (uint32_t *) malloc ((n_mers + 1) * sizeof (uint32_t));
+      snprintf (path, sizeof path, "%s.mdx", sdxname);
+      FILE *mf = fopen (path, "r");
+      if (!mf || fread (mers, sizeof (uint32_t), n_mers, mf) != n_mers)
+        die ("\nCould Not read file %s", path);
+      fclose (mf);
+      ck (dev, pemap_dev_load_index (dev, pos_index, mers, n_mers, genome, c.gsize, contig_starts, n_contigs, idepth));
+      free (pos_index);
+      free (mers);
+    }
+  else
+    ck (dev, pemap_dev_build_index (dev, genome, c.gsize, contig_len, n_contigs, bis));
+  ck (dev, pemap_dev_set_params (dev, paired, min_dist, max_dist, min_align, bis));
+
+  if (paired)
+    {
+      const char *nm[9] = { "Unique Mate-Paired", "Unique Mate-Paired with slip", "Unique Single End", "Unique Mis-size",
+        "Non-Unique Mate-Paired", "Non-Unique Mis-size", "Fragment Mismatch", "Non-unique with no map", "Neither Map"
+      };
+      for (int i = 0; i < 9; i++)
+        strcpy (c.mate_names[i], nm[i]);
+    }
+  else
+    {
+      const char *nm[9] = { "Not Used", "Not Used", "Unique Mapping", "Not Used", "Not Used", "Not Used", "Not Used",
+        "Non-Unique Mapping, discarded", "No mapping reaches threshold"
+      };
+      for (int i = 0; i < 9; i++)
+        strcpy (c.mate_names[i], nm[i]);
+    }
+
+  char basename[1024];
+  strncpy (basename, argv[1], 1000);
+  basename[1000] = 0;
+  char *r1 = (char *) malloc ((size_t) BATCH_PAIRS * ROW_STRIDE), *r2 = paired ? (char *) malloc ((size_t) BATCH_PAIRS * ROW_STRIDE) : NULL;
+  int *l1 = (int *) malloc (sizeof (int) * BATCH_PAIRS), *l2 = (int *) malloc (sizeof (int) * BATCH_PAIRS);
+  int *mt = (int *) malloc (sizeof (int) * BATCH_PAIRS);
+  printf ("\n About to start mapping everything \n\n");
+  long tot_pairs = 0;
+  for (int iter = 0; iter < file_num; iter++)
+    {
+      printf ("\n About to open new set of files \n");
+      /* pemapper_tsw.c:636-648: a new output name closes the previous output set */
+      if (outs[iter] && strcmp (basename, outs[iter]) != 0)
+        {
+          if (iter > 0)
+            {
+              dump_output (&c, basename, tot_pairs);
+              tot_pairs = 0;
+            }
+          strncpy (basename, outs[iter], 1000);
+        }
+      lreader in1, in2;
+      lr_open (&in1, names1[iter]);
+      if (paired)
+        lr_open (&in2, names2[iter]);
+      size_t cap = 1 << 20, current_read = 0;
+      uint32_t *maps1 = (uint32_t *) calloc (cap, sizeof (uint32_t)), *maps2 = paired ? (uint32_t *) calloc (cap, sizeof (uint32_t)) : NULL;
+      /* first record: header line, then the sequence (pemapper.c:649-656) */
+      char *s2 = NULL, *s1;
+      if (paired)
+        {
+          lr_gets (&in2);
+          s2 = lr_gets (&in2);
+        }
+      lr_gets (&in1);
+      s1 = lr_gets (&in1);
+      int not_done = (s1 != NULL) && (!paired || s2 != NULL);
+      int nb = 0;
+      printf ("\n Ready to map \n");
+      while (not_done)
+        {
+          /* trimming, pemapper_tsw.c:693-704 */
+          int sl1 = (int) strlen (s1) - trim_s;
+          s1 += (sl1 >= 0) ? trim_s : (int) strlen (s1);
+          sl1 = sl1 - trim_e;
+          if (sl1 < 0)
+            sl1 = 0;
+          int sl2 = 0;
+          if (paired)
+            {
+              sl2 = (int) strlen (s2) - trim_s;
+              s2 += (sl2 >= 0) ? trim_s : (int) strlen (s2);
+              sl2 = sl2 - trim_e;
+              if (sl2 < 0)
+                sl2 = 0;
+            }
+          if (sl1 <= 12)
+            break;              /* pemapper.c:663 */
+          if (sl1 > PEMAP_MAX_READ || sl1 < PEMAP_MIN_READ || (paired && (sl2 > PEMAP_MAX_READ || sl2 < PEMAP_MIN_READ)))
+            {
+              printf ("\n Read %ld of %s has length %d/%d: supported range is %d..%d \n", (long) current_read, names1[iter], sl1, sl2,
+                      PEMAP_MIN_READ, PEMAP_MAX_READ);
+              exit (1);
+            }
+          memcpy (r1 + (size_t) nb * ROW_STRIDE, s1, (size_t) sl1);
+          l1[nb] = sl1;
+          if (paired)
+            {
+              memcpy (r2 + (size_t) nb * ROW_STRIDE, s2, (size_t) sl2);
+              l2[nb] = sl2;
+            }
+          nb++;
+          current_read++;
+          if ((long) current_read >= max_reads)
+            not_done = 0;
+          else
+            {
+              /* skip two lines, then scan to the next line that starts with '@'; the line after it is the sequence
+                 (pemapper.c:713-748) */
+              lr_gets (&in1);
+              lr_gets (&in1);
+              s1 = lr_gets (&in1);
+              int not_there = 1;
+              while (s1 != NULL && not_there)
+                {
+                  if (s1[0] == '@')
+                    not_there = 0;
+                  s1 = lr_gets (&in1);
+                }
+              if (not_there || s1 == NULL)
+                not_done = 0;
+              if (paired && not_done)
+                {
+                  not_there = 1;
+                  lr_gets (&in2);
+                  lr_gets (&in2);
+                  s2 = lr_gets (&in2);
+                  while (s2 != NULL && not_there)
+                    {
+                      if (s2[0] == '@')
+                        not_there = 0;
+                      s2 = lr_gets (&in2);
+                    }
+                  if (not_there || s2 == NULL)
+                    not_done = 0;
+                }
+            }
+          if (nb == BATCH_PAIRS || !not_done)
+            {
+              if (current_read > cap)
+                {
+                  size_t ncap = cap;
+                  while (ncap < current_read)
+                    ncap *= 2;
+                  maps1 = (uint32_t *) realloc (maps1, ncap * sizeof (uint32_t));
+                  if (paired)
+                    maps2 = (uint32_t *) realloc (maps2, ncap * sizeof (uint32_t));
+                  cap = ncap;
+                }
+              ck (dev, pemap_dev_map_batch (dev, r1, l1, r2, l2, nb, ROW_STRIDE, maps1 + (current_read - (size_t) nb),
+                                            paired ? maps2 + (current_read - (size_t) nb) : NULL, mt));
+              printf ("\n We have read %ld reads \n\n", (long) current_read);
+              nb = 0;
+            }
+        }
+      if (nb > 0)               /* loop left through the length test */
+        {
+          if (current_read > cap)
+            {
+              maps1 = (uint32_t *) realloc (maps1, current_read * sizeof (uint32_t));
+              if (paired)
+                maps2 = (uint32_t *) realloc (maps2, current_read * sizeof (uint32_t));
+            }
+          ck (dev, pemap_dev_map_batch (dev, r1, l1, r2, l2, nb, ROW_STRIDE, maps1 + (current_read - (size_t) nb),
+                                        paired ? maps2 + (current_read - (size_t) nb) : NULL, mt));
+        }
+      printf ("\n Made it out alive, and have started cleanup \n\n");
+      snprintf (path, sizeof path, "%s.mfile", names1[iter]);
+      FILE *m = fopen (path, "wb");
+      if (!m)
+        die ("\n Can not open file %s", path);
+      fwrite (maps1, sizeof (uint32_t), current_read, m);
+      fclose (m);
+      if (paired)
+        {
+          snprintf (path, sizeof path, "%s.mfile", names2[iter]);
+          m = fopen (path, "wb");
+          if (!m)
+            die ("\n Can not open file %s", path);
+          fwrite (maps2, sizeof (uint32_t), current_read, m);
+          fclose (m);
+          lr_close (&in2);
+        }
+      lr_close (&in1);
+      free (maps1);
+      free (maps2);
+      tot_pairs += (long) current_read;
+    }
+  dump_output (&c, basename, tot_pairs);
+  pemap_dev_destroy (dev);
+  return 0;
+}

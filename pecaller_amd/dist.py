@@ -1,0 +1,69 @@
+"""Multi-GPU plumbing of the mapping path (one process per GPU, torch.distributed; backend "nccl" is RCCL on ROCm).
+
+The path shards by reads: every rank holds a full index replica and its own pileup counters, nothing is exchanged
+while mapping.  Two collectives exist, both outside the timed loop:
+  * broadcast_index: rank `src` loaded or built the index; the others receive pos_index / mers / genome / contig table;
+  * reduce_pileup:   element-wise sum of the u32 counters (the reference's shared all_base_list, pemapper.c:156).  The
+    reference's counters are unsigned short and wrap; sums are taken in 32 bits and truncated at the writer, which is the
+    same arithmetic (int32 two's-complement addition == uint32 addition).
+shard_range gives the contiguous slice of reads a rank maps; .mfile entries are concatenated in rank order.
+The tensors may live on the GPU (wrapping the device pointers of pemap_dev_buffer) or on the CPU (gloo tests).
+"""
+import numpy as np
+
+
+def shard_range(n_reads, rank, world):
+    """contiguous, balanced: the first n_reads % world ranks get one extra read"""
+    base, rem = divmod(n_reads, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class DevArray:
+    """exposes a device pointer handed out by the C-ABI to torch through __cuda_array_interface__"""
+
+    def __init__(self, ptr, n_items, typestr):
+        self.__cuda_array_interface__ = {"shape": (n_items,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def device_tensor(torch, dev, which):
+    """torch view (no copy) of one of the object's resident buffers; u32 arrays are viewed as int32"""
+    ptr, nbytes = dev.buffer(which)
+    if which == 2:
+        return torch.as_tensor(DevArray(ptr, nbytes, "|u1"), device="cuda")
+    return torch.as_tensor(DevArray(ptr, nbytes // 4, "<i4"), device="cuda")
+
+
+def _chunks(t, chunk):
+    n = t.numel()
+    for o in range(0, n, chunk):
+        yield t[o:min(n, o + chunk)]
+
+
+def broadcast_tensors(dist, tensors, src=0, chunk=1 << 28):
+    for t in tensors:
+        for c in _chunks(t, chunk):
+            dist.broadcast(c, src=src)
+
+
+def reduce_pileup(dist, counts, dst=None, chunk=1 << 28):
+    """in-place sum of the int32-viewed counters over all ranks (all_reduce, or reduce to `dst`)"""
+    for c in _chunks(counts.view(-1), chunk):
+        if dst is None:
+            dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        else:
+            dist.reduce(c, dst=dst, op=dist.ReduceOp.SUM)
+    return counts
+
+
+def counts_to_u16(counts_i32):
+    """what the pileup writer does with the summed counters (numpy or torch int32 array)"""
+    a = counts_i32.cpu().numpy() if hasattr(counts_i32, "cpu") else np.asarray(counts_i32)
+    return a.astype(np.uint32).astype(np.uint16)
+
+
+def merge_summaries(dist, torch, summary13):
+    """scalar totals and class histogram are plain sums over ranks (pemapper.c:1238-1265)"""
+    t = torch.as_tensor(np.asarray(summary13, dtype=np.int64))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.numpy()

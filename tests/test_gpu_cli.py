@@ -1,0 +1,75 @@
+"""The C host program (pecaller_amd/pemapper_hip) run as a drop-in for the reference's pemapper / pemapper_tsw command
+lines on the golden fixture: output FILES compared with the reference's."""
+import gzip
+import os
+import shutil
+import subprocess
+import numpy as np
+import pytest
+import fixtures
+import refio
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "pecaller_amd", "pemapper_hip")
+
+
+def _prep(tmp_path):
+    """index files next to each other as the reference expects: <base>.sdx and <base>.seq (gz of the letters)"""
+    ix = fixtures.index()
+    shutil.copy(os.path.join(fixtures.GOLD, "g1.sdx"), tmp_path / "g1.sdx")
+    with gzip.open(tmp_path / "g1.seq", "wb", compresslevel=1) as f:
+        f.write(ix["genome"].tobytes())
+    return str(tmp_path / "g1.sdx")
+
+
+def _compare(name, out, f1, f2):
+    m = fixtures.meta()[name]
+    assert np.array_equal(np.fromfile(f1 + ".mfile", dtype="<u4"), fixtures.golden_m(name, 1))
+    if f2:
+        assert np.array_equal(np.fromfile(f2 + ".mfile", dtype="<u4"), fixtures.golden_m(name, 2))
+    pile = refio.read_pileup(out + ".pileup.gz")
+    assert len(pile) == m["pileup_records"] and refio.md5(pile) == m["pileup_md5"]
+    assert refio.read_indel(out + ".indel.txt.gz") == refio.read_indel(os.path.join(fixtures.GOLD, name + ".indel.txt.gz"))
+    assert open(out + ".summary.txt").read() == open(os.path.join(fixtures.GOLD, name + ".summary.txt")).read()
+
+
+@pytest.mark.parametrize("name", ["r150", "r100", "r250"])
+def test_cli_outputs_equal_reference(tmp_path, name):
+    assert os.path.exists(EXE), "build with make -C pecaller_amd/csrc"
+    sdx = _prep(tmp_path)
+    s = fixtures.SETS[name]
+    f1 = str(tmp_path / ("%s_1_.fastq.gz" % s["prefix"]))
+    shutil.copy(os.path.join(fixtures.GOLD, os.path.basename(f1)), f1)
+    f2 = None
+    out = str(tmp_path / "out")
+    extra = [str(x) for x in fixtures.meta()[name]["extra_args"]]
+    if s["paired"]:
+        f2 = str(tmp_path / ("%s_2_.fastq.gz" % s["prefix"]))
+        shutil.copy(os.path.join(fixtures.GOLD, os.path.basename(f2)), f2)
+        cmd = [EXE, out, sdx, "p", f1, f2, "500", "0", "N", "0.85", "8", "200000000"] + extra
+    else:
+        cmd = [EXE, out, sdx, "s", f1, "N", "0.85", "8", "200000000"] + extra
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    _compare(name, out, f1, f2)
+
+
+def test_cli_array_mode_and_max_reads(tmp_path):
+    """'pa' array files (pemapper.c:307-348) and the max_reads cut (709-710)"""
+    sdx = _prep(tmp_path)
+    f1 = str(tmp_path / "g1_1_.fastq.gz")
+    f2 = str(tmp_path / "g1_2_.fastq.gz")
+    shutil.copy(os.path.join(fixtures.GOLD, "g1_1_.fastq.gz"), f1)
+    shutil.copy(os.path.join(fixtures.GOLD, "g1_2_.fastq.gz"), f2)
+    (tmp_path / "a1.txt").write_text(f1 + "\n")
+    (tmp_path / "a2.txt").write_text(f2 + "\n")
+    out = str(tmp_path / "outa")
+    subprocess.check_call([EXE, out, sdx, "pa", str(tmp_path / "a1.txt"), str(tmp_path / "a2.txt"), "500", "0", "N", "0.85", "8",
+                           "5000"], stdout=subprocess.DEVNULL)
+    m1 = np.fromfile(f1 + ".mfile", dtype="<u4")
+    assert len(m1) == 5000 and np.array_equal(m1, fixtures.golden_m("r150", 1)[:5000])
+    # bad arguments fail like the reference: usage text, exit status 1
+    r = subprocess.run([EXE, out, sdx, "p", f1], stdout=subprocess.PIPE)
+    assert r.returncode == 1 and b"Usage" in r.stdout
+    r = subprocess.run([EXE, out, sdx, "s", f1, "N", "0.85", "1", "100"], stdout=subprocess.PIPE)
+    assert r.returncode == 1 and b"Max_threads" in r.stdout
