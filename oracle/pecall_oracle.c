@@ -6,10 +6,10 @@
  * gammln, src/pecaller.c:3163-3214).  Used by tests/ and bench.py's cpu_baseline only; nothing under pecaller_amd/
  * links it.  Built with -ffp-contract=off.
  *
- * Parity pin: the reference's pecaller writes only final calls/posteriors (after its configuration search), not the
- * per-sample likelihoods, so this function is pinned through tests/test_pecall_golden.py, which feeds these
- * likelihoods into the restated single-sample posterior and compares with the reference's .base.gz probabilities
- * for INDIV = 1 runs; see DESIGN.md.
+ * Parity pin: tests/golden/pecall_like.npz holds the inputs and outputs of the reference's own fill_sample_like for
+ * 4032 (site, pass) records of a 6-sample run, captured from an instrumented scratch build of the reference
+ * (tests/golden/make_golden_pecall.py).  tests/test_pecall.py::test_oracle_matches_reference_dump requires equality to the
+ * last bit on this host (same formula, same libm).
  */
 #include <math.h>
 #include <stdint.h>

@@ -1,0 +1,72 @@
+"""ctypes mirror of the pecall_dev_* entry points of include/pemap_hip.h (PECaller per-site genotype likelihoods)."""
+import ctypes as C
+import numpy as np
+from .pemap import load_library, PemapError
+
+MAX_GEN = 14
+ALLELES = 6
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data
+
+
+class PecallDev:
+    def __init__(self, device_id=0):
+        L = load_library()
+        vp, i, dbl = C.c_void_p, C.c_int, C.c_double
+        L.pecall_dev_create.argtypes = [C.POINTER(vp), i]
+        L.pecall_dev_destroy.argtypes = [vp]
+        L.pecall_dev_destroy.restype = None
+        L.pecall_dev_last_error.argtypes = [vp]
+        L.pecall_dev_last_error.restype = C.c_char_p
+        L.pecall_dev_site_like.argtypes = [vp, vp, vp, i, i, i, i, dbl, vp, vp, vp]
+        L.pecall_dev_stage.argtypes = [vp, vp, vp, i, i]
+        L.pecall_dev_run.argtypes = [vp, i, i, i, i, dbl, i]
+        L.pecall_dev_collect.argtypes = [vp, i, i, vp, vp, vp]
+        self.L = L
+        h = vp()
+        if L.pecall_dev_create(C.byref(h), device_id):
+            raise PemapError(L.pecall_dev_last_error(None).decode())
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pecall_dev_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _ck(self, rc):
+        if rc:
+            raise PemapError(self.L.pecall_dev_last_error(self.h).decode())
+
+    def site_like(self, reads, alpha_mean, norm, max_gen=14, min_depth=2):
+        """reads [n_sites][indiv][6] u16, alpha_mean [n_sites][14][6] f64 -> like [n_sites][indiv][14], best, margin"""
+        reads = np.ascontiguousarray(reads, np.uint16)
+        alpha_mean = np.ascontiguousarray(alpha_mean, np.float64)
+        n_sites, indiv = reads.shape[:2]
+        like = np.zeros((n_sites, indiv, MAX_GEN))
+        best = np.zeros((n_sites, indiv), np.int8)
+        margin = np.zeros((n_sites, indiv))
+        self._ck(self.L.pecall_dev_site_like(self.h, _p(reads), _p(alpha_mean), n_sites, indiv, max_gen, min_depth, norm, _p(like),
+                                             _p(best), _p(margin)))
+        return like, best, margin
+
+    def stage(self, reads, alpha_mean):
+        reads = np.ascontiguousarray(reads, np.uint16)
+        alpha_mean = np.ascontiguousarray(alpha_mean, np.float64)
+        self._shape = reads.shape[:2]
+        self._ck(self.L.pecall_dev_stage(self.h, _p(reads), _p(alpha_mean), reads.shape[0], reads.shape[1]))
+
+    def run(self, norm, max_gen=14, min_depth=2, sync=True):
+        self._ck(self.L.pecall_dev_run(self.h, self._shape[0], self._shape[1], max_gen, min_depth, norm, int(sync)))
+
+    def collect(self):
+        n_sites, indiv = self._shape
+        like = np.zeros((n_sites, indiv, MAX_GEN))
+        best = np.zeros((n_sites, indiv), np.int8)
+        margin = np.zeros((n_sites, indiv))
+        self._ck(self.L.pecall_dev_collect(self.h, n_sites, indiv, _p(like), _p(best), _p(margin)))
+        return like, best, margin

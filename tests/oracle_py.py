@@ -129,3 +129,35 @@ def sw(ref, seq, bisulfite=False, planes=False):
     pl = np.zeros(3 * (len(ref) + 1) * (len(seq) + 1)) if planes else None
     s = L.ora_sw(bytes(ref), len(ref), bytes(seq), len(seq), int(bisulfite), _p(st), _p(pl))
     return s, st, (pl.reshape(3, len(ref) + 1, len(seq) + 1) if planes else None)
+
+
+# ---- PECaller likelihood oracle (oracle/pecall_oracle.c)
+_plib = None
+
+
+def pecall_lib():
+    global _plib
+    if _plib is None:
+        so = os.path.join(ROOT, "oracle", "liboracle_pecall.so")
+        src = os.path.join(ROOT, "oracle", "pecall_oracle.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), so])
+        L = C.CDLL(so)
+        L.ora_site_like.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p,
+                                    C.c_void_p]
+        L.ora_factln.restype = C.c_double
+        L.ora_factln.argtypes = [C.c_int]
+        _plib = L
+    return _plib
+
+
+def site_like(reads, alpha_mean, norm, max_gen=14, min_depth=2):
+    L = pecall_lib()
+    reads = np.ascontiguousarray(reads, np.uint16)
+    alpha_mean = np.ascontiguousarray(alpha_mean, np.float64)
+    n_sites, indiv = reads.shape[:2]
+    like = np.zeros((n_sites, indiv, 14))
+    best = np.zeros((n_sites, indiv), np.int8)
+    margin = np.zeros((n_sites, indiv))
+    L.ora_site_like(_p(reads), _p(alpha_mean), n_sites, indiv, max_gen, min_depth, norm, _p(like), _p(best), _p(margin))
+    return like, best, margin
