@@ -153,8 +153,8 @@ extern "C" int pemap_dev_create (pemap_dev ** out, int device_id)
       return 1;
     }
   int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  d->seed_grid = cus * 8;
-  d->sw_grid = cus * 16;
+  { const char *sg = getenv ("PEMAP_SEED_BLOCKS_PER_CU"); d->seed_grid = cus * (sg ? atoi (sg) : 8); }
+  { const char *sg = getenv ("PEMAP_SW_WAVES_PER_CU"); d->sw_grid = cus * (sg ? atoi (sg) : 16); }
   if (hipStreamCreateWithFlags (&d->stream, hipStreamNonBlocking) != hipSuccess)
     {
       delete d;

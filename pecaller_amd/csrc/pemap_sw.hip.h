@@ -24,8 +24,8 @@
 //
 // With DIRS the four comparisons the traceback will make at a cell (pemapper.c:1799-1831) are stored as one nibble:
 //   bit0 S1>S0   bit1 S2>max(S0,S1)   bit2 S1-ge > S0-go   bit3 S2-ge > S0-go
-// in the alignment's direction slab: dword ((g * tstride + step-1) * DW + c/8), nibble c%8 -- lane-major, so that the
-// diagonal walk of the traceback reads consecutive addresses.
+// in the alignment's direction slab: dword ((g * tstride + step-1) * DW + c/8), first cell of a dword in its highest
+// nibble -- lane-major, so that the diagonal walk of the traceback reads consecutive addresses.
 // ============================================================================================================
 #define PM_GO 2.0
 #define PM_GE (1.0 / 36.0)
@@ -75,14 +75,31 @@ __device__ __forceinline__ uint8_t pm_oriented (const uint8_t * read, int mm, in
   return orient ? pm_rc (read[mm - 1 - jz]) : read[jz];
 }
 
-// one DP cell; after unrolling all state lives in registers
-template < bool DIRS > __device__ __forceinline__ void pm_cell (double &dg, double &s2, double &U1c, double &Dc, uint32_t mword, int bit,
-                                                                uint32_t & dword, int nibpos, double &o0, double &o1, double &o2)
+// Bonus constants as bit patterns: 1.0 = 0x3FF00000'00000000, -1/3 = 0xBFD55555'55555555 (pemapper.c:2011-2019).
+struct PmBumpK
 {
-  // bonus = match ? 1.0 : -1/3 (pemapper.c:2011-2019), assembled from the mask bit without a branch
-  const int t = __builtin_amdgcn_sbfe ((int) mword, bit, 1);            // 0 or -1
-  const uint32_t hi = ((uint32_t) t & 0x3FF00000u) | (~(uint32_t) t & 0xBFD55555u);
-  const uint32_t lo = ~(uint32_t) t & 0x55555555u;
+  uint32_t hi_match, hi_miss, lo_miss;
+};
+
+// acc = 2 * acc + (a > b): the compare writes a lane mask to an SGPR pair and v_addc_co_u32 shifts it in as the carry --
+// two instructions per stored comparison instead of compare + select + shift/or.
+__device__ __forceinline__ void pm_push_gt (uint32_t & acc, double a, double b)
+{
+  const unsigned long long m = __builtin_amdgcn_fcmp (a, b, 2);  // FCMP_OGT
+  unsigned long long carry_out;
+  asm ("v_addc_co_u32 %0, %1, %0, %0, %2":"+v" (acc), "=s" (carry_out):"s" (m));
+}
+
+// one DP cell; after unrolling all state lives in registers
+template < bool DIRS > __device__ __forceinline__ void pm_cell (double &dg, double &s2, double &U1c, double &Dc, uint32_t mword, const int bit,
+                                                                const PmBumpK & bk, uint32_t & dword, double &o0, double &o1, double &o2)
+{
+  // bonus = match ? 1.0 : -1/3, assembled from the mask bit: v_bfe_i32 (0 / -1) and two v_bfi_b32
+  int t;
+  uint32_t hi, lo;
+  asm ("v_bfe_i32 %0, %1, %2, 1":"=v" (t):"v" (mword), "n" (bit));
+  asm ("v_bfi_b32 %0, %1, %2, %3":"=v" (hi):"v" (t), "v" (bk.hi_match), "v" (bk.hi_miss));
+  asm ("v_bfi_b32 %0, %1, 0, %2":"=v" (lo):"v" (t), "v" (bk.lo_miss));
   const double bump = __hiloint2double ((int) hi, (int) lo);
   const double s1 = U1c;
   const double s0 = dg + bump;
@@ -95,8 +112,11 @@ template < bool DIRS > __device__ __forceinline__ void pm_cell (double &dg, doub
   Dc = pm_max (m01, s2);
   if (DIRS)
     {
-      uint32_t nib = (s1 > s0 ? 1u : 0u) | (s2 > m01 ? 2u : 0u) | (x1 > a0 ? 4u : 0u) | (x2 > a0 ? 8u : 0u);
-      dword |= nib << nibpos;
+      // nibble, most significant bit first: S2-ge > S0-go, S1-ge > S0-go, S2 > max(S0,S1), S1 > S0
+      pm_push_gt (dword, x2, a0);
+      pm_push_gt (dword, x1, a0);
+      pm_push_gt (dword, s2, m01);
+      pm_push_gt (dword, s1, s0);
     }
   o0 = s0;
   o1 = s1;
@@ -107,6 +127,11 @@ template < bool DIRS > __device__ __forceinline__ void pm_cell (double &dg, doub
 template < int W > struct PmSwGeom
 {
   static constexpr int DW = (W * 4 + 31) / 32;   // dwords of direction nibbles per lane per row
+  // Cells are shifted into their dword first-in-highest: cell c of a lane sits in dword c / 8 at this bit offset
+  __host__ __device__ static constexpr int nib_shift (int c)
+  {
+    return 4 * (((W - (c / 8) * 8) < 8 ? (W - (c / 8) * 8) : 8) - 1 - (c % 8));
+  }
 };
 
 // match mask of one lane's columns against an arbitrary reference byte (IUPAC codes, lower case): rare, kept out of line
@@ -200,6 +225,10 @@ __device__ __forceinline__ void pm_sw_forward (const PmSwTask & tk, int bis, int
       D[c] = bj;
       U1[c] = (j >= 1) ? pm_max (bj - PM_GO, bj - PM_GE) : PM_NEGBIG;
     }
+  PmBumpK bumpk;
+  bumpk.hi_match = 0x3FF00000u;
+  bumpk.hi_miss = 0xBFD55555u;
+  bumpk.lo_miss = 0x55555555u;
   double Dprev = pm_top (g * W - pad);     // max3 of the cell left of this lane's first column, row 0
   const double R2in0 = (pad > 0) ? PM_NEGBIG : pm_max (0.0 - PM_GO, -PM_GO - PM_GE);        // S2[i][1] from the border (2079-2081)
   const double Dimp0 = pm_top (-pad);
@@ -234,7 +263,7 @@ __device__ __forceinline__ void pm_sw_forward (const PmSwTask & tk, int bis, int
           double o0 = 0.0, o1 = 0.0, o2 = 0.0;
 #pragma unroll
           for (int c = 0; c < W; c++)
-            pm_cell < DIRS > (dg, s2, U1[c], D[c], (c < 32) ? m0 : m1, c & 31, dw[c >> 3], (c & 7) * 4, o0, o1, o2);
+            pm_cell < DIRS > (dg, s2, U1[c], D[c], (c < 32) ? m0 : m1, c & 31, bumpk, dw[c >> 3], o0, o1, o2);
           // The last column of lane 7 is read column mm: rows ascending, planes 0,1,2, strict '>' (pemapper.c:1724-1741).
           // Every lane runs the selects (no branch); only lane 7's result is read.
           const bool u0 = o0 > bst;
@@ -595,7 +624,8 @@ template < int W > __global__ __launch_bounds__ (256) void pm_walk_kernel (PmBat
             {
               const int J = cj - 1 + pad, gg = J / W, c = J - gg * W;
               const uint32_t wv = slab[((size_t) gg * tstride + (ci + gg - 1)) * DW + (c >> 3)];
-              const uint32_t nib = (wv >> ((c & 7) * 4)) & 0xFu;
+              const int nd = (W - (c >> 3) * 8) < 8 ? (W - (c >> 3) * 8) : 8;      // cells in this dword
+              const uint32_t nib = (wv >> (4 * (nd - 1 - (c & 7)))) & 0xFu;
               if (k == 0)
                 maxk = (nib & 2u) ? 2 : ((nib & 1u) ? 1 : 0);
               else if (k == 2)
