@@ -14,6 +14,7 @@
 #include <rocprim/rocprim.hpp>
 
 static char g_create_err[512] = "";
+struct PmChunkCtr;
 
 struct pemap_dev
 {
@@ -53,11 +54,22 @@ struct pemap_dev
   int seed_grid, sw_grid;
   // run bookkeeping
   int run_first, run_n;
-  bool run_pending;             // kernels of the last chunk still in flight / not yet accounted
+  bool run_pending;             // kernels of the last run still in flight / not yet accounted
+  bool run_split, serial_split;
+  int run_chunks;
   hipEvent_t ev[7];
+  // two-stream pipeline: the look-up kernel of chunk k+1 (memory stream) runs beside vote/SW/walk of chunk k
+  hipStream_t stream2;
+  hipEvent_t ev_lists_ready[2], ev_lists_free[2];
+  PmLists lists[2];
+  int lists_cap;
+  PmChunkCtr *d_chunk_ctr;
+  std::vector < hipEvent_t > evs;
+  int big_grid;
+  uint64_t last_big;
   PmCounters last_ctr;          // summed over the chunks of the last run
   PmInsCursor last_cur;
-  float last_ms[6];
+  float last_ms[8];
   std::vector < uint8_t > h_ins;        // host copy of all insertion-log bytes so far
   long summary[13];
 };
@@ -132,6 +144,13 @@ extern "C" int pemap_dev_create (pemap_dev ** out, int device_id)
   d->ins_cap = 0;
   d->run_first = d->run_n = 0;
   d->run_pending = false;
+  d->run_split = false;
+  d->run_chunks = 0;
+  d->stream2 = nullptr;
+  memset (d->lists, 0, sizeof (d->lists));
+  d->lists_cap = 0;
+  d->d_chunk_ctr = nullptr;
+  d->last_big = 0;
   memset (&d->last_ctr, 0, sizeof (d->last_ctr));
   memset (d->last_ms, 0, sizeof (d->last_ms));
   memset (d->summary, 0, sizeof (d->summary));
@@ -155,6 +174,7 @@ extern "C" int pemap_dev_create (pemap_dev ** out, int device_id)
   int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   { const char *sg = getenv ("PEMAP_SEED_BLOCKS_PER_CU"); d->seed_grid = cus * (sg ? atoi (sg) : 8); }
   { const char *sg = getenv ("PEMAP_SW_WAVES_PER_CU"); d->sw_grid = cus * (sg ? atoi (sg) : 16); }
+  d->big_grid = cus * 2;
   if (hipStreamCreateWithFlags (&d->stream, hipStreamNonBlocking) != hipSuccess)
     {
       delete d;
@@ -229,6 +249,23 @@ extern "C" void pemap_dev_destroy (pemap_dev * d)
   hipFree (d->d_ins_log);
   for (int i = 0; i < 7; i++)
     hipEventDestroy (d->ev[i]);
+  if (d->stream2)
+    {
+      hipStreamSynchronize (d->stream2);
+      for (int i = 0; i < 2; i++)
+        {
+          hipEventDestroy (d->ev_lists_ready[i]);
+          hipEventDestroy (d->ev_lists_free[i]);
+          hipFree (d->lists[i].hdr);
+          hipFree (d->lists[i].key);
+          hipFree (d->lists[i].seg);
+          hipFree (d->lists[i].big_list);
+        }
+      for (size_t i = 0; i < d->evs.size (); i++)
+        hipEventDestroy (d->evs[i]);
+      hipFree (d->d_chunk_ctr);
+      hipStreamDestroy (d->stream2);
+    }
   hipStreamDestroy (d->stream);
   delete d;
 }
@@ -587,72 +624,189 @@ struct RunCtx
   uint32_t *dump_slab;
 };
 
-template < int W > static void launch_chunk (pemap_dev * d, const RunCtx & c, uint32_t * m1, uint32_t * m2, int *mt)
+// per-chunk device counters: the kernels' PmCounters plus what the look-up kernel counts
+struct PmChunkCtr
+{
+  PmCounters c;
+  unsigned long long positions;
+  unsigned n_big;
+  unsigned pad;
+};
+
+#define PM_MAX_CHUNKS 256
+#define PM_NEV 10               // events per chunk: lookup start/end, then the ALU stream's kernel boundaries
+
+static int seg_template (int L)
+{
+  const int segs = L / 16 + ((L % 16) ? 1 : 0);      // len/16 (+1 unless divisible), pemapper.c:1573-1587
+  return segs <= 7 ? 7 : segs <= 10 ? 10 : segs <= 13 ? 13 : segs <= 16 ? 16 : 19;
+}
+
+// ---- the memory stream's work for one chunk: look-ups + slice gather into the slot's lists
+static void launch_lookup (pemap_dev * d, const RunCtx & c, int slot, PmChunkCtr * cc, hipEvent_t * ev)
+{
+  PmLists L = d->lists[slot];
+  L.n_big = &cc->n_big;
+  L.positions = &cc->positions;
+  hipStream_t st = d->serial_split ? d->stream : d->stream2;
+  hipEventRecord (ev[0], st);
+#define PM_LK(SM) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_lookup_kernel < SM >), dim3 (c.b.n_ends), dim3 (PM_SEED_THREADS), 0, st, c.ix, c.b, c.prm, L)
+  switch (seg_template (c.L))
+    {
+    case 7: PM_LK (7); break;
+    case 10: PM_LK (10); break;
+    case 13: PM_LK (13); break;
+    case 16: PM_LK (16); break;
+    default: PM_LK (19); break;
+    }
+#undef PM_LK
+  hipEventRecord (ev[1], st);
+}
+
+// ---- the ALU stream's work for one chunk.  split: the seed stage is vote + list-mode remainder on lists made by
+//      launch_lookup; otherwise the monolithic seed kernel does everything.
+template < int W > static void launch_chunk (pemap_dev * d, const RunCtx & c, uint32_t * m1, uint32_t * m2, int *mt, bool split, int slot,
+                                             PmChunkCtr * cc, hipEvent_t * ev)
 {
   const int n_ends = c.b.n_ends;
-  hipEventRecord (d->ev[0], d->stream);
-  int sgrid = d->seed_grid < n_ends ? d->seed_grid : n_ends;
-  // segments of the longest read: len/16 (+1 unless divisible), pemapper.c:1573-1587
-  const int segs = c.L / 16 + ((c.L % 16) ? 1 : 0);
+  PmCounters *ctr = &cc->c;
   const char *pl = getenv ("PEMAP_SEED_PHASE");      // timing probe only: results are meaningless when set
   const int phase_limit = pl ? atoi (pl) : 0;
+  hipEventRecord (ev[2], d->stream);
+  if (split)
+    {
+      PmLists L = d->lists[slot];
+      L.n_big = &cc->n_big;
+      L.positions = &cc->positions;
+#define PM_VT(SM) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_vote_kernel < SM >), dim3 (n_ends), dim3 (PM_SEED_THREADS), 0, d->stream, c.ix, c.b, c.prm, \
+                                      d->hits, d->d_tasks_s, d->d_tasks_m, ctr, L)
+#define PM_SEEDL(SM) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_seed_kernel < SM >), dim3 (d->big_grid), dim3 (PM_SEED_THREADS), 0, d->stream, c.ix, c.b, \
+                                         c.prm, d->hits, d->d_tasks_s, d->d_tasks_m, ctr, d->d_seed_scratch, 0, L.big_list, L.n_big)
+      switch (seg_template (c.L))
+        {
+        case 7: PM_VT (7); PM_SEEDL (7); break;
+        case 10: PM_VT (10); PM_SEEDL (10); break;
+        case 13: PM_VT (13); PM_SEEDL (13); break;
+        case 16: PM_VT (16); PM_SEEDL (16); break;
+        default: PM_VT (19); PM_SEEDL (19); break;
+        }
+#undef PM_VT
+#undef PM_SEEDL
+    }
+  else
+    {
+      int sgrid = d->seed_grid < n_ends ? d->seed_grid : n_ends;
 #define PM_SEED(SM) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_seed_kernel < SM >), dim3 (sgrid), dim3 (PM_SEED_THREADS), 0, d->stream, c.ix, c.b, c.prm, \
-                                        d->hits, d->d_tasks_s, d->d_tasks_m, d->d_ctr, d->d_seed_scratch, phase_limit)
-  if (segs <= 7) PM_SEED (7);
-  else if (segs <= 10) PM_SEED (10);
-  else if (segs <= 13) PM_SEED (13);
-  else if (segs <= 16) PM_SEED (16);
-  else PM_SEED (19);
+                                        d->hits, d->d_tasks_s, d->d_tasks_m, ctr, d->d_seed_scratch, phase_limit, (const uint32_t *) nullptr, \
+                                        (const unsigned *) nullptr)
+      switch (seg_template (c.L))
+        {
+        case 7: PM_SEED (7); break;
+        case 10: PM_SEED (10); break;
+        case 13: PM_SEED (13); break;
+        case 16: PM_SEED (16); break;
+        default: PM_SEED (19); break;
+        }
 #undef PM_SEED
-  hipEventRecord (d->ev[1], d->stream);
+    }
+  hipEventRecord (ev[3], d->stream);
   hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, true >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, d->hits,
-                      d->d_tasks_s, &d->d_ctr->n_tasks_s, d->d_ctr, d->d_dirbuf, c.dump_slab, c.tstride, c.L);
-  hipEventRecord (d->ev[2], d->stream);
+                      d->d_tasks_s, &ctr->n_tasks_s, ctr, d->d_dirbuf, c.dump_slab, c.tstride, c.L);
+  hipEventRecord (ev[4], d->stream);
   hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, false >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, d->hits,
-                      d->d_tasks_m, &d->d_ctr->n_tasks_m, d->d_ctr, d->d_dirbuf, c.dump_slab, c.tstride, c.L);
-  hipEventRecord (d->ev[3], d->stream);
-  hipLaunchKernelGGL (pm_select_kernel, dim3 ((c.b.n + 255) / 256), dim3 (256), 0, d->stream, c.b, c.prm, d->hits, d->d_redo, d->d_wins, d->d_ctr,
+                      d->d_tasks_m, &ctr->n_tasks_m, ctr, d->d_dirbuf, c.dump_slab, c.tstride, c.L);
+  hipEventRecord (ev[5], d->stream);
+  hipLaunchKernelGGL (pm_select_kernel, dim3 ((c.b.n + 255) / 256), dim3 (256), 0, d->stream, c.b, c.prm, d->hits, d->d_redo, d->d_wins, ctr,
                       m1, m2, mt);
-  hipEventRecord (d->ev[4], d->stream);
+  hipEventRecord (ev[6], d->stream);
   hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, true >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, d->hits,
-                      d->d_redo, &d->d_ctr->n_redo, d->d_ctr, d->d_dirbuf, c.dump_slab, c.tstride, c.L);
-  hipEventRecord (d->ev[5], d->stream);
+                      d->d_redo, &ctr->n_redo, ctr, d->d_dirbuf, c.dump_slab, c.tstride, c.L);
+  hipEventRecord (ev[7], d->stream);
   int wgrid = (n_ends + 255) / 256;
   if (wgrid > d->sw_grid)
     wgrid = d->sw_grid;
-  hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_walk_kernel < W >), dim3 (wgrid), dim3 (256), 0, d->stream, c.b, d->hits, d->d_wins, d->d_ctr, d->d_cur,
+  hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_walk_kernel < W >), dim3 (wgrid), dim3 (256), 0, d->stream, c.b, d->hits, d->d_wins, ctr, d->d_cur,
                       d->d_dirbuf, c.tstride, d->d_counts, d->d_ins_log, d->ins_cap);
-  hipEventRecord (d->ev[6], d->stream);
+  hipEventRecord (ev[8], d->stream);
 }
 
-// fold the counters and kernel times of the chunk that just finished into the run's totals
-static int absorb_chunk (pemap_dev * d)
+// wait for the run in flight and fold its chunks' counters and kernel times into the run's totals
+static int absorb_run (pemap_dev * d)
 {
+  HIPCHK (d, hipStreamSynchronize (d->stream2));
   HIPCHK (d, hipStreamSynchronize (d->stream));
-  PmCounters c;
-  HIPCHK (d, hipMemcpy (&c, d->d_ctr, sizeof (PmCounters), hipMemcpyDeviceToHost));
+  const int nch = d->run_chunks;
+  std::vector < PmChunkCtr > hc (nch);
+  HIPCHK (d, hipMemcpy (hc.data (), d->d_chunk_ctr, sizeof (PmChunkCtr) * nch, hipMemcpyDeviceToHost));
   HIPCHK (d, hipMemcpy (&d->last_cur, d->d_cur, sizeof (PmInsCursor), hipMemcpyDeviceToHost));
   PmCounters & t = d->last_ctr;
-  t.n_tasks_s += c.n_tasks_s;
-  t.n_tasks_m += c.n_tasks_m;
-  t.n_slots += c.n_slots;
-  t.n_redo += c.n_redo;
-  t.n_wins += c.n_wins;
-  t.positions += c.positions;
-  t.cells_score += c.cells_score;
-  t.cells_dirs += c.cells_dirs;
-  t.pile_incs += c.pile_incs;
-  t.n_ins += c.n_ins;
-  for (int i = 0; i < 6; i++)
+  for (int k = 0; k < nch; k++)
     {
+      const PmCounters & c = hc[k].c;
+      t.n_tasks_s += c.n_tasks_s;
+      t.n_tasks_m += c.n_tasks_m;
+      t.n_slots += c.n_slots;
+      t.n_redo += c.n_redo;
+      t.n_wins += c.n_wins;
+      t.positions += c.positions + hc[k].positions;
+      t.cells_score += c.cells_score;
+      t.cells_dirs += c.cells_dirs;
+      t.pile_incs += c.pile_incs;
+      t.n_ins += c.n_ins;
+      d->last_big += hc[k].n_big;
+      hipEvent_t *ev = &d->evs[(size_t) k * PM_NEV];
       float ms = 0.f;
-      if (hipEventElapsedTime (&ms, d->ev[i], d->ev[i + 1]) == hipSuccess)
-        d->last_ms[i] += ms;
+      if (d->run_split && hipEventElapsedTime (&ms, ev[0], ev[1]) == hipSuccess)
+        {
+          d->last_ms[0] += ms;
+          d->last_ms[6] += ms;
+        }
+      if (hipEventElapsedTime (&ms, ev[2], ev[3]) == hipSuccess)
+        {
+          d->last_ms[0] += ms;
+          d->last_ms[7] += ms;
+        }
+      for (int i = 1; i < 6; i++)
+        if (hipEventElapsedTime (&ms, ev[2 + i], ev[3 + i]) == hipSuccess)
+          d->last_ms[i] += ms;
     }
   if (d->last_cur.ins_overflow)
-    return fail (d, "insertion log overflow (%u bytes per chunk): lower PEMAP_DIR_BUDGET_GB or map smaller slices", d->ins_cap);
+    return fail (d, "insertion log overflow (%u bytes): lower PEMAP_CHUNK_PAIRS or map smaller slices", d->ins_cap);
   if (d->last_cur.ins_bytes > d->ins_cap / 2)
     return drain_ins (d);
+  return 0;
+}
+
+static int ensure_pipeline (pemap_dev * d, int chunk_ends)
+{
+  if (!d->stream2)
+    {
+      HIPCHK (d, hipStreamCreateWithFlags (&d->stream2, hipStreamNonBlocking));
+      for (int i = 0; i < 2; i++)
+        {
+          HIPCHK (d, hipEventCreateWithFlags (&d->ev_lists_ready[i], hipEventDisableTiming));
+          HIPCHK (d, hipEventCreateWithFlags (&d->ev_lists_free[i], hipEventDisableTiming));
+        }
+      TRY (dev_alloc (d, &d->d_chunk_ctr, (size_t) PM_MAX_CHUNKS));
+      d->evs.resize ((size_t) PM_MAX_CHUNKS * PM_NEV);
+      for (size_t i = 0; i < d->evs.size (); i++)
+        HIPCHK (d, hipEventCreate (&d->evs[i]));
+    }
+  if (chunk_ends > d->lists_cap)
+    {
+      for (int i = 0; i < 2; i++)
+        {
+          hipFree (d->lists[i].hdr);
+          hipFree (d->lists[i].key);
+          hipFree (d->lists[i].seg);
+          hipFree (d->lists[i].big_list);
+          TRY (dev_alloc (d, &d->lists[i].hdr, (size_t) chunk_ends));
+          TRY (dev_alloc (d, &d->lists[i].key, (size_t) chunk_ends * 2 * PM_SEED_CAP));
+          TRY (dev_alloc (d, &d->lists[i].seg, (size_t) chunk_ends * 2 * PM_SEED_CAP));
+          TRY (dev_alloc (d, &d->lists[i].big_list, (size_t) chunk_ends));
+        }
+      d->lists_cap = chunk_ends;
+    }
   return 0;
 }
 
@@ -670,22 +824,36 @@ static int run_slice (pemap_dev * d, int first, int n, int sync)
   // finish (and account for) an asynchronous previous run before its work arrays are reused
   if (d->run_pending)
     {
-      TRY (absorb_chunk (d));
+      TRY (absorb_run (d));
       d->run_pending = false;
     }
   const int L = d->max_len_staged;
   const int per = d->paired ? 2 : 1;
-  // chunk so that one direction slab per read-end fits the budget
+  const char *pe = getenv ("PEMAP_PIPELINE");
+  // PEMAP_PIPELINE: 0 (default) monolithic seed kernel, one stream; 1 look-up kernel on a second stream beside vote/SW/walk
+  // of the previous chunk; 2 split kernels on one stream (diagnostic).  The split path is measured slower on MI355X so
+  // far (the vote kernel is latency-bound and loses the wave slots the look-up kernel occupies), see DESIGN.md.
+  const bool split = pe && atoi (pe) != 0 && !getenv ("PEMAP_SEED_PHASE");
+  d->serial_split = pe && atoi (pe) == 2;
+  // chunk: one direction slab per read-end must fit the budget; the two-stream pipeline wants several chunks per run
   size_t slab_bytes = slab_dwords_for (L) * 4;
   long max_ends = (long) (dir_budget_bytes () / slab_bytes);
   if (max_ends > 20000000)
     max_ends = 20000000;        // task ids are end * 200 + hit in 32 bits
   int chunk = (int) (max_ends / per);
+  const char *ce = getenv ("PEMAP_CHUNK_PAIRS");
+  const int want = ce ? atoi (ce) : 131072;
+  if (split && want > 0 && chunk > want)
+    chunk = want;
   if (chunk < 1)
     chunk = 1;
   if (chunk > n)
     chunk = n;
+  if ((n + chunk - 1) / chunk > PM_MAX_CHUNKS)
+    chunk = (n + PM_MAX_CHUNKS - 1) / PM_MAX_CHUNKS;
+  const int nch = (n + chunk - 1) / chunk;
   TRY (ensure_work (d, chunk * per));
+  TRY (ensure_pipeline (d, chunk * per));
   RunCtx c;
   c.ix.pos_index = d->d_pos_index;
   c.ix.mers = d->d_mers;
@@ -704,38 +872,65 @@ static int run_slice (pemap_dev * d, int first, int n, int sync)
   c.dump_slab = d->d_dirbuf + (size_t) (chunk * per) * slab_dwords_for (L);
   memset (&d->last_ctr, 0, sizeof (d->last_ctr));
   memset (d->last_ms, 0, sizeof (d->last_ms));
+  d->last_big = 0;
   d->run_first = first;
   d->run_n = n;
-  for (int off = 0; off < n; off += chunk)
+  d->run_chunks = nch;
+  d->run_split = split;
+  HIPCHK (d, hipMemsetAsync (d->d_chunk_ctr, 0, sizeof (PmChunkCtr) * nch, d->stream));
+  hipEvent_t ev_zero = d->ev[0];
+  HIPCHK (d, hipEventRecord (ev_zero, d->stream));
+  if (split)
+    HIPCHK (d, hipStreamWaitEvent (d->stream2, ev_zero, 0));
+  auto batch_of = [&] (int k, PmBatch & bb, int &f, int &m)
+  {
+    const int off = k * chunk;
+    m = (n - off < chunk) ? n - off : chunk;
+    f = first + off;
+    bb.reads1 = d->d_reads1 + (size_t) f * d->stride;
+    bb.reads2 = d->paired ? d->d_reads2 + (size_t) f * d->stride : nullptr;
+    bb.len1 = d->d_len1 + f;
+    bb.len2 = d->paired ? d->d_len2 + f : nullptr;
+    bb.n = m;
+    bb.stride = d->stride;
+    bb.paired = d->paired;
+    bb.n_ends = m * per;
+  };
+  for (int k = 0; k < nch; k++)
     {
-      const int m = (n - off < chunk) ? n - off : chunk;
-      const int f = first + off;
-      c.b.reads1 = d->d_reads1 + (size_t) f * d->stride;
-      c.b.reads2 = d->paired ? d->d_reads2 + (size_t) f * d->stride : nullptr;
-      c.b.len1 = d->d_len1 + f;
-      c.b.len2 = d->paired ? d->d_len2 + f : nullptr;
-      c.b.n = m;
-      c.b.stride = d->stride;
-      c.b.paired = d->paired;
-      c.b.n_ends = m * per;
-      HIPCHK (d, hipMemsetAsync (d->d_ctr, 0, sizeof (PmCounters), d->stream));
+      int f, m;
+      batch_of (k, c.b, f, m);
+      const int slot = k & 1;
+      PmChunkCtr *cc = d->d_chunk_ctr + k;
+      hipEvent_t *ev = &d->evs[(size_t) k * PM_NEV];
+      if (split)
+        {
+          // memory stream: the slot's lists must have been consumed by the vote of chunk k-2
+          if (k >= 2)
+            HIPCHK (d, hipStreamWaitEvent (d->stream2, d->ev_lists_free[slot], 0));
+          launch_lookup (d, c, slot, cc, ev);
+          HIPCHK (d, hipEventRecord (d->ev_lists_ready[slot], d->stream2));
+          HIPCHK (d, hipStreamWaitEvent (d->stream, d->ev_lists_ready[slot], 0));
+        }
       uint32_t *m1 = d->d_m1 + f, *m2 = d->paired ? d->d_m2 + f : nullptr;
       int *mt = d->d_mtype + f;
       switch (pick_w (L))
         {
-        case 13: launch_chunk < 13 > (d, c, m1, m2, mt); break;
-        case 19: launch_chunk < 19 > (d, c, m1, m2, mt); break;
-        case 26: launch_chunk < 26 > (d, c, m1, m2, mt); break;
-        case 32: launch_chunk < 32 > (d, c, m1, m2, mt); break;
-        default: launch_chunk < 38 > (d, c, m1, m2, mt); break;
+        case 13: launch_chunk < 13 > (d, c, m1, m2, mt, split, slot, cc, ev); break;
+        case 19: launch_chunk < 19 > (d, c, m1, m2, mt, split, slot, cc, ev); break;
+        case 26: launch_chunk < 26 > (d, c, m1, m2, mt, split, slot, cc, ev); break;
+        case 32: launch_chunk < 32 > (d, c, m1, m2, mt, split, slot, cc, ev); break;
+        default: launch_chunk < 38 > (d, c, m1, m2, mt, split, slot, cc, ev); break;
         }
+      if (split)
+        HIPCHK (d, hipEventRecord (d->ev_lists_free[slot], d->stream));    // (recorded after the whole chunk: simple and sufficient)
       HIPCHK (d, hipGetLastError ());
-      d->run_pending = true;
-      if (off + m < n || sync)
-        {
-          TRY (absorb_chunk (d));
-          d->run_pending = false;
-        }
+    }
+  d->run_pending = true;
+  if (sync)
+    {
+      TRY (absorb_run (d));
+      d->run_pending = false;
     }
   return 0;
 }
@@ -755,7 +950,7 @@ extern "C" int pemap_dev_sync (pemap_dev * d)
   HIPCHK (d, hipSetDevice (d->device));
   if (d->run_pending)
     {
-      TRY (absorb_chunk (d));
+      TRY (absorb_run (d));
       d->run_pending = false;
     }
   HIPCHK (d, hipStreamSynchronize (d->stream));
@@ -854,6 +1049,7 @@ extern "C" int pemap_dev_run_stats (pemap_dev * d, uint64_t * s, float *t)
       s[7] = c.n_ins;
       s[8] = c.n_wins;
       s[9] = c.n_redo;
+      s[10] = d->last_big;
     }
   if (t)
     memcpy (t, d->last_ms, sizeof (d->last_ms));

@@ -174,4 +174,5 @@ __device__ __forceinline__ uint32_t pm_neighbour (uint32_t k, int j)
 }
 
 #include "pemap_seed.hip.h"
+#include "pemap_seed2.hip.h"
 #include "pemap_sw.hip.h"

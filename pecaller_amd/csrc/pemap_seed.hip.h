@@ -233,6 +233,51 @@ __device__ void pm_vote_strand (SH & sh, const uint32_t * ekey, const uint8_t * 
   go_on = sh.state[2] != 0;
 }
 
+// hits -> spots and SW windows (pemapper.c:1664-1669, 1047-1081), task lists.
+// An end with one hit is scored once, with direction nibbles, into its own slab; ends with several hits are scored
+// without, and only the winner is scored again (pm_select_kernel).
+template < class SH > __device__ __forceinline__ void pm_seed_emit (SH & sh, const PmIndex & ix, const PmHits & h, uint32_t * tasks_s,
+                                                                    uint32_t * tasks_m, PmCounters * ctr, int e, int len, int tot)
+{
+  const int tid = threadIdx.x;
+  if (tid == 0)
+    {
+      unsigned tb = 0;
+      h.n_hits[e] = tot;
+      h.slot[e] = (tot == 1) ? (int) atomicAdd (&ctr->n_slots, 1u) : -1;
+      if (tot == 1)
+        tb = atomicAdd (&ctr->n_tasks_s, 1u);
+      else if (tot > 1)
+        tb = atomicAdd (&ctr->n_tasks_m, (unsigned) tot);
+      sh.state[3] = (int) tb;
+    }
+  pm_lds_barrier ();
+  const unsigned tbase = (unsigned) sh.state[3];
+  uint32_t *tasks = (tot == 1) ? tasks_s : tasks_m;
+  for (int t = tid; t < tot; t += PM_SEED_THREADS)
+    {
+      long temp = (long) sh.hits[t] - (long) sh.hits_off[t];
+      uint32_t spot = (uint32_t) (temp > 0 ? temp : 0);
+      int chrom = pm_find_chrom (ix.contig_starts, ix.n_contigs, spot);
+      unsigned extra = 15u * (unsigned) chrom;
+      long tt = (long) extra + (long) spot - (long) PM_SLOP;
+      if (tt < 0)
+        tt = 0;
+      unsigned cs0 = ix.contig_starts[chrom] + extra;
+      unsigned start_match = ((long) cs0 > tt) ? cs0 : (unsigned) tt;
+      unsigned e1 = ix.contig_starts[chrom + 1] + extra;
+      unsigned e2w = extra + spot + (unsigned) len + PM_SLOP;
+      unsigned end_match = e1 < e2w ? e1 : e2w;
+      int blen = (int) (1u + end_match - start_match);
+      size_t o = (size_t) e * PM_MAX_HITS + t;
+      h.spot[o] = spot;
+      h.orient[o] = sh.hits_or[t];
+      h.gpos[o] = start_match;
+      h.nn[o] = (int16_t) blen;
+      tasks[tbase + t] = (uint32_t) o;
+    }
+}
+
 // Stage A of a read-end (software-pipelined one end ahead of the vote): the read and its reverse complement into LDS
 // buffer `buf`, the N filter, the segment offsets and 16-mers, and the 2 x S x 49 look-ups ISSUED into registers.
 // They complete while the workgroup votes on the previous end.
@@ -300,8 +345,10 @@ __device__ __forceinline__ void pm_seed_stage_a (SH & sh, const PmIndex & ix, co
 
 template < int SMAX > __global__ __launch_bounds__ (PM_SEED_THREADS) void pm_seed_kernel (PmIndex ix, PmBatch b, PmParams prm, PmHits h,
                                                                                           uint32_t * tasks_s, uint32_t * tasks_m,
-                                                                                          PmCounters * ctr, uint32_t * gscratch, int phase_limit)
+                                                                                          PmCounters * ctr, uint32_t * gscratch, int phase_limit,
+                                                                                          const uint32_t * end_list, const unsigned *n_list)
 {
+  // end_list != NULL: only the listed read-ends are processed (the ends the split look-up / vote kernels passed over)
   typedef PmSeedShared < SMAX > SH;
   __shared__ SH sh;
   constexpr int NI = (SH::NITEMS + PM_SEED_THREADS - 1) / PM_SEED_THREADS;   // look-ups per thread
@@ -319,15 +366,17 @@ template < int SMAX > __global__ __launch_bounds__ (PM_SEED_THREADS) void pm_see
 
   uint32_t v0[NI], v1[NI];
   const uint32_t pos_index_0 = ix.pos_index[0];
-  int e = blockIdx.x;
+  const int n_iter = end_list ? (int) *n_list : b.n_ends;
+  int it = blockIdx.x;
   int buf = 0;
   if (tid < 2)
     sh.ncount[tid] = 0;
   __syncthreads ();
-  if (e < b.n_ends)
-    pm_seed_stage_a < SMAX, NI > (sh, ix, b, prm.bisulfite, e, 0, v0, v1);
-  for (; e < b.n_ends; e += gridDim.x, buf ^= 1)
+  if (it < n_iter)
+    pm_seed_stage_a < SMAX, NI > (sh, ix, b, prm.bisulfite, end_list ? (int) end_list[it] : it, 0, v0, v1);
+  for (; it < n_iter; it += gridDim.x, buf ^= 1)
     {
+      const int e = end_list ? (int) end_list[it] : it;
       int len;
       (void) pm_read_ptr (b, e, &len);
       int total_cuts = len / idepth;
@@ -419,9 +468,9 @@ template < int SMAX > __global__ __launch_bounds__ (PM_SEED_THREADS) void pm_see
           sh.eseg[strand][p] = (uint8_t) seg;
         }
       // ---- stage A of the workgroup's NEXT end: its look-ups fly while this end is voted on
-      const int e2 = e + gridDim.x;
-      if (e2 < b.n_ends)
-        pm_seed_stage_a < SMAX, NI > (sh, ix, b, prm.bisulfite, e2, buf ^ 1, v0, v1);
+      const int it2 = it + gridDim.x;
+      if (it2 < n_iter)
+        pm_seed_stage_a < SMAX, NI > (sh, ix, b, prm.bisulfite, end_list ? (int) end_list[it2] : it2, buf ^ 1, v0, v1);
       if (!skip && phase_limit != 1 && phase_limit != 2)
         {
           int min_match = max (1, total_cuts);       // pemapper.c:1642-1645
@@ -494,44 +543,6 @@ template < int SMAX > __global__ __launch_bounds__ (PM_SEED_THREADS) void pm_see
                 go_on = false;
             }
         }
-      // ---- hits -> spots and SW windows (pemapper.c:1664-1669, 1047-1081)
-      // an end with one hit is scored once, with direction nibbles, into its own slab; ends with several hits are
-      // scored without, and only the winner is scored again (pm_select_kernel)
-      if (tid == 0)
-        {
-          unsigned tb = 0;
-          h.n_hits[e] = tot;
-          h.slot[e] = (tot == 1) ? (int) atomicAdd (&ctr->n_slots, 1u) : -1;
-          if (tot == 1)
-            tb = atomicAdd (&ctr->n_tasks_s, 1u);
-          else if (tot > 1)
-            tb = atomicAdd (&ctr->n_tasks_m, (unsigned) tot);
-          sh.state[3] = (int) tb;
-        }
-      pm_lds_barrier ();
-      const unsigned tbase = (unsigned) sh.state[3];
-      uint32_t *tasks = (tot == 1) ? tasks_s : tasks_m;
-      for (int t = tid; t < tot; t += PM_SEED_THREADS)
-        {
-          long temp = (long) sh.hits[t] - (long) sh.hits_off[t];
-          uint32_t spot = (uint32_t) (temp > 0 ? temp : 0);
-          int chrom = pm_find_chrom (ix.contig_starts, ix.n_contigs, spot);
-          unsigned extra = 15u * (unsigned) chrom;
-          long tt = (long) extra + (long) spot - (long) PM_SLOP;
-          if (tt < 0)
-            tt = 0;
-          unsigned cs0 = ix.contig_starts[chrom] + extra;
-          unsigned start_match = ((long) cs0 > tt) ? cs0 : (unsigned) tt;
-          unsigned e1 = ix.contig_starts[chrom + 1] + extra;
-          unsigned e2w = extra + spot + (unsigned) len + PM_SLOP;
-          unsigned end_match = e1 < e2w ? e1 : e2w;
-          int blen = (int) (1u + end_match - start_match);
-          size_t o = (size_t) e * PM_MAX_HITS + t;
-          h.spot[o] = spot;
-          h.orient[o] = sh.hits_or[t];
-          h.gpos[o] = start_match;
-          h.nn[o] = (int16_t) blen;
-          tasks[tbase + t] = (uint32_t) o;
-        }
+      pm_seed_emit (sh, ix, h, tasks_s, tasks_m, ctr, e, len, tot);
     }
 }

@@ -1,0 +1,277 @@
+// pemap_seed2.hip.h -- the seed stage split in two kernels so that its HBM-random half and its LDS/VALU half can run
+// concurrently (on two HIP streams) with each other and with the fp64 SW kernel of the previous chunk:
+//
+//   pm_lookup_kernel   one workgroup per read-end: look-ups in pos_index, slice gather from .mdx -> per-end lists of
+//                      (diagonal key, segment) in HBM.  Tiny register/LDS footprint, 32 waves per CU: HBM-random bound.
+//   pm_vote_kernel     one workgroup per read-end: lists -> LDS, find_matches (pm_vote_strand) -> hits, windows, SW tasks.
+//
+// Read-ends whose strand holds more than PM_SEED_CAP positions (repeats) are appended to a list and handled afterwards
+// by the monolithic pm_seed_kernel (list mode), which has the global spill path.
+#pragma once
+
+enum { PM_KIND_NORMAL = 0, PM_KIND_SKIP = 1, PM_KIND_BIG = 2 };
+
+struct PmEndHeader
+{
+  uint16_t T[2];                       // positions per strand
+  uint16_t seg_base[2][PM_MAX_SEG + 1];
+  uint8_t kind;
+  uint8_t pad[3];
+};
+
+struct PmLists
+{
+  PmEndHeader *hdr;                    // [n_ends]
+  uint32_t *key;                       // [n_ends][2][PM_SEED_CAP]
+  uint8_t *seg;                        // [n_ends][2][PM_SEED_CAP]
+  uint32_t *big_list;                  // ends left to the monolithic kernel
+  unsigned *n_big;
+  unsigned long long *positions;       // P counter
+};
+
+template < int SMAX > struct __align__ (8) PmLookupShared
+{
+  static constexpr int NITEMS = 2 * SMAX * 49;
+  uint32_t it_start[NITEMS];
+  uint16_t it_len[NITEMS];
+  uint16_t it_off[NITEMS];
+  uint32_t kmer[2 * SMAX];
+  int seg_cnt[2 * SMAX];
+  int seg_base[2][SMAX + 1];
+  int offsets[SMAX + 1];
+  int ncount;
+  uint8_t seq[2][320];
+};
+
+template < int SMAX > __global__ __launch_bounds__ (PM_SEED_THREADS, 8) void pm_lookup_kernel (PmIndex ix, PmBatch b, PmParams prm, PmLists out)
+{
+  typedef PmLookupShared < SMAX > SH;
+  __shared__ SH sh;
+  constexpr int NI = (SH::NITEMS + PM_SEED_THREADS - 1) / PM_SEED_THREADS;
+  const int tid = threadIdx.x;
+  const int idepth = ix.idepth;
+  const int e = blockIdx.x;
+  if (e >= b.n_ends)
+    return;
+  int len;
+  const uint8_t *src = pm_read_ptr (b, e, &len);
+  if (tid == 0)
+    sh.ncount = 0;
+  __syncthreads ();
+  // ---- read + reverse complement; N filter (pemapper.c:1552-1559: upper-case 'N' only)
+  int isn = 0;
+  for (int i = tid; i < len; i += PM_SEED_THREADS)
+    {
+      uint8_t c = src[i];
+      sh.seq[0][i] = c;
+      sh.seq[1][len - 1 - i] = pm_rc (c);
+      isn += (c == 'N');
+    }
+  int total_cuts = len / idepth;        // pemapper.c:1573-1587
+  if (len % idepth == 0)
+    total_cuts--;
+  if (total_cuts > SMAX - 1)
+    total_cuts = SMAX - 1;
+  const int S = total_cuts + 1;
+  if (tid <= total_cuts)
+    sh.offsets[tid] = (tid < total_cuts || total_cuts == 0) ? tid * idepth : len - idepth;
+  if (isn)
+    atomicAdd (&sh.ncount, isn);
+  __syncthreads ();
+  PmEndHeader *hd = &out.hdr[e];
+  if (sh.ncount >= 1 + len / 10)
+    {
+      if (tid == 0)
+        hd->kind = PM_KIND_SKIP;
+      return;
+    }
+  if (tid < 2 * S)
+    {
+      const int strand = tid / S, seg = tid - strand * S;
+      const uint8_t *p = &sh.seq[strand][sh.offsets[seg]];
+      uint32_t k = 0;
+      for (int i = 0; i < 16; i++)
+        k = (k << 2) + pm_code (p[i], prm.bisulfite);
+      sh.kmer[tid] = k;
+    }
+  __syncthreads ();
+  // ---- 2 x S x 49 bucket look-ups, 8-byte gathers, all in flight (get_mers, pemapper.c:2158-2165)
+  {
+    uint32_t v0[NI], v1[NI], nbv[NI];
+    const uint32_t pos_index_0 = ix.pos_index[0];
+#pragma unroll
+    for (int r = 0; r < NI; r++)
+      {
+        const int x = tid + r * PM_SEED_THREADS;
+        v0[r] = v1[r] = nbv[r] = 0;
+        if (x < 2 * S * 49)
+          {
+            const int sg = x / 49, j = x - sg * 49;
+            const uint32_t nb = pm_neighbour (sh.kmer[sg], j);
+            const pm_u32x2 pr = *(const pm_u32x2 *) (ix.pos_index + nb);
+            v0[r] = pr.x;
+            v1[r] = pr.y;
+            nbv[r] = nb;
+          }
+      }
+#pragma unroll
+    for (int r = 0; r < NI; r++)
+      {
+        const int x = tid + r * PM_SEED_THREADS;
+        if (x < 2 * S * 49)
+          {
+            // the all-T k-mer's successor is entry 0: `which + 1` is evaluated in 32 bits (pemapper.c:2163)
+            const uint32_t ln = ((nbv[r] == 0xFFFFFFFFu) ? pos_index_0 : v1[r]) - v0[r];
+            sh.it_start[x] = v0[r];
+            sh.it_len[x] = (ln >= PM_TOO_MANY) ? 0xFFFF : (uint16_t) ln;
+          }
+      }
+  }
+  __syncthreads ();
+  // ---- a segment with any bucket >= too_many_spots is emptied (pemapper.c:1602-1606)
+  if (tid < 2 * S)
+    {
+      int sum = 0;
+      bool bad = false;
+      for (int j = 0; j < 49; j++)
+        {
+          const uint16_t ln = sh.it_len[tid * 49 + j];
+          sh.it_off[tid * 49 + j] = (uint16_t) sum;
+          if (ln == 0xFFFF)
+            bad = true;
+          else
+            sum += ln;
+        }
+      sh.seg_cnt[tid] = bad ? 0 : sum;
+    }
+  __syncthreads ();
+  if (tid < 2)
+    {
+      int acc = 0;
+      for (int s = 0; s < S; s++)
+        {
+          sh.seg_base[tid][s] = acc;
+          acc += sh.seg_cnt[tid * S + s];
+        }
+      sh.seg_base[tid][S] = acc;
+    }
+  __syncthreads ();
+  const int T0 = sh.seg_base[0][S], T1 = sh.seg_base[1][S];
+  if (T0 > PM_SEED_CAP || T1 > PM_SEED_CAP)
+    {
+      if (tid == 0)
+        {
+          hd->kind = PM_KIND_BIG;
+          out.big_list[atomicAdd (out.n_big, 1u)] = (uint32_t) e;
+        }
+      return;
+    }
+  if (tid == 0)
+    {
+      hd->kind = PM_KIND_NORMAL;
+      hd->T[0] = (uint16_t) T0;
+      hd->T[1] = (uint16_t) T1;
+      atomicAdd (out.positions, (unsigned long long) (T0 + T1));
+    }
+  if (tid < 2 * (S + 1))
+    {
+      const int st = tid / (S + 1), k = tid - st * (S + 1);
+      hd->seg_base[st][k] = (uint16_t) sh.seg_base[st][k];
+    }
+  // ---- bucket slices -> (diagonal key, segment) lists, one position per thread and round
+  uint32_t *okey = out.key + (size_t) e * 2 * PM_SEED_CAP;
+  uint8_t *oseg = out.seg + (size_t) e * 2 * PM_SEED_CAP;
+  for (int pp = tid; pp < T0 + T1; pp += PM_SEED_THREADS)
+    {
+      const int strand = pp < T0 ? 0 : 1;
+      const int p = strand ? pp - T0 : pp;
+      int seg = 0;
+      while (p >= sh.seg_base[strand][seg + 1])
+        seg++;
+      const int q = p - sh.seg_base[strand][seg];
+      const int x0 = (strand * S + seg) * 49;
+      int lo = 0, hi = 48;      // largest j with it_off[j] <= q: that slice holds position q
+      while (lo < hi)
+        {
+          const int mid = (lo + hi + 1) >> 1;
+          if ((int) sh.it_off[x0 + mid] <= q)
+            lo = mid;
+          else
+            hi = mid - 1;
+        }
+      const uint32_t m = ix.mers[sh.it_start[x0 + lo] + (uint32_t) (q - (int) sh.it_off[x0 + lo])];
+      okey[strand * PM_SEED_CAP + p] = m + (uint32_t) (PM_DIAG_BIAS - sh.offsets[seg]);
+      oseg[strand * PM_SEED_CAP + p] = (uint8_t) seg;
+    }
+}
+
+template < int SMAX > __global__ __launch_bounds__ (PM_SEED_THREADS) void pm_vote_kernel (PmIndex ix, PmBatch b, PmParams prm, PmHits h,
+                                                                                          uint32_t * tasks_s, uint32_t * tasks_m,
+                                                                                          PmCounters * ctr, PmLists in)
+{
+  typedef PmSeedShared < SMAX > SH;
+  __shared__ SH sh;
+  const int tid = threadIdx.x;
+  const int idepth = ix.idepth;
+  const int max_off = max (2, idepth - 4);
+  const int e = blockIdx.x;
+  if (e >= b.n_ends)
+    return;
+  const PmEndHeader *hd = &in.hdr[e];
+  const int kind = hd->kind;
+  if (kind == PM_KIND_BIG)
+    return;                     // left to pm_seed_kernel in list mode
+  int len;
+  (void) pm_read_ptr (b, e, &len);
+  int total_cuts = len / idepth;
+  if (len % idepth == 0)
+    total_cuts--;
+  if (total_cuts > SMAX - 1)
+    total_cuts = SMAX - 1;
+  const int S = total_cuts + 1;
+  int tot = 0;
+  if (kind == PM_KIND_NORMAL)
+    {
+      const int T0 = hd->T[0], T1 = hd->T[1];
+      if (tid <= total_cuts)
+        sh.offsets[0][tid] = (tid < total_cuts || total_cuts == 0) ? tid * idepth : len - idepth;
+      if (tid < 2 * (S + 1))
+        {
+          const int st = tid / (S + 1), k = tid - st * (S + 1);
+          sh.seg_base[st][k] = hd->seg_base[st][k];
+        }
+      const uint32_t *ikey = in.key + (size_t) e * 2 * PM_SEED_CAP;
+      const uint8_t *iseg = in.seg + (size_t) e * 2 * PM_SEED_CAP;
+      for (int p = tid; p < T0; p += PM_SEED_THREADS)
+        {
+          sh.ekey[0][p] = ikey[p];
+          sh.eseg[0][p] = iseg[p];
+        }
+      for (int p = tid; p < T1; p += PM_SEED_THREADS)
+        {
+          sh.ekey[1][p] = ikey[PM_SEED_CAP + p];
+          sh.eseg[1][p] = iseg[PM_SEED_CAP + p];
+        }
+      __syncthreads ();
+      if (tid < 2 * S)
+        {
+          const int st = tid / S, k = tid - st * S;
+          sh.seg_cnt[tid] = sh.seg_base[st][k + 1] - sh.seg_base[st][k];
+        }
+      __syncthreads ();
+      int min_match = max (1, total_cuts);   // pemapper.c:1642-1645
+      if (total_cuts > 4)
+        min_match = (4 * total_cuts) / 5;
+      min_match = min (min_match, 4);
+      bool go_on = true;
+      for (int strand = 0; strand < 2 && go_on; strand++)
+        {
+          pm_vote_strand < SH, uint16_t > (sh, sh.ekey[strand], sh.eseg[strand], sh.surv, sh.order, sh.tfs, strand ? T1 : T0,
+                                           &sh.seg_cnt[strand * S], sh.offsets[0], total_cuts, max_off, min_match, tot, go_on, (uint8_t) strand);
+          if (tot >= PM_MAX_HITS)
+            go_on = false;
+          pm_lds_barrier ();
+        }
+    }
+  pm_seed_emit (sh, ix, h, tasks_s, tasks_m, ctr, e, len, tot);
+}
