@@ -174,7 +174,7 @@ extern "C" int pemap_dev_create (pemap_dev ** out, int device_id)
   int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   { const char *sg = getenv ("PEMAP_SEED_BLOCKS_PER_CU"); d->seed_grid = cus * (sg ? atoi (sg) : 8); }
   { const char *sg = getenv ("PEMAP_SW_WAVES_PER_CU"); d->sw_grid = cus * (sg ? atoi (sg) : 16); }
-  d->big_grid = cus * 2;
+  d->big_grid = cus * 4;
   if (hipStreamCreateWithFlags (&d->stream, hipStreamNonBlocking) != hipSuccess)
     {
       delete d;
@@ -542,7 +542,7 @@ static int ensure_work (pemap_dev * d, int n_ends)
       d->cap_ends = n_ends;
     }
   if (!d->d_seed_scratch)
-    TRY (dev_alloc (d, &d->d_seed_scratch, (size_t) d->seed_grid * 4 * PM_MAX_SEG * PM_SEG_LIST_MAX));
+    TRY (dev_alloc (d, &d->d_seed_scratch, (size_t) d->seed_grid * 6 * PM_MAX_SEG * PM_SEG_LIST_MAX));
   size_t need = ((size_t) n_ends + 1) * slab_dwords_for (d->max_len_staged);       // + 1: dump slab for task-less lane groups
   if (need > d->dirbuf_dwords)
     {
@@ -650,7 +650,11 @@ static void launch_lookup (pemap_dev * d, const RunCtx & c, int slot, PmChunkCtr
   L.positions = &cc->positions;
   hipStream_t st = d->serial_split ? d->stream : d->stream2;
   hipEventRecord (ev[0], st);
-#define PM_LK(SM) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_lookup_kernel < SM >), dim3 (c.b.n_ends), dim3 (PM_SEED_THREADS), 0, st, c.ix, c.b, c.prm, L)
+  // occupancy knob of the look-up kernel (diagnostic): dynamic LDS padding in KB limits its workgroups per CU, so that
+  // the latency-bound vote kernel running beside it keeps its wave slots
+  const char *padenv = getenv ("PEMAP_LOOKUP_LDS_PAD_KB");
+  const unsigned pad = (padenv ? (unsigned) atoi (padenv) : 30u) * 1024u;    // 4 look-up workgroups per CU
+#define PM_LK(SM) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_lookup_kernel < SM >), dim3 (c.b.n_ends), dim3 (PM_SEED_THREADS), pad, st, c.ix, c.b, c.prm, L)
   switch (seg_template (c.L))
     {
     case 7: PM_LK (7); break;
@@ -830,10 +834,9 @@ static int run_slice (pemap_dev * d, int first, int n, int sync)
   const int L = d->max_len_staged;
   const int per = d->paired ? 2 : 1;
   const char *pe = getenv ("PEMAP_PIPELINE");
-  // PEMAP_PIPELINE: 0 (default) monolithic seed kernel, one stream; 1 look-up kernel on a second stream beside vote/SW/walk
-  // of the previous chunk; 2 split kernels on one stream (diagnostic).  The split path is measured slower on MI355X so
-  // far (the vote kernel is latency-bound and loses the wave slots the look-up kernel occupies), see DESIGN.md.
-  const bool split = pe && atoi (pe) != 0 && !getenv ("PEMAP_SEED_PHASE");
+  // PEMAP_PIPELINE: 1 (default) look-up kernel on a second stream beside vote/SW/walk of the previous chunk;
+  // 0 monolithic seed kernel, one stream; 2 split kernels on one stream (diagnostic).
+  const bool split = !(pe && atoi (pe) == 0) && !getenv ("PEMAP_SEED_PHASE");
   d->serial_split = pe && atoi (pe) == 2;
   // chunk: one direction slab per read-end must fit the budget; the two-stream pipeline wants several chunks per run
   size_t slab_bytes = slab_dwords_for (L) * 4;

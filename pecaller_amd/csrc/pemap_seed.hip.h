@@ -12,10 +12,10 @@
 //      DIAGONAL key  m + 300 - offset(segment)  (read start implied by that seed) together with its segment number;
 //   4. per strand, find_matches (pemapper.c:2189-2289) WITHOUT sorting the lists: the reference counts, per anchor, the
 //      later segments that hold a position within max_off of the anchor's diagonal (tot_found) and only acts on anchors
-//      whose count reaches the running best.  A 2048-bin LDS table of segment masks over diagonal/16 discards the
-//      anchors that cannot reach it (random bucket hits: almost all), the survivors get their exact count by scanning
-//      the strand's positions, are put in the walk's order (segment, position) and ONE wave replays the walk's state
-//      machine on them -- reset on '>', append on '==' if the diagonal is new, stop at max_hits tied hits.
+//      whose count reaches the running best.  The positions are counting-sorted into 2048 buckets by a hash of
+//      diagonal/16, every anchor gets its exact count from the three buckets around its bin, the few anchors that reach
+//      the running best are put in the walk's order (segment, position) and ONE wave replays the walk's state machine on
+//      them -- reset on '>', append on '==' if the diagonal is new, stop at max_hits tied hits.
 #define PM_SEED_THREADS 256
 typedef uint32_t pm_u32x2 __attribute__ ((ext_vector_type (2), aligned (4)));
 #define PM_SEED_TABLE 2048
@@ -36,7 +36,9 @@ template < int SMAX > struct __align__ (8) PmSeedShared
     uint32_t table[PM_SEED_TABLE];      // phase 4: segment masks per diagonal bin
   } u;
   uint32_t ekey[2][PM_SEED_CAP];        // diagonal keys of the gathered positions, per strand
+  uint32_t bkey[PM_SEED_CAP];           // the strand being voted on, bucketed by hashed diagonal bin
   uint32_t hits[PM_MAX_HITS];
+  uint32_t wsum[4];
   uint32_t kmer[2][2 * SMAX];           // [pipeline buffer][strand * S + segment]
   int seg_cnt[2 * SMAX];
   int seg_base[2][SMAX + 1];
@@ -49,7 +51,8 @@ template < int SMAX > struct __align__ (8) PmSeedShared
   uint16_t order[PM_SEED_CAP];
   uint16_t hits_off[PM_MAX_HITS];
   uint8_t eseg[2][PM_SEED_CAP];
-  uint8_t tfs[PM_SEED_CAP];             // exact tot_found of the survivors
+  uint8_t bseg[PM_SEED_CAP];
+  uint8_t tfs[PM_SEED_CAP];             // tot_found of the candidates
   uint8_t hits_or[PM_MAX_HITS];
   uint8_t seq[2][2][320];               // [pipeline buffer][strand]
 };
@@ -76,11 +79,17 @@ __device__ __forceinline__ unsigned pm_bin_hash (uint32_t bin)
 
 // find_matches for one strand on unsorted diagonal keys; see the header comment.  All 256 threads enter; returns through
 // sh.state.  IdxT = uint16_t (LDS arrays) or uint32_t (global spill arrays of a strand with more than PM_SEED_CAP positions).
+//
+// The positions are bucketed by a hash of diagonal/16 (counting sort through the LDS table: count, exclusive scan, scatter);
+// an anchor's tot_found (pemapper.c:2241-2249) then only has to look at the buckets of its own and the two neighbouring
+// bins -- a handful of entries -- instead of at every position of the strand.  Buckets may mix bins (hash collisions) and
+// may be visited twice; the test on the real diagonals makes that harmless.
 template < class SH, class IdxT >
-__device__ void pm_vote_strand (SH & sh, const uint32_t * ekey, const uint8_t * eseg, IdxT * surv, IdxT * order, uint8_t * tfs, int T,
-                                const int *seg_cnt, const int *offsets, int total_cuts, int max_off, int &min_match, int &tot, bool & go_on,
-                                uint8_t strand)
+__device__ void pm_vote_strand (SH & sh, const uint32_t * ekey, const uint8_t * eseg, uint32_t * bkey, uint8_t * bseg, IdxT * surv, IdxT * order,
+                                uint8_t * tfs, int T, const int *seg_cnt, const int *offsets, int total_cuts, int max_off, int &min_match,
+                                int &tot, bool & go_on, uint8_t strand)
 {
+  constexpr bool LDSP = sizeof (IdxT) == 2;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   // pemapper.c:2200-2207: nothing is searched (and earlier hits are dropped) when every segment holds more than max_hits positions
   unsigned min_spots = 10000;
@@ -91,44 +100,87 @@ __device__ void pm_vote_strand (SH & sh, const uint32_t * ekey, const uint8_t * 
       tot = 0;
       return;
     }
-  for (int i = tid; i < PM_SEED_TABLE; i += PM_SEED_THREADS)
-    sh.u.table[i] = 0;
+  constexpr int PER = PM_SEED_TABLE / PM_SEED_THREADS;   // table entries per thread
+  for (int i = 0; i < PER; i++)
+    sh.u.table[tid * PER + i] = 0;
   if (tid == 0)
     sh.n_surv = 0;
-  pm_barrier < sizeof (IdxT) == 2 > ();
+  pm_barrier < LDSP > ();
+  // ---- counting sort by bucket: count
   for (int p = tid; p < T; p += PM_SEED_THREADS)
-    atomicOr (&sh.u.table[pm_bin_hash (ekey[p] >> 4)], 1u << eseg[p]);
-  pm_barrier < sizeof (IdxT) == 2 > ();
-  // an anchor of segment `loop` is only visited while loop <= 1 + max_depth - min_match (pemapper.c:2216; the bound only shrinks)
+    atomicAdd (&sh.u.table[pm_bin_hash (ekey[p] >> 4)], 1u);
+  pm_barrier < LDSP > ();
+  // ---- exclusive scan of the 2048 counts
+  {
+    uint32_t v[PER], run = 0;
+    for (int i = 0; i < PER; i++)
+      {
+        v[i] = run;
+        run += sh.u.table[tid * PER + i];
+      }
+    uint32_t inc = run;
+    for (int o = 1; o < 64; o <<= 1)
+      {
+        const uint32_t t = __shfl_up (inc, o);
+        if (lane >= o)
+          inc += t;
+      }
+    if (lane == 63)
+      sh.wsum[wv] = inc;
+    pm_barrier < LDSP > ();
+    uint32_t base = inc - run;
+    for (int w = 0; w < wv; w++)
+      base += sh.wsum[w];
+    for (int i = 0; i < PER; i++)
+      sh.u.table[tid * PER + i] = base + v[i];
+  }
+  pm_barrier < LDSP > ();
+  // ---- scatter; afterwards table[h] is the END of bucket h (= start of bucket h + 1)
+  for (int p = tid; p < T; p += PM_SEED_THREADS)
+    {
+      const uint32_t k = ekey[p];
+      const uint32_t pos = atomicAdd (&sh.u.table[pm_bin_hash (k >> 4)], 1u);
+      bkey[pos] = k;
+      bseg[pos] = eseg[p];
+    }
+  pm_barrier < LDSP > ();
+  // ---- tot_found of every anchor the walk can reach: 1 + number of LATER segments holding a position whose diagonal
+  //      differs by less than max_off.  An anchor of segment `loop` is only visited while loop <= 1 + max_depth - min_match
+  //      (pemapper.c:2216; the bound only shrinks), and only acts if its count reaches min_match (which only grows).
   const int loop_max = 1 + total_cuts - min_match;
+  const uint32_t span = (uint32_t) (2 * (max_off - 1));
   for (int p = tid; p < T; p += PM_SEED_THREADS)
     {
-      const uint32_t bin = ekey[p] >> 4;
-      const uint32_t mask = sh.u.table[pm_bin_hash (bin - 1u)] | sh.u.table[pm_bin_hash (bin)] | sh.u.table[pm_bin_hash (bin + 1u)];
-      if ((int) eseg[p] <= loop_max && __popc (mask) >= min_match)
-        surv[atomicAdd (&sh.n_surv, 1u)] = (IdxT) p;
-    }
-  pm_barrier < sizeof (IdxT) == 2 > ();
-  const int ns = (int) sh.n_surv;
-  // exact tot_found (pemapper.c:2241-2249): 1 + number of LATER segments with a position whose diagonal differs by less than max_off
-  for (int sv = wv; sv < ns; sv += PM_SEED_THREADS / 64)
-    {
-      const int a = (int) surv[sv];
-      const int64_t ka = (int64_t) ekey[a];
-      const int sa = eseg[a];
+      const int sa = eseg[p];
+      if (sa > loop_max)
+        continue;
+      const uint32_t ka = ekey[p];
+      const uint32_t bin = ka >> 4;
+      const uint32_t later = (total_cuts >= 31 ? 0xFFFFFFFFu : ((1u << (total_cuts + 1)) - 1u)) & ~((2u << sa) - 1u);
       uint32_t bits = 0;
-      for (int x = lane; x < T; x += 64)
+      for (int db = -1; db <= 1 && bits != later; db++)
         {
-          const int64_t d = (int64_t) ekey[x] - ka;
-          if ((int) eseg[x] > sa && d > -(int64_t) max_off && d < (int64_t) max_off)
-            bits |= 1u << eseg[x];
+          const unsigned hh = pm_bin_hash (bin + (uint32_t) db);
+          const uint32_t lo = hh ? sh.u.table[hh - 1] : 0u, hi = sh.u.table[hh];
+          for (uint32_t x = lo; x < hi; x++)
+            {
+              // |diag_x - diag_a| < max_off, in wrapping 32-bit arithmetic (keys stay below 2^32 - 100)
+              const uint32_t d = bkey[x] - ka + (uint32_t) (max_off - 1);
+              const int sx = bseg[x];
+              if (d <= span && sx > sa)
+                bits |= 1u << sx;
+            }
         }
-      for (int o = 32; o > 0; o >>= 1)
-        bits |= __shfl_xor (bits, o);
-      if (lane == 0)
-        tfs[sv] = (uint8_t) (1 + __popc (bits));
+      const int tf = 1 + __popc (bits);
+      if (tf >= min_match)
+        {
+          const unsigned slot = atomicAdd (&sh.n_surv, 1u);
+          surv[slot] = (IdxT) p;
+          tfs[slot] = (uint8_t) tf;
+        }
     }
-  pm_barrier < sizeof (IdxT) == 2 > ();
+  pm_barrier < LDSP > ();
+  const int ns = (int) sh.n_surv;
   // walk order: segment ascending, position ascending inside a segment (same offset, so diagonal ascending)
   for (int sv = tid; sv < ns; sv += PM_SEED_THREADS)
     {
@@ -142,7 +194,7 @@ __device__ void pm_vote_strand (SH & sh, const uint32_t * ekey, const uint8_t * 
         }
       order[rank] = (IdxT) sv;
     }
-  pm_barrier < sizeof (IdxT) == 2 > ();
+  pm_barrier < LDSP > ();
   if (tid < 64)
     {
       bool more = true, done = false;
@@ -227,7 +279,7 @@ __device__ void pm_vote_strand (SH & sh, const uint32_t * ekey, const uint8_t * 
           sh.state[2] = more ? 1 : 0;
         }
     }
-  pm_barrier < sizeof (IdxT) == 2 > ();
+  pm_barrier < LDSP > ();
   min_match = sh.state[0];
   tot = sh.state[1];
   go_on = sh.state[2] != 0;
@@ -343,7 +395,7 @@ __device__ __forceinline__ void pm_seed_stage_a (SH & sh, const PmIndex & ix, co
     }
 }
 
-template < int SMAX > __global__ __launch_bounds__ (PM_SEED_THREADS) void pm_seed_kernel (PmIndex ix, PmBatch b, PmParams prm, PmHits h,
+template < int SMAX > __global__ __launch_bounds__ (PM_SEED_THREADS, 4) void pm_seed_kernel (PmIndex ix, PmBatch b, PmParams prm, PmHits h,
                                                                                           uint32_t * tasks_s, uint32_t * tasks_m,
                                                                                           PmCounters * ctr, uint32_t * gscratch, int phase_limit,
                                                                                           const uint32_t * end_list, const unsigned *n_list)
@@ -358,11 +410,13 @@ template < int SMAX > __global__ __launch_bounds__ (PM_SEED_THREADS) void pm_see
   // per-workgroup spill area for the rare strand whose positions exceed the LDS capacity: keys, survivors, order (u32 each),
   // segment numbers and counts (u8 each), PM_MAX_SEG * PM_SEG_LIST_MAX entries each
   constexpr size_t GN = (size_t) PM_MAX_SEG * PM_SEG_LIST_MAX;
-  uint32_t *g_key = gscratch + (size_t) blockIdx.x * 4 * GN;
-  uint32_t *g_surv = g_key + GN;
+  uint32_t *g_key = gscratch + (size_t) blockIdx.x * 6 * GN;
+  uint32_t *g_bkey = g_key + GN;
+  uint32_t *g_surv = g_bkey + GN;
   uint32_t *g_order = g_surv + GN;
   uint8_t *g_seg = (uint8_t *) (g_order + GN);
-  uint8_t *g_tfs = g_seg + GN;
+  uint8_t *g_bseg = g_seg + GN;
+  uint8_t *g_tfs = g_bseg + GN;
 
   uint32_t v0[NI], v1[NI];
   const uint32_t pos_index_0 = ix.pos_index[0];
@@ -534,11 +588,12 @@ template < int SMAX > __global__ __launch_bounds__ (PM_SEED_THREADS) void pm_see
               else
                 pm_lds_barrier ();
               if (in_lds)
-                pm_vote_strand < SH, uint16_t > (sh, sh.ekey[strand], sh.eseg[strand], sh.surv, sh.order, sh.tfs, T, &sh.seg_cnt[strand * S],
-                                                 sh.offsets[buf], total_cuts, max_off, min_match, tot, go_on, (uint8_t) strand);
+                pm_vote_strand < SH, uint16_t > (sh, sh.ekey[strand], sh.eseg[strand], sh.bkey, sh.bseg, sh.surv, sh.order, sh.tfs, T,
+                                                 &sh.seg_cnt[strand * S], sh.offsets[buf], total_cuts, max_off, min_match, tot, go_on,
+                                                 (uint8_t) strand);
               else
-                pm_vote_strand < SH, uint32_t > (sh, g_key, g_seg, g_surv, g_order, g_tfs, T, &sh.seg_cnt[strand * S], sh.offsets[buf], total_cuts,
-                                                 max_off, min_match, tot, go_on, (uint8_t) strand);
+                pm_vote_strand < SH, uint32_t > (sh, g_key, g_seg, g_bkey, g_bseg, g_surv, g_order, g_tfs, T, &sh.seg_cnt[strand * S],
+                                                 sh.offsets[buf], total_cuts, max_off, min_match, tot, go_on, (uint8_t) strand);
               if (tot >= PM_MAX_HITS)
                 go_on = false;
             }

@@ -205,11 +205,36 @@ template < int SMAX > __global__ __launch_bounds__ (PM_SEED_THREADS, 8) void pm_
     }
 }
 
+// LDS of the vote kernel: one strand at a time (the lists come from HBM), no look-up items
+template < int SMAX > struct __align__ (8) PmVoteShared
+{
+  union
+  {
+    uint32_t table[PM_SEED_TABLE];
+  } u;
+  uint32_t ekey[1][PM_SEED_CAP];
+  uint32_t bkey[PM_SEED_CAP];
+  uint32_t hits[PM_MAX_HITS];
+  uint32_t wsum[4];
+  int seg_cnt[2 * SMAX];
+  int seg_base[2][SMAX + 1];
+  int offsets[1][SMAX + 1];
+  int state[4];
+  unsigned n_surv;
+  uint16_t surv[PM_SEED_CAP];
+  uint16_t order[PM_SEED_CAP];
+  uint16_t hits_off[PM_MAX_HITS];
+  uint8_t eseg[1][PM_SEED_CAP];
+  uint8_t bseg[PM_SEED_CAP];
+  uint8_t tfs[PM_SEED_CAP];
+  uint8_t hits_or[PM_MAX_HITS];
+};
+
 template < int SMAX > __global__ __launch_bounds__ (PM_SEED_THREADS) void pm_vote_kernel (PmIndex ix, PmBatch b, PmParams prm, PmHits h,
                                                                                           uint32_t * tasks_s, uint32_t * tasks_m,
                                                                                           PmCounters * ctr, PmLists in)
 {
-  typedef PmSeedShared < SMAX > SH;
+  typedef PmVoteShared < SMAX > SH;
   __shared__ SH sh;
   const int tid = threadIdx.x;
   const int idepth = ix.idepth;
@@ -242,15 +267,21 @@ template < int SMAX > __global__ __launch_bounds__ (PM_SEED_THREADS) void pm_vot
         }
       const uint32_t *ikey = in.key + (size_t) e * 2 * PM_SEED_CAP;
       const uint8_t *iseg = in.seg + (size_t) e * 2 * PM_SEED_CAP;
+      // strand 1's list is prefetched into registers while strand 0 is voted on
+      constexpr int NP = PM_SEED_CAP / PM_SEED_THREADS;
+      uint32_t k1[NP];
+      uint8_t s1[NP];
+#pragma unroll
+      for (int r = 0; r < NP; r++)
+        {
+          const int p = tid + r * PM_SEED_THREADS;
+          k1[r] = p < T1 ? ikey[PM_SEED_CAP + p] : 0u;
+          s1[r] = p < T1 ? iseg[PM_SEED_CAP + p] : (uint8_t) 0;
+        }
       for (int p = tid; p < T0; p += PM_SEED_THREADS)
         {
           sh.ekey[0][p] = ikey[p];
           sh.eseg[0][p] = iseg[p];
-        }
-      for (int p = tid; p < T1; p += PM_SEED_THREADS)
-        {
-          sh.ekey[1][p] = ikey[PM_SEED_CAP + p];
-          sh.eseg[1][p] = iseg[PM_SEED_CAP + p];
         }
       __syncthreads ();
       if (tid < 2 * S)
@@ -266,7 +297,21 @@ template < int SMAX > __global__ __launch_bounds__ (PM_SEED_THREADS) void pm_vot
       bool go_on = true;
       for (int strand = 0; strand < 2 && go_on; strand++)
         {
-          pm_vote_strand < SH, uint16_t > (sh, sh.ekey[strand], sh.eseg[strand], sh.surv, sh.order, sh.tfs, strand ? T1 : T0,
+          if (strand == 1)
+            {
+#pragma unroll
+              for (int r = 0; r < NP; r++)
+                {
+                  const int p = tid + r * PM_SEED_THREADS;
+                  if (p < T1)
+                    {
+                      sh.ekey[0][p] = k1[r];
+                      sh.eseg[0][p] = s1[r];
+                    }
+                }
+              pm_lds_barrier ();
+            }
+          pm_vote_strand < SH, uint16_t > (sh, sh.ekey[0], sh.eseg[0], sh.bkey, sh.bseg, sh.surv, sh.order, sh.tfs, strand ? T1 : T0,
                                            &sh.seg_cnt[strand * S], sh.offsets[0], total_cuts, max_off, min_match, tot, go_on, (uint8_t) strand);
           if (tot >= PM_MAX_HITS)
             go_on = false;
