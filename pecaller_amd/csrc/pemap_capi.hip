@@ -41,6 +41,10 @@ struct pemap_dev
   int cap_ends;
   PmHits hits;
   uint32_t *d_tasks_s, *d_tasks_m, *d_redo, *d_wins;
+  // second set of the arrays the walk kernel reads, so that walk(chunk k) can run beside vote/SW(chunk k+1)
+  PmHits hits2;
+  uint32_t *d_wins2, *d_dirbuf2;
+  hipEvent_t ev_alu_done[2], ev_walk_done[2];
   uint32_t *d_m1, *d_m2;
   int *d_mtype;
   int cap_out;
@@ -55,7 +59,7 @@ struct pemap_dev
   // run bookkeeping
   int run_first, run_n;
   bool run_pending;             // kernels of the last run still in flight / not yet accounted
-  bool run_split, serial_split;
+  bool run_split, serial_split, walk_on_mem;
   int run_chunks;
   hipEvent_t ev[7];
   // two-stream pipeline: the look-up kernel of chunk k+1 (memory stream) runs beside vote/SW/walk of chunk k
@@ -131,6 +135,8 @@ extern "C" int pemap_dev_create (pemap_dev ** out, int device_id)
   d->staged_paired = 0;
   d->cap_ends = 0;
   memset (&d->hits, 0, sizeof (d->hits));
+  memset (&d->hits2, 0, sizeof (d->hits2));
+  d->d_wins2 = d->d_dirbuf2 = nullptr;
   d->d_tasks_s = d->d_tasks_m = d->d_redo = d->d_wins = d->d_m1 = d->d_m2 = nullptr;
   d->d_cur = nullptr;
   d->dirbuf_dwords = 0;
@@ -207,23 +213,30 @@ static void free_index (pemap_dev * d)
   d->index_ready = false;
 }
 
+static void free_hits (PmHits & h)
+{
+  hipFree (h.n_hits);
+  hipFree (h.spot);
+  hipFree (h.gpos);
+  hipFree (h.nn);
+  hipFree (h.orient);
+  hipFree (h.score);
+  hipFree (h.sti);
+  hipFree (h.stk);
+  hipFree (h.slot);
+  memset (&h, 0, sizeof (h));
+}
+
 static void free_work (pemap_dev * d)
 {
-  hipFree (d->hits.n_hits);
-  hipFree (d->hits.spot);
-  hipFree (d->hits.gpos);
-  hipFree (d->hits.nn);
-  hipFree (d->hits.orient);
-  hipFree (d->hits.score);
-  hipFree (d->hits.sti);
-  hipFree (d->hits.stk);
-  hipFree (d->hits.slot);
-  memset (&d->hits, 0, sizeof (d->hits));
+  free_hits (d->hits);
+  free_hits (d->hits2);
   hipFree (d->d_tasks_s);
   hipFree (d->d_tasks_m);
   hipFree (d->d_redo);
   hipFree (d->d_wins);
-  d->d_tasks_s = d->d_tasks_m = d->d_redo = d->d_wins = nullptr;
+  hipFree (d->d_wins2);
+  d->d_tasks_s = d->d_tasks_m = d->d_redo = d->d_wins = d->d_wins2 = nullptr;
   d->cap_ends = 0;
 }
 
@@ -246,6 +259,7 @@ extern "C" void pemap_dev_destroy (pemap_dev * d)
   hipFree (d->d_cur);
   hipFree (d->d_seed_scratch);
   hipFree (d->d_dirbuf);
+  hipFree (d->d_dirbuf2);
   hipFree (d->d_ins_log);
   for (int i = 0; i < 7; i++)
     hipEventDestroy (d->ev[i]);
@@ -256,6 +270,8 @@ extern "C" void pemap_dev_destroy (pemap_dev * d)
         {
           hipEventDestroy (d->ev_lists_ready[i]);
           hipEventDestroy (d->ev_lists_free[i]);
+          hipEventDestroy (d->ev_alu_done[i]);
+          hipEventDestroy (d->ev_walk_done[i]);
           hipFree (d->lists[i].hdr);
           hipFree (d->lists[i].key);
           hipFree (d->lists[i].seg);
@@ -520,36 +536,51 @@ static size_t dir_budget_bytes ()
   return (size_t) (gb * 1073741824.0);
 }
 
-static int ensure_work (pemap_dev * d, int n_ends)
+static int alloc_hits (pemap_dev * d, PmHits & h, int n_ends)
 {
-  if (n_ends > d->cap_ends)
+  size_t nh = (size_t) n_ends * PM_MAX_HITS;
+  TRY (dev_alloc (d, &h.n_hits, (size_t) n_ends));
+  TRY (dev_alloc (d, &h.slot, (size_t) n_ends));
+  TRY (dev_alloc (d, &h.spot, nh));
+  TRY (dev_alloc (d, &h.gpos, nh));
+  TRY (dev_alloc (d, &h.nn, nh));
+  TRY (dev_alloc (d, &h.orient, nh));
+  TRY (dev_alloc (d, &h.score, nh));
+  TRY (dev_alloc (d, &h.sti, nh));
+  TRY (dev_alloc (d, &h.stk, nh));
+  return 0;
+}
+
+static int ensure_work (pemap_dev * d, int n_ends, bool two_sets)
+{
+  if (n_ends > d->cap_ends || (two_sets && !d->hits2.n_hits))
     {
       free_work (d);
       size_t nh = (size_t) n_ends * PM_MAX_HITS;
-      TRY (dev_alloc (d, &d->hits.n_hits, (size_t) n_ends));
-      TRY (dev_alloc (d, &d->hits.slot, (size_t) n_ends));
-      TRY (dev_alloc (d, &d->hits.spot, nh));
-      TRY (dev_alloc (d, &d->hits.gpos, nh));
-      TRY (dev_alloc (d, &d->hits.nn, nh));
-      TRY (dev_alloc (d, &d->hits.orient, nh));
-      TRY (dev_alloc (d, &d->hits.score, nh));
-      TRY (dev_alloc (d, &d->hits.sti, nh));
-      TRY (dev_alloc (d, &d->hits.stk, nh));
+      TRY (alloc_hits (d, d->hits, n_ends));
+      TRY (dev_alloc (d, &d->d_wins, (size_t) n_ends));
+      if (two_sets)
+        {
+          TRY (alloc_hits (d, d->hits2, n_ends));
+          TRY (dev_alloc (d, &d->d_wins2, (size_t) n_ends));
+        }
       TRY (dev_alloc (d, &d->d_tasks_s, (size_t) n_ends));
       TRY (dev_alloc (d, &d->d_tasks_m, nh));
       TRY (dev_alloc (d, &d->d_redo, (size_t) n_ends));
-      TRY (dev_alloc (d, &d->d_wins, (size_t) n_ends));
       d->cap_ends = n_ends;
     }
   if (!d->d_seed_scratch)
     TRY (dev_alloc (d, &d->d_seed_scratch, (size_t) d->seed_grid * 6 * PM_MAX_SEG * PM_SEG_LIST_MAX));
   size_t need = ((size_t) n_ends + 1) * slab_dwords_for (d->max_len_staged);       // + 1: dump slab for task-less lane groups
-  if (need > d->dirbuf_dwords)
+  if (need > d->dirbuf_dwords || (two_sets && !d->d_dirbuf2))
     {
       hipFree (d->d_dirbuf);
-      d->d_dirbuf = nullptr;
+      hipFree (d->d_dirbuf2);
+      d->d_dirbuf = d->d_dirbuf2 = nullptr;
       d->dirbuf_dwords = 0;
       TRY (dev_alloc (d, &d->d_dirbuf, need));
+      if (two_sets)
+        TRY (dev_alloc (d, &d->d_dirbuf2, need));
       d->dirbuf_dwords = need;
     }
   // insertion log: 64 bytes per read-end of a chunk is ample for real data; overflow is reported as an error
@@ -653,7 +684,7 @@ static void launch_lookup (pemap_dev * d, const RunCtx & c, int slot, PmChunkCtr
   // occupancy knob of the look-up kernel (diagnostic): dynamic LDS padding in KB limits its workgroups per CU, so that
   // the latency-bound vote kernel running beside it keeps its wave slots
   const char *padenv = getenv ("PEMAP_LOOKUP_LDS_PAD_KB");
-  const unsigned pad = (padenv ? (unsigned) atoi (padenv) : 30u) * 1024u;    // 4 look-up workgroups per CU
+  const unsigned pad = (padenv ? (unsigned) atoi (padenv) : 20u) * 1024u;    // 5 look-up workgroups per CU (swept: 8..44 KB)
 #define PM_LK(SM) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_lookup_kernel < SM >), dim3 (c.b.n_ends), dim3 (PM_SEED_THREADS), pad, st, c.ix, c.b, c.prm, L)
   switch (seg_template (c.L))
     {
@@ -672,6 +703,11 @@ static void launch_lookup (pemap_dev * d, const RunCtx & c, int slot, PmChunkCtr
 template < int W > static void launch_chunk (pemap_dev * d, const RunCtx & c, uint32_t * m1, uint32_t * m2, int *mt, bool split, int slot,
                                              PmChunkCtr * cc, hipEvent_t * ev)
 {
+  // the arrays the walk reads alternate between two sets in the split pipeline
+  const PmHits & H = (split && slot) ? d->hits2 : d->hits;
+  uint32_t *wins = (split && slot) ? d->d_wins2 : d->d_wins;
+  uint32_t *dirbuf = (split && slot) ? d->d_dirbuf2 : d->d_dirbuf;
+  uint32_t *dump_slab = dirbuf + (c.dump_slab - d->d_dirbuf);
   const int n_ends = c.b.n_ends;
   PmCounters *ctr = &cc->c;
   const char *pl = getenv ("PEMAP_SEED_PHASE");      // timing probe only: results are meaningless when set
@@ -683,9 +719,9 @@ template < int W > static void launch_chunk (pemap_dev * d, const RunCtx & c, ui
       L.n_big = &cc->n_big;
       L.positions = &cc->positions;
 #define PM_VT(SM) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_vote_kernel < SM >), dim3 (n_ends), dim3 (PM_SEED_THREADS), 0, d->stream, c.ix, c.b, c.prm, \
-                                      d->hits, d->d_tasks_s, d->d_tasks_m, ctr, L)
+                                      H, d->d_tasks_s, d->d_tasks_m, ctr, L)
 #define PM_SEEDL(SM) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_seed_kernel < SM >), dim3 (d->big_grid), dim3 (PM_SEED_THREADS), 0, d->stream, c.ix, c.b, \
-                                         c.prm, d->hits, d->d_tasks_s, d->d_tasks_m, ctr, d->d_seed_scratch, 0, L.big_list, L.n_big)
+                                         c.prm, H, d->d_tasks_s, d->d_tasks_m, ctr, d->d_seed_scratch, 0, L.big_list, L.n_big)
       switch (seg_template (c.L))
         {
         case 7: PM_VT (7); PM_SEEDL (7); break;
@@ -696,12 +732,13 @@ template < int W > static void launch_chunk (pemap_dev * d, const RunCtx & c, ui
         }
 #undef PM_VT
 #undef PM_SEEDL
+      hipEventRecord (d->ev_lists_free[slot], d->stream);      // the slot's lists are consumed
     }
   else
     {
       int sgrid = d->seed_grid < n_ends ? d->seed_grid : n_ends;
 #define PM_SEED(SM) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_seed_kernel < SM >), dim3 (sgrid), dim3 (PM_SEED_THREADS), 0, d->stream, c.ix, c.b, c.prm, \
-                                        d->hits, d->d_tasks_s, d->d_tasks_m, ctr, d->d_seed_scratch, phase_limit, (const uint32_t *) nullptr, \
+                                        H, d->d_tasks_s, d->d_tasks_m, ctr, d->d_seed_scratch, phase_limit, (const uint32_t *) nullptr, \
                                         (const unsigned *) nullptr)
       switch (seg_template (c.L))
         {
@@ -714,24 +751,36 @@ template < int W > static void launch_chunk (pemap_dev * d, const RunCtx & c, ui
 #undef PM_SEED
     }
   hipEventRecord (ev[3], d->stream);
-  hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, true >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, d->hits,
-                      d->d_tasks_s, &ctr->n_tasks_s, ctr, d->d_dirbuf, c.dump_slab, c.tstride, c.L);
+  hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, true >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, H,
+                      d->d_tasks_s, &ctr->n_tasks_s, ctr, dirbuf, dump_slab, c.tstride, c.L);
   hipEventRecord (ev[4], d->stream);
-  hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, false >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, d->hits,
-                      d->d_tasks_m, &ctr->n_tasks_m, ctr, d->d_dirbuf, c.dump_slab, c.tstride, c.L);
+  hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, false >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, H,
+                      d->d_tasks_m, &ctr->n_tasks_m, ctr, dirbuf, dump_slab, c.tstride, c.L);
   hipEventRecord (ev[5], d->stream);
-  hipLaunchKernelGGL (pm_select_kernel, dim3 ((c.b.n + 255) / 256), dim3 (256), 0, d->stream, c.b, c.prm, d->hits, d->d_redo, d->d_wins, ctr,
+  hipLaunchKernelGGL (pm_select_kernel, dim3 ((c.b.n + 255) / 256), dim3 (256), 0, d->stream, c.b, c.prm, H, d->d_redo, wins, ctr,
                       m1, m2, mt);
   hipEventRecord (ev[6], d->stream);
-  hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, true >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, d->hits,
-                      d->d_redo, &ctr->n_redo, ctr, d->d_dirbuf, c.dump_slab, c.tstride, c.L);
+  hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, true >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, H,
+                      d->d_redo, &ctr->n_redo, ctr, dirbuf, dump_slab, c.tstride, c.L);
   hipEventRecord (ev[7], d->stream);
+  hipEventRecord (ev[9], d->stream);
   int wgrid = (n_ends + 255) / 256;
   if (wgrid > d->sw_grid)
     wgrid = d->sw_grid;
-  hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_walk_kernel < W >), dim3 (wgrid), dim3 (256), 0, d->stream, c.b, d->hits, d->d_wins, ctr, d->d_cur,
-                      d->d_dirbuf, c.tstride, d->d_counts, d->d_ins_log, d->ins_cap);
-  hipEventRecord (ev[8], d->stream);
+  // the walk (dependent-load latency) goes to the memory stream in the split pipeline: it runs beside the next chunk's vote/SW
+  // (measured on MI355X: 107 ms per step against 103 ms with the walk left on the ALU stream, so it is opt-in: PEMAP_WALK_ON_MEM_STREAM=1)
+  hipStream_t ws = (split && !d->serial_split && d->walk_on_mem) ? d->stream2 : d->stream;
+  if (ws != d->stream)
+    {
+      hipEventRecord (d->ev_alu_done[slot], d->stream);
+      hipStreamWaitEvent (ws, d->ev_alu_done[slot], 0);
+      hipEventRecord (ev[7], ws);
+    }
+  hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_walk_kernel < W >), dim3 (wgrid), dim3 (256), 0, ws, c.b, H, wins, ctr, d->d_cur,
+                      dirbuf, c.tstride, d->d_counts, d->d_ins_log, d->ins_cap);
+  hipEventRecord (ev[8], ws);
+  if (ws != d->stream)
+    hipEventRecord (d->ev_walk_done[slot], ws);
 }
 
 // wait for the run in flight and fold its chunks' counters and kernel times into the run's totals
@@ -771,7 +820,7 @@ static int absorb_run (pemap_dev * d)
           d->last_ms[7] += ms;
         }
       for (int i = 1; i < 6; i++)
-        if (hipEventElapsedTime (&ms, ev[2 + i], ev[3 + i]) == hipSuccess)
+        if (hipEventElapsedTime (&ms, ev[2 + i], (i == 4) ? ev[9] : ev[3 + i]) == hipSuccess)
           d->last_ms[i] += ms;
     }
   if (d->last_cur.ins_overflow)
@@ -790,6 +839,8 @@ static int ensure_pipeline (pemap_dev * d, int chunk_ends)
         {
           HIPCHK (d, hipEventCreateWithFlags (&d->ev_lists_ready[i], hipEventDisableTiming));
           HIPCHK (d, hipEventCreateWithFlags (&d->ev_lists_free[i], hipEventDisableTiming));
+          HIPCHK (d, hipEventCreateWithFlags (&d->ev_alu_done[i], hipEventDisableTiming));
+          HIPCHK (d, hipEventCreateWithFlags (&d->ev_walk_done[i], hipEventDisableTiming));
         }
       TRY (dev_alloc (d, &d->d_chunk_ctr, (size_t) PM_MAX_CHUNKS));
       d->evs.resize ((size_t) PM_MAX_CHUNKS * PM_NEV);
@@ -838,6 +889,7 @@ static int run_slice (pemap_dev * d, int first, int n, int sync)
   // 0 monolithic seed kernel, one stream; 2 split kernels on one stream (diagnostic).
   const bool split = !(pe && atoi (pe) == 0) && !getenv ("PEMAP_SEED_PHASE");
   d->serial_split = pe && atoi (pe) == 2;
+  { const char *we = getenv ("PEMAP_WALK_ON_MEM_STREAM"); d->walk_on_mem = we && atoi (we) != 0; }
   // chunk: one direction slab per read-end must fit the budget; the two-stream pipeline wants several chunks per run
   size_t slab_bytes = slab_dwords_for (L) * 4;
   long max_ends = (long) (dir_budget_bytes () / slab_bytes);
@@ -855,7 +907,7 @@ static int run_slice (pemap_dev * d, int first, int n, int sync)
   if ((n + chunk - 1) / chunk > PM_MAX_CHUNKS)
     chunk = (n + PM_MAX_CHUNKS - 1) / PM_MAX_CHUNKS;
   const int nch = (n + chunk - 1) / chunk;
-  TRY (ensure_work (d, chunk * per));
+  TRY (ensure_work (d, chunk * per, split));
   TRY (ensure_pipeline (d, chunk * per));
   RunCtx c;
   c.ix.pos_index = d->d_pos_index;
@@ -899,6 +951,23 @@ static int run_slice (pemap_dev * d, int first, int n, int sync)
     bb.paired = d->paired;
     bb.n_ends = m * per;
   };
+  auto enqueue_lookup = [&] (int k) -> int
+  {
+    int f, m;
+    RunCtx cl = c;
+    batch_of (k, cl.b, f, m);
+    const int slot = k & 1;
+    // the slot's lists must have been consumed by the vote of chunk k-2
+    if (k >= 2)
+      HIPCHK (d, hipStreamWaitEvent (d->serial_split ? d->stream : d->stream2, d->ev_lists_free[slot], 0));
+    launch_lookup (d, cl, slot, d->d_chunk_ctr + k, &d->evs[(size_t) k * PM_NEV]);
+    HIPCHK (d, hipEventRecord (d->ev_lists_ready[slot], d->serial_split ? d->stream : d->stream2));
+    return 0;
+  };
+  // memory stream order: lookup(0), lookup(1), then per chunk k: walk(k), lookup(k+2) -- the look-ups stay one chunk ahead
+  if (split && !d->serial_split)
+    for (int k = 0; k < 2 && k < nch; k++)
+      TRY (enqueue_lookup (k));
   for (int k = 0; k < nch; k++)
     {
       int f, m;
@@ -908,12 +977,12 @@ static int run_slice (pemap_dev * d, int first, int n, int sync)
       hipEvent_t *ev = &d->evs[(size_t) k * PM_NEV];
       if (split)
         {
-          // memory stream: the slot's lists must have been consumed by the vote of chunk k-2
-          if (k >= 2)
-            HIPCHK (d, hipStreamWaitEvent (d->stream2, d->ev_lists_free[slot], 0));
-          launch_lookup (d, c, slot, cc, ev);
-          HIPCHK (d, hipEventRecord (d->ev_lists_ready[slot], d->stream2));
+          if (d->serial_split)
+            TRY (enqueue_lookup (k));
           HIPCHK (d, hipStreamWaitEvent (d->stream, d->ev_lists_ready[slot], 0));
+          // this chunk's vote overwrites the array set that walk(k-2) reads
+          if (k >= 2 && !d->serial_split && d->walk_on_mem)
+            HIPCHK (d, hipStreamWaitEvent (d->stream, d->ev_walk_done[slot], 0));
         }
       uint32_t *m1 = d->d_m1 + f, *m2 = d->paired ? d->d_m2 + f : nullptr;
       int *mt = d->d_mtype + f;
@@ -925,9 +994,9 @@ static int run_slice (pemap_dev * d, int first, int n, int sync)
         case 32: launch_chunk < 32 > (d, c, m1, m2, mt, split, slot, cc, ev); break;
         default: launch_chunk < 38 > (d, c, m1, m2, mt, split, slot, cc, ev); break;
         }
-      if (split)
-        HIPCHK (d, hipEventRecord (d->ev_lists_free[slot], d->stream));    // (recorded after the whole chunk: simple and sufficient)
       HIPCHK (d, hipGetLastError ());
+      if (split && !d->serial_split && k + 2 < nch)
+        TRY (enqueue_lookup (k + 2));
     }
   d->run_pending = true;
   if (sync)
