@@ -190,11 +190,17 @@ def main():
             "sw_redo": (agg["redo"] / ends) * (L + 21 + L + slab),
             "walk": (agg["walks"] / ends) * ((L + 21) * 0.5 + 4 * L) + 4,   # nibbles along the path + pileup RMW + mfile
         }
-        alg_bytes = per_end[dom] * (ends / a.steps)
-        achieved = alg_bytes / (avg_ms[dom] * 1e-3) / 1e9
+        # one "launch" of the dominant kernel = one chunk of the step (the run is cut into chunks that pipeline on two
+        # streams); algorithmic bytes per launch / average launch duration (HIP events on the kernel's own stream)
+        launches = max(1, agg["chunks"] // a.steps)
+        launch_ms = avg_ms[dom] / launches
+        alg_bytes = per_end[dom] * (ends / a.steps) / launches
+        achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
+        traffic, tsrc = pmc_traffic("pm_%s_kernel" % dom, gs, B, L)
         total_b = algorithmic_bytes_per_end(L, P_e, H_e)
         roof = {"bound": "hbm", "kernel": "pm_%s_kernel" % dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc,
+                "launches_per_step": launches, "avg_launch_ms": round(launch_ms, 3), "algorithmic_bytes_per_launch": round(alg_bytes),
                 "kernel_ms": {k: round(v, 3) for k, v in avg_ms.items()},
                 "bytes_per_end_path": round(total_b, 1), "P_per_end": round(P_e, 2), "H_per_end": round(H_e, 3),
                 "path_GBs": round(total_b * ends / a.steps / (dt / a.steps) / 1e9, 2),
@@ -219,6 +225,23 @@ def main():
     dev.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel, gsize, B, L):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs
+    of this same command, profiles/r01_bench_pmc_final.json), valid for the default workload only.  FETCH_SIZE is taken
+    at face value: on this kernel's 8-byte random gathers it equals TCC_EA0_RDREQ x 64 B, one 64-byte request per gather
+    (calibrated with tools/micro/gather_calib.hip; the 1/2 factor of MI355X_MICROARCH.md applies to coalesced streams)."""
+    path = os.path.join(ROOT, "profiles", "r01_bench_pmc_final.json")
+    if not (os.path.exists(path) and gsize == 3100000000 and B == 1000000 and L == 150):
+        return None, None
+    try:
+        pm = json.load(open(path))
+        f = [v for k, v in pm["FETCH_SIZE"].items() if k.startswith(kernel)][0]["mean_KB_per_launch"]
+        w = [v for k, v in pm["WRITE_SIZE"].items() if k.startswith(kernel)][0]["mean_KB_per_launch"]
+        return round((f + w) * 1024.0), "profiles/r01_bench_pmc_final.json"
+    except Exception:
+        return None, None
 
 
 def cpu_baseline(dev, a, B):

@@ -1122,6 +1122,7 @@ extern "C" int pemap_dev_run_stats (pemap_dev * d, uint64_t * s, float *t)
       s[8] = c.n_wins;
       s[9] = c.n_redo;
       s[10] = d->last_big;
+      s[11] = (uint64_t) d->run_chunks;
     }
   if (t)
     memcpy (t, d->last_ms, sizeof (d->last_ms));
