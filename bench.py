@@ -148,12 +148,15 @@ def main():
     t0 = time.perf_counter()
     kt = {"seed": [], "sw_single": [], "sw_multi": [], "select": [], "sw_redo": [], "walk": [], "lookup": [], "vote": []}
     agg = None
+    # the K steps are queued back to back (each step = one slice of the resident reads) and synchronised once: the
+    # library pipelines the look-ups of a step's first chunk under the previous step's last chunk
     for s in range(a.steps):
-        dev.run_slice((a.warmup + s) * B, B, sync=True)
-        st, tm = dev.run_stats()
-        for k in kt:
-            kt[k].append(tm[k])
-        agg = st if agg is None else {k: agg[k] + st[k] for k in st}
+        dev.run_slice((a.warmup + s) * B, B, sync=False)
+    dev.sync()
+    st, tm = dev.run_stats()        # totals over the K queued steps
+    for k in kt:
+        kt[k].append(tm[k] / a.steps)
+    agg = st
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0

@@ -60,7 +60,8 @@ struct pemap_dev
   int run_first, run_n;
   bool run_pending;             // kernels of the last run still in flight / not yet accounted
   bool run_split, serial_split, walk_on_mem;
-  int run_chunks;
+  int run_chunks, run_chunk_pairs, run_L;
+  uint64_t run_ends;
   hipEvent_t ev[7];
   // two-stream pipeline: the look-up kernel of chunk k+1 (memory stream) runs beside vote/SW/walk of chunk k
   hipStream_t stream2;
@@ -876,12 +877,6 @@ static int run_slice (pemap_dev * d, int first, int n, int sync)
     return fail (d, "run: slice [%d, %d) outside the %d staged reads", first, first + n, d->n_staged);
   if (d->staged_paired != d->paired)
     return fail (d, "run: reads were staged in %s mode", d->staged_paired ? "paired" : "single");
-  // finish (and account for) an asynchronous previous run before its work arrays are reused
-  if (d->run_pending)
-    {
-      TRY (absorb_run (d));
-      d->run_pending = false;
-    }
   const int L = d->max_len_staged;
   const int per = d->paired ? 2 : 1;
   const char *pe = getenv ("PEMAP_PIPELINE");
@@ -907,6 +902,21 @@ static int run_slice (pemap_dev * d, int first, int n, int sync)
   if ((n + chunk - 1) / chunk > PM_MAX_CHUNKS)
     chunk = (n + PM_MAX_CHUNKS - 1) / PM_MAX_CHUNKS;
   const int nch = (n + chunk - 1) / chunk;
+  // Asynchronous runs queue up behind each other: the chunks of this run continue the pipeline of the pending ones (same
+  // slots, same event chain), so that look-ups of this run's first chunk overlap the previous run's last.  The pending runs
+  // are absorbed first only when the per-chunk bookkeeping would overflow or the geometry changes.
+  int k0 = 0;
+  if (d->run_pending)
+    {
+      const bool same = d->run_split == split && d->run_chunk_pairs == chunk && d->run_L == L && split && !d->serial_split;
+      if (same && d->run_chunks + nch <= PM_MAX_CHUNKS)
+        k0 = d->run_chunks;
+      else
+        {
+          TRY (absorb_run (d));
+          d->run_pending = false;
+        }
+    }
   TRY (ensure_work (d, chunk * per, split));
   TRY (ensure_pipeline (d, chunk * per));
   RunCtx c;
@@ -925,18 +935,23 @@ static int run_slice (pemap_dev * d, int first, int n, int sync)
   c.L = L;
   c.tstride = tstride_for (L);
   c.dump_slab = d->d_dirbuf + (size_t) (chunk * per) * slab_dwords_for (L);
-  memset (&d->last_ctr, 0, sizeof (d->last_ctr));
-  memset (d->last_ms, 0, sizeof (d->last_ms));
-  d->last_big = 0;
+  if (k0 == 0)
+    {
+      memset (&d->last_ctr, 0, sizeof (d->last_ctr));
+      memset (d->last_ms, 0, sizeof (d->last_ms));
+      d->last_big = 0;
+      d->run_ends = 0;
+    }
   d->run_first = first;
   d->run_n = n;
-  d->run_chunks = nch;
+  d->run_ends += (uint64_t) n * per;
+  d->run_chunks = k0 + nch;
   d->run_split = split;
-  HIPCHK (d, hipMemsetAsync (d->d_chunk_ctr, 0, sizeof (PmChunkCtr) * nch, d->stream));
-  hipEvent_t ev_zero = d->ev[0];
-  HIPCHK (d, hipEventRecord (ev_zero, d->stream));
-  if (split)
-    HIPCHK (d, hipStreamWaitEvent (d->stream2, ev_zero, 0));
+  d->run_chunk_pairs = chunk;
+  d->run_L = L;
+  // fresh per-chunk counters: zeroed on the stream that touches them first (the look-up stream in the split pipeline, so
+  // that a queued run's first look-ups do not wait for the previous run's ALU work)
+  HIPCHK (d, hipMemsetAsync (d->d_chunk_ctr + k0, 0, sizeof (PmChunkCtr) * nch, (split && !d->serial_split) ? d->stream2 : d->stream));
   auto batch_of = [&] (int k, PmBatch & bb, int &f, int &m)
   {
     const int off = k * chunk;
@@ -956,11 +971,11 @@ static int run_slice (pemap_dev * d, int first, int n, int sync)
     int f, m;
     RunCtx cl = c;
     batch_of (k, cl.b, f, m);
-    const int slot = k & 1;
-    // the slot's lists must have been consumed by the vote of chunk k-2
-    if (k >= 2)
+    const int g = k0 + k, slot = g & 1;
+    // the slot's lists must have been consumed by the vote of chunk g-2
+    if (g >= 2)
       HIPCHK (d, hipStreamWaitEvent (d->serial_split ? d->stream : d->stream2, d->ev_lists_free[slot], 0));
-    launch_lookup (d, cl, slot, d->d_chunk_ctr + k, &d->evs[(size_t) k * PM_NEV]);
+    launch_lookup (d, cl, slot, d->d_chunk_ctr + g, &d->evs[(size_t) g * PM_NEV]);
     HIPCHK (d, hipEventRecord (d->ev_lists_ready[slot], d->serial_split ? d->stream : d->stream2));
     return 0;
   };
@@ -972,16 +987,16 @@ static int run_slice (pemap_dev * d, int first, int n, int sync)
     {
       int f, m;
       batch_of (k, c.b, f, m);
-      const int slot = k & 1;
-      PmChunkCtr *cc = d->d_chunk_ctr + k;
-      hipEvent_t *ev = &d->evs[(size_t) k * PM_NEV];
+      const int g = k0 + k, slot = g & 1;
+      PmChunkCtr *cc = d->d_chunk_ctr + g;
+      hipEvent_t *ev = &d->evs[(size_t) g * PM_NEV];
       if (split)
         {
           if (d->serial_split)
             TRY (enqueue_lookup (k));
           HIPCHK (d, hipStreamWaitEvent (d->stream, d->ev_lists_ready[slot], 0));
           // this chunk's vote overwrites the array set that walk(k-2) reads
-          if (k >= 2 && !d->serial_split && d->walk_on_mem)
+          if (g >= 2 && !d->serial_split && d->walk_on_mem)
             HIPCHK (d, hipStreamWaitEvent (d->stream, d->ev_walk_done[slot], 0));
         }
       uint32_t *m1 = d->d_m1 + f, *m2 = d->paired ? d->d_m2 + f : nullptr;
@@ -1111,7 +1126,7 @@ extern "C" int pemap_dev_run_stats (pemap_dev * d, uint64_t * s, float *t)
   const PmCounters & c = d->last_ctr;
   if (s)
     {
-      s[0] = (uint64_t) (d->paired ? 2 * d->run_n : d->run_n);
+      s[0] = d->run_ends;
       s[1] = c.positions;
       s[2] = (uint64_t) c.n_tasks_s + c.n_tasks_m;
       s[3] = (uint64_t) c.n_tasks_s + c.n_redo;
