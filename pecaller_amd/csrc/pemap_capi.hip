@@ -65,6 +65,7 @@ struct pemap_dev
   hipEvent_t ev[7];
   // two-stream pipeline: the look-up kernel of chunk k+1 (memory stream) runs beside vote/SW/walk of chunk k
   hipStream_t stream2;
+  int n_cus;
   hipEvent_t ev_lists_ready[2], ev_lists_free[2];
   PmLists lists[2];
   int lists_cap;
@@ -182,6 +183,7 @@ extern "C" int pemap_dev_create (pemap_dev ** out, int device_id)
   { const char *sg = getenv ("PEMAP_SEED_BLOCKS_PER_CU"); d->seed_grid = cus * (sg ? atoi (sg) : 8); }
   { const char *sg = getenv ("PEMAP_SW_WAVES_PER_CU"); d->sw_grid = cus * (sg ? atoi (sg) : 16); }
   d->big_grid = cus * 4;
+  d->n_cus = cus;
   if (hipStreamCreateWithFlags (&d->stream, hipStreamNonBlocking) != hipSuccess)
     {
       delete d;
@@ -686,7 +688,17 @@ static void launch_lookup (pemap_dev * d, const RunCtx & c, int slot, PmChunkCtr
   // the latency-bound vote kernel running beside it keeps its wave slots
   const char *padenv = getenv ("PEMAP_LOOKUP_LDS_PAD_KB");
   const unsigned pad = (padenv ? (unsigned) atoi (padenv) : 20u) * 1024u;    // 5 look-up workgroups per CU (swept: 8..44 KB)
-#define PM_LK(SM) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_lookup_kernel < SM >), dim3 (c.b.n_ends), dim3 (PM_SEED_THREADS), pad, st, c.ix, c.b, c.prm, L)
+  // PEMAP_LOOKUP_WAVES=n (default 8): n persistent one-wave workgroups per CU; 0 = the workgroup-per-end kernel
+  const char *lwenv = getenv ("PEMAP_LOOKUP_WAVES");
+  const int lw = lwenv ? atoi (lwenv) : 8;
+  int lgrid = lw * d->n_cus;
+  if (lgrid > c.b.n_ends)
+    lgrid = c.b.n_ends;
+  const char *lbenv = getenv ("PEMAP_LOOKUP_BATCH");     // look-up rounds (x 64 lanes) a wave keeps in flight: 4, 8 or 16
+  const int lb = lbenv ? atoi (lbenv) : 4;
+#define PM_LKW(SM, B) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_lookup_wave_kernel < SM, B >), dim3 (lgrid), dim3 (64), 0, st, c.ix, c.b, c.prm, L)
+#define PM_LK(SM) do { if (lw > 0 && lb >= 16) PM_LKW (SM, 16); else if (lw > 0 && lb >= 8) PM_LKW (SM, 8); else if (lw > 0) PM_LKW (SM, 4); \
+    else hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_lookup_kernel < SM >), dim3 (c.b.n_ends), dim3 (PM_SEED_THREADS), pad, st, c.ix, c.b, c.prm, L); } while (0)
   switch (seg_template (c.L))
     {
     case 7: PM_LK (7); break;
@@ -696,6 +708,7 @@ static void launch_lookup (pemap_dev * d, const RunCtx & c, int slot, PmChunkCtr
     default: PM_LK (19); break;
     }
 #undef PM_LK
+#undef PM_LKW
   hipEventRecord (ev[1], st);
 }
 
@@ -716,11 +729,13 @@ template < int W > static void launch_chunk (pemap_dev * d, const RunCtx & c, ui
   hipEventRecord (ev[2], d->stream);
   if (split)
     {
+      static const int vote_probe = getenv ("PEMAP_VOTE_PROBE") ? atoi (getenv ("PEMAP_VOTE_PROBE")) : 0;     // timing experiments only
+
       PmLists L = d->lists[slot];
       L.n_big = &cc->n_big;
       L.positions = &cc->positions;
 #define PM_VT(SM) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_vote_kernel < SM >), dim3 (n_ends), dim3 (PM_SEED_THREADS), 0, d->stream, c.ix, c.b, c.prm, \
-                                      H, d->d_tasks_s, d->d_tasks_m, ctr, L)
+                                      H, d->d_tasks_s, d->d_tasks_m, ctr, L, vote_probe)
 #define PM_SEEDL(SM) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_seed_kernel < SM >), dim3 (d->big_grid), dim3 (PM_SEED_THREADS), 0, d->stream, c.ix, c.b, \
                                          c.prm, H, d->d_tasks_s, d->d_tasks_m, ctr, d->d_seed_scratch, 0, L.big_list, L.n_big)
       switch (seg_template (c.L))
@@ -751,6 +766,7 @@ template < int W > static void launch_chunk (pemap_dev * d, const RunCtx & c, ui
         }
 #undef PM_SEED
     }
+  hipLaunchKernelGGL (pm_emit_kernel, dim3 ((n_ends + 255) / 256), dim3 (256), 0, d->stream, c.ix, c.b, H, d->d_tasks_s, d->d_tasks_m, ctr);
   hipEventRecord (ev[3], d->stream);
   hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, true >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, H,
                       d->d_tasks_s, &ctr->n_tasks_s, ctr, dirbuf, dump_slab, c.tstride, c.L);
@@ -835,7 +851,18 @@ static int ensure_pipeline (pemap_dev * d, int chunk_ends)
 {
   if (!d->stream2)
     {
-      HIPCHK (d, hipStreamCreateWithFlags (&d->stream2, hipStreamNonBlocking));
+      // PEMAP_MEM_CUS=n: the look-up stream only runs on n CUs of every XCD (CU-mask bit i is CU i/8 of XCD i%8)
+      const char *mc = getenv ("PEMAP_MEM_CUS");
+      int ncu = mc ? atoi (mc) : 0;
+      if (ncu > 0 && ncu < 32)
+        {
+          uint32_t mask[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+          for (int i = 0; i < ncu * 8; i++)
+            mask[i >> 5] |= 1u << (i & 31);
+          HIPCHK (d, hipExtStreamCreateWithCUMask (&d->stream2, 8, mask));
+        }
+      else
+        HIPCHK (d, hipStreamCreateWithFlags (&d->stream2, hipStreamNonBlocking));
       for (int i = 0; i < 2; i++)
         {
           HIPCHK (d, hipEventCreateWithFlags (&d->ev_lists_ready[i], hipEventDisableTiming));

@@ -87,7 +87,7 @@ __device__ __forceinline__ unsigned pm_bin_hash (uint32_t bin)
 template < class SH, class IdxT >
 __device__ void pm_vote_strand (SH & sh, const uint32_t * ekey, const uint8_t * eseg, uint32_t * bkey, uint8_t * bseg, IdxT * surv, IdxT * order,
                                 uint8_t * tfs, int T, const int *seg_cnt, const int *offsets, int total_cuts, int max_off, int &min_match,
-                                int &tot, bool & go_on, uint8_t strand)
+                                int &tot, bool & go_on, uint8_t strand, int probe = 0)
 {
   constexpr bool LDSP = sizeof (IdxT) == 2;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -144,6 +144,8 @@ __device__ void pm_vote_strand (SH & sh, const uint32_t * ekey, const uint8_t * 
       bseg[pos] = eseg[p];
     }
   pm_barrier < LDSP > ();
+  if (probe == 2)
+    return;
   // ---- tot_found of every anchor the walk can reach: 1 + number of LATER segments holding a position whose diagonal
   //      differs by less than max_off.  An anchor of segment `loop` is only visited while loop <= 1 + max_depth - min_match
   //      (pemapper.c:2216; the bound only shrinks), and only acts if its count reaches min_match (which only grows).
@@ -180,6 +182,8 @@ __device__ void pm_vote_strand (SH & sh, const uint32_t * ekey, const uint8_t * 
         }
     }
   pm_barrier < LDSP > ();
+  if (probe == 3)
+    return;
   const int ns = (int) sh.n_surv;
   // walk order: segment ascending, position ascending inside a segment (same offset, so diagonal ascending)
   for (int sv = tid; sv < ns; sv += PM_SEED_THREADS)
@@ -195,6 +199,8 @@ __device__ void pm_vote_strand (SH & sh, const uint32_t * ekey, const uint8_t * 
       order[rank] = (IdxT) sv;
     }
   pm_barrier < LDSP > ();
+  if (probe == 4)
+    return;
   if (tid < 64)
     {
       bool more = true, done = false;
@@ -206,14 +212,17 @@ __device__ void pm_vote_strand (SH & sh, const uint32_t * ekey, const uint8_t * 
           const int sv = act ? (int) order[i] : 0;
           const int tf = act ? (int) tfs[sv] : 0;
           const int a = act ? (int) surv[sv] : 0;
+          // every lane fetches its own candidate's segment, offset and position up front; the serial part below only shuffles
+          const int my_loop = act ? (int) eseg[a] : 0;
+          const int my_off = offsets[my_loop];
+          const uint32_t my_ml = (act ? ekey[a] : 0u) - (uint32_t) (PM_DIAG_BIAS - my_off);        // the position itself
           unsigned long long cand = __ballot (act && tf >= min_match);
           while (cand)
             {
               const int l = __ffsll ((long long) cand) - 1;
               cand &= cand - 1;
               const int tfl = __shfl (tf, l);
-              const int al = __shfl (a, l);
-              const int loop = eseg[al];
+              const int loop = __shfl (my_loop, l);
               if (loop != cur_loop)
                 {
                   // the walk's loop bound is tested when a segment is entered, not inside it (pemapper.c:2216)
@@ -224,8 +233,8 @@ __device__ void pm_vote_strand (SH & sh, const uint32_t * ekey, const uint8_t * 
                     }
                   cur_loop = loop;
                 }
-              const int off_a = offsets[loop];
-              const uint32_t ml = ekey[al] - (uint32_t) (PM_DIAG_BIAS - off_a);      // the position itself
+              const int off_a = __shfl (my_off, l);
+              const uint32_t ml = __shfl (my_ml, l);
               if (tfl > min_match)
                 {
                   min_match = tfl;
@@ -238,6 +247,7 @@ __device__ void pm_vote_strand (SH & sh, const uint32_t * ekey, const uint8_t * 
                   tot = 1;
                   __builtin_amdgcn_fence (__ATOMIC_SEQ_CST, "wavefront");
                   __builtin_amdgcn_wave_barrier ();
+                  cand &= __ballot (tf >= min_match);     // candidates below the new best would fall through both tests
                 }
               else if (tfl == min_match)
                 {
@@ -285,48 +295,104 @@ __device__ void pm_vote_strand (SH & sh, const uint32_t * ekey, const uint8_t * 
   go_on = sh.state[2] != 0;
 }
 
-// hits -> spots and SW windows (pemapper.c:1664-1669, 1047-1081), task lists.
-// An end with one hit is scored once, with direction nibbles, into its own slab; ends with several hits are scored
-// without, and only the winner is scored again (pm_select_kernel).
-template < class SH > __device__ __forceinline__ void pm_seed_emit (SH & sh, const PmIndex & ix, const PmHits & h, uint32_t * tasks_s,
-                                                                    uint32_t * tasks_m, PmCounters * ctr, int e, int len, int tot)
+// The vote's result for one read-end leaves the workgroup raw: the hit count and, per hit, the matched position, the
+// segment offset it was found with and the strand.  pm_emit_kernel turns them into SW windows and task lists afterwards
+// with one thread per end, so that no workgroup waits on contig look-ups or on the shared task counters.
+template < class SH > __device__ __forceinline__ void pm_seed_emit (SH & sh, const PmHits & h, int e, int tot)
 {
   const int tid = threadIdx.x;
   if (tid == 0)
-    {
-      unsigned tb = 0;
-      h.n_hits[e] = tot;
-      h.slot[e] = (tot == 1) ? (int) atomicAdd (&ctr->n_slots, 1u) : -1;
-      if (tot == 1)
-        tb = atomicAdd (&ctr->n_tasks_s, 1u);
-      else if (tot > 1)
-        tb = atomicAdd (&ctr->n_tasks_m, (unsigned) tot);
-      sh.state[3] = (int) tb;
-    }
-  pm_lds_barrier ();
-  const unsigned tbase = (unsigned) sh.state[3];
-  uint32_t *tasks = (tot == 1) ? tasks_s : tasks_m;
+    h.n_hits[e] = tot;
   for (int t = tid; t < tot; t += PM_SEED_THREADS)
     {
-      long temp = (long) sh.hits[t] - (long) sh.hits_off[t];
-      uint32_t spot = (uint32_t) (temp > 0 ? temp : 0);
-      int chrom = pm_find_chrom (ix.contig_starts, ix.n_contigs, spot);
-      unsigned extra = 15u * (unsigned) chrom;
-      long tt = (long) extra + (long) spot - (long) PM_SLOP;
-      if (tt < 0)
-        tt = 0;
-      unsigned cs0 = ix.contig_starts[chrom] + extra;
-      unsigned start_match = ((long) cs0 > tt) ? cs0 : (unsigned) tt;
-      unsigned e1 = ix.contig_starts[chrom + 1] + extra;
-      unsigned e2w = extra + spot + (unsigned) len + PM_SLOP;
-      unsigned end_match = e1 < e2w ? e1 : e2w;
-      int blen = (int) (1u + end_match - start_match);
-      size_t o = (size_t) e * PM_MAX_HITS + t;
-      h.spot[o] = spot;
+      const size_t o = (size_t) e * PM_MAX_HITS + t;
+      h.spot[o] = sh.hits[t];
+      h.nn[o] = (int16_t) sh.hits_off[t];
       h.orient[o] = sh.hits_or[t];
-      h.gpos[o] = start_match;
-      h.nn[o] = (int16_t) blen;
-      tasks[tbase + t] = (uint32_t) o;
+    }
+}
+
+// hit -> spot and SW window (pemapper.c:1664-1669, 1047-1081), in place
+__device__ __forceinline__ void pm_emit_hit (const PmIndex & ix, const PmHits & h, size_t o, int len)
+{
+  long temp = (long) h.spot[o] - (long) h.nn[o];
+  uint32_t spot = (uint32_t) (temp > 0 ? temp : 0);
+  int chrom = pm_find_chrom (ix.contig_starts, ix.n_contigs, spot);
+  unsigned extra = 15u * (unsigned) chrom;
+  long tt = (long) extra + (long) spot - (long) PM_SLOP;
+  if (tt < 0)
+    tt = 0;
+  unsigned cs0 = ix.contig_starts[chrom] + extra;
+  unsigned start_match = ((long) cs0 > tt) ? cs0 : (unsigned) tt;
+  unsigned e1 = ix.contig_starts[chrom + 1] + extra;
+  unsigned e2w = extra + spot + (unsigned) len + PM_SLOP;
+  unsigned end_match = e1 < e2w ? e1 : e2w;
+  int blen = (int) (1u + end_match - start_match);
+  h.spot[o] = spot;
+  h.gpos[o] = start_match;
+  h.nn[o] = (int16_t) blen;
+}
+
+// One thread per read-end.  An end with one hit is scored once, with direction nibbles, into its own slab; ends with
+// several hits are scored without, and only the winner is scored again (pm_select_kernel).  Slab numbers and task-list
+// ranges are handed out with one atomic per wave.
+__global__ __launch_bounds__ (256) void pm_emit_kernel (PmIndex ix, PmBatch b, PmHits h, uint32_t * tasks_s, uint32_t * tasks_m, PmCounters * ctr)
+{
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int tot = e < b.n_ends ? h.n_hits[e] : 0;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  // ---- single hits
+  const unsigned long long ms = __ballot (tot == 1);
+  unsigned slot0 = 0, task0 = 0;
+  if (ms)
+    {
+      if (lane == 0)
+        {
+          slot0 = atomicAdd (&ctr->n_slots, (unsigned) __popcll (ms));
+          task0 = atomicAdd (&ctr->n_tasks_s, (unsigned) __popcll (ms));
+        }
+      slot0 = __shfl (slot0, 0);
+      task0 = __shfl (task0, 0);
+    }
+  // ---- several hits: exclusive prefix of the counts inside the wave
+  const unsigned mine = tot > 1 ? (unsigned) tot : 0u;
+  unsigned inc = mine;
+  for (int o = 1; o < 64; o <<= 1)
+    {
+      const unsigned t = __shfl_up (inc, o);
+      if (lane >= o)
+        inc += t;
+    }
+  const unsigned wave_total = __shfl (inc, 63);
+  unsigned mbase = 0;
+  if (wave_total)
+    {
+      if (lane == 0)
+        mbase = atomicAdd (&ctr->n_tasks_m, wave_total);
+      mbase = __shfl (mbase, 0);
+    }
+  if (e >= b.n_ends)
+    return;
+  int len;
+  (void) pm_read_ptr (b, e, &len);
+  const size_t o0 = (size_t) e * PM_MAX_HITS;
+  if (tot == 1)
+    {
+      const unsigned r = (unsigned) __popcll (ms & below);
+      h.slot[e] = (int) (slot0 + r);
+      pm_emit_hit (ix, h, o0, len);
+      tasks_s[task0 + r] = (uint32_t) o0;
+    }
+  else
+    {
+      h.slot[e] = -1;
+      const unsigned tb = mbase + inc - mine;
+      for (int t = 0; t < tot; t++)
+        {
+          pm_emit_hit (ix, h, o0 + t, len);
+          tasks_m[tb + t] = (uint32_t) (o0 + t);
+        }
     }
 }
 
@@ -598,6 +664,7 @@ template < int SMAX > __global__ __launch_bounds__ (PM_SEED_THREADS, 4) void pm_
                 go_on = false;
             }
         }
-      pm_seed_emit (sh, ix, h, tasks_s, tasks_m, ctr, e, len, tot);
+      pm_lds_barrier ();
+      pm_seed_emit (sh, h, e, tot);
     }
 }

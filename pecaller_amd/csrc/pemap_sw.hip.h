@@ -83,45 +83,83 @@ struct PmBumpK
 
 // acc = 2 * acc + (a > b): the compare writes a lane mask to an SGPR pair and v_addc_co_u32 shifts it in as the carry --
 // two instructions per stored comparison instead of compare + select + shift/or.
-__device__ __forceinline__ void pm_push_gt (uint32_t & acc, double a, double b)
+__device__ __forceinline__ unsigned long long pm_gt (double a, double b)
 {
-  const unsigned long long m = __builtin_amdgcn_fcmp (a, b, 2);  // FCMP_OGT
+  return __builtin_amdgcn_fcmp (a, b, 2);       // FCMP_OGT
+}
+
+__device__ __forceinline__ void pm_push (uint32_t & acc, unsigned long long m)
+{
   unsigned long long carry_out;
   asm ("v_addc_co_u32 %0, %1, %0, %0, %2":"+v" (acc), "=s" (carry_out):"s" (m));
 }
 
-// one DP cell; after unrolling all state lives in registers
-template < bool DIRS > __device__ __forceinline__ void pm_cell (double &dg, double &s2, double &U1c, double &Dc, uint32_t mword, const int bit,
-                                                                const PmBumpK & bk, uint32_t & dword, double &o0, double &o1, double &o2)
+// bonus = match ? 1.0 : -1/3, assembled from bit `bit` of the lane's match mask: v_bfe_i32 (0 / -1) and two v_bfi_b32
+__device__ __forceinline__ double pm_bump (uint32_t mword, const int bit, const PmBumpK & bk)
 {
-  // bonus = match ? 1.0 : -1/3, assembled from the mask bit: v_bfe_i32 (0 / -1) and two v_bfi_b32
   int t;
   uint32_t hi, lo;
   asm ("v_bfe_i32 %0, %1, %2, 1":"=v" (t):"v" (mword), "n" (bit));
   asm ("v_bfi_b32 %0, %1, %2, %3":"=v" (hi):"v" (t), "v" (bk.hi_match), "v" (bk.hi_miss));
   asm ("v_bfi_b32 %0, %1, 0, %2":"=v" (lo):"v" (t), "v" (bk.lo_miss));
-  const double bump = __hiloint2double ((int) hi, (int) lo);
+  return __hiloint2double ((int) hi, (int) lo);
+}
+
+// One DP cell; after unrolling all state lives in registers.  s0 = S0 of this cell (diagonal + bonus) comes in already
+// added: the caller forms the NEXT cell's s0 from the old Dc before this cell overwrites it, and every read of an old
+// value precedes the write of the new one, so no register copies are needed.
+template < bool DIRS > __device__ __forceinline__ void pm_cell (const double s0, double &s2, double &U1c, double &Dc, uint32_t & dword)
+{
   const double s1 = U1c;
-  const double s0 = dg + bump;
-  dg = Dc;
   const double a0 = s0 - PM_GO;
   const double x1 = s1 - PM_GE;
   const double x2 = s2 - PM_GE;
   const double m01 = pm_max (s0, s1);
-  U1c = pm_max (a0, x1);
-  Dc = pm_max (m01, s2);
+  unsigned long long k3 = 0, k2 = 0, k1 = 0, k0 = 0;
   if (DIRS)
     {
       // nibble, most significant bit first: S2-ge > S0-go, S1-ge > S0-go, S2 > max(S0,S1), S1 > S0
-      pm_push_gt (dword, x2, a0);
-      pm_push_gt (dword, x1, a0);
-      pm_push_gt (dword, s2, m01);
-      pm_push_gt (dword, s1, s0);
+      k3 = pm_gt (x2, a0);
+      k2 = pm_gt (x1, a0);
+      k1 = pm_gt (s2, m01);
+      k0 = pm_gt (s1, s0);
     }
-  o0 = s0;
-  o1 = s1;
-  o2 = s2;
+  Dc = pm_max (m01, s2);
+  U1c = pm_max (a0, x1);
   s2 = pm_max (a0, x2);
+  if (DIRS)
+    {
+      pm_push (dword, k3);
+      pm_push (dword, k2);
+      pm_push (dword, k1);
+      pm_push (dword, k0);
+    }
+}
+
+// value of lane - 1 (row_shr:1 inside rows of 16 lanes; the first lane of a row reads 0).  The first lane of every
+// 8-lane alignment group overrides what it receives, so the row boundary never shows.
+__device__ __forceinline__ uint32_t pm_from_left (uint32_t v)
+{
+  return (uint32_t) __builtin_amdgcn_update_dpp (0, (int) v, 0x111, 0xF, 0xF, true);
+}
+
+__device__ __forceinline__ double pm_from_left (double v)
+{
+  const uint32_t lo = pm_from_left ((uint32_t) __double2loint (v)), hi = pm_from_left ((uint32_t) __double2hiint (v));
+  return __hiloint2double ((int) hi, (int) lo);
+}
+
+typedef uint64_t pm_u64_unaligned __attribute__ ((aligned (1)));
+
+// reference bytes 8 k .. 8 k + 7 of a window of nn bytes, byte 8 k in the low byte; bytes past the window read as 0
+__device__ __forceinline__ uint64_t pm_ref_chunk (const uint8_t * ref, int nn, int k)
+{
+  const int s = 8 * k;
+  const int last = nn > 8 ? nn - 8 : 0;
+  const int sc = s < last ? s : last;
+  const uint64_t v = *(const pm_u64_unaligned *) (ref + sc);
+  const int shift = s - sc;
+  return shift >= 8 ? 0ull : (v >> (8 * shift));
 }
 
 template < int W > struct PmSwGeom
@@ -236,34 +274,56 @@ __device__ __forceinline__ void pm_sw_forward (const PmSwTask & tk, int bis, int
   double bst = pm_border (mm);     // S[0][0][mm], pemapper.c:1701-1703
   int k_b = 0, i_b = 0;
   const int nn1 = nn > 0 ? nn - 1 : 0;
-  uint8_t r_next = tk.ref[0];
+  // The reference byte of row i is needed by lane g at step i + g: it enters at lane 0 of the group and moves one lane
+  // per step with the DP values.  Lane 0 takes it from an 8-byte chunk loaded 8 steps ahead.
+  uint32_t r_last = 0;
+  uint64_t rw = 0, rw_next = pm_ref_chunk (tk.ref, nn, 0);
 
   for (int t = 1; t <= nn_max + PM_LPA - 1; t++)
     {
       const int i = t - g;
-      double R2in = __shfl_up (R2out, 1, PM_LPA);
-      double Dimp = __shfl_up (Dout, 1, PM_LPA);
+      double R2in = pm_from_left (R2out);
+      double Dimp = pm_from_left (Dout);
+      const uint32_t r_in = pm_from_left (r_last);
+      if (((t - 1) & 7) == 0)
+        {
+          rw = rw_next;
+          rw_next = pm_ref_chunk (tk.ref, nn, ((t - 1) >> 3) + 1);
+        }
+      const uint32_t r = (g == 0) ? ((uint32_t) rw & 0xFFu) : r_in;
+      rw >>= 8;
+      r_last = r;
       R2in = (g == 0) ? R2in0 : R2in;
       Dimp = (g == 0) ? Dimp0 : Dimp;
       const bool act = (i >= 1) && (i <= nn);
-      const uint8_t r = r_next;
-      r_next = tk.ref[min (max (i, 0), nn1)];      // next step's reference byte (row i + 1), clamped into the window
       if (act)
         {
           uint64_t msel = (r == 'A') ? mk[0] : (r == 'C') ? mk[1] : (r == 'G') ? mk[2] : (r == 'T') ? mk[3] : mk[4];
           if (__builtin_expect (r != 'A' && r != 'C' && r != 'G' && r != 'T' && r != 'N', 0))
-            msel = pm_slow_mask < W > (tk.read, mm, tk.orient, g, pad, r, bis);
+            msel = pm_slow_mask < W > (tk.read, mm, tk.orient, g, pad, (uint8_t) r, bis);
           const uint32_t m0 = (uint32_t) msel, m1 = (uint32_t) (msel >> 32);
-          double dg = Dprev;
           double s2 = R2in;
           uint32_t dw[DW];
 #pragma unroll
           for (int d = 0; d < DW; d++)
             dw[d] = 0;
           double o0 = 0.0, o1 = 0.0, o2 = 0.0;
+          double s0 = Dprev + pm_bump (m0, 0, bumpk);
 #pragma unroll
           for (int c = 0; c < W; c++)
-            pm_cell < DIRS > (dg, s2, U1[c], D[c], (c < 32) ? m0 : m1, c & 31, bumpk, dw[c >> 3], o0, o1, o2);
+            {
+              double s0n = 0.0;
+              if (c + 1 < W)
+                s0n = D[c] + pm_bump ((c + 1 < 32) ? m0 : m1, (c + 1) & 31, bumpk);   // the old D[c] is the next cell's diagonal
+              if (c == W - 1)
+                {
+                  o0 = s0;
+                  o1 = U1[c];
+                  o2 = s2;
+                }
+              pm_cell < DIRS > (s0, s2, U1[c], D[c], dw[c >> 3]);
+              s0 = s0n;
+            }
           // The last column of lane 7 is read column mm: rows ascending, planes 0,1,2, strict '>' (pemapper.c:1724-1741).
           // Every lane runs the selects (no branch); only lane 7's result is read.
           const bool u0 = o0 > bst;
