@@ -199,9 +199,12 @@ def main():
         launch_ms = avg_ms[dom] / launches
         alg_bytes = per_end[dom] * (ends / a.steps) / launches
         achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
-        traffic, tsrc = pmc_traffic("pm_%s_kernel" % dom, gs, B, L)
+        kname = "pm_%s_kernel" % dom
+        if dom == "lookup" and os.environ.get("PEMAP_LOOKUP_WAVES", "6") != "0":
+            kname = "pm_lookup_wave_kernel"     # the persistent wave-per-end form of the look-up kernel (default)
+        traffic, tsrc = pmc_traffic(kname, gs, B, L)
         total_b = algorithmic_bytes_per_end(L, P_e, H_e)
-        roof = {"bound": "hbm", "kernel": "pm_%s_kernel" % dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roof = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc,
                 "launches_per_step": launches, "avg_launch_ms": round(launch_ms, 3), "algorithmic_bytes_per_launch": round(alg_bytes),
                 "kernel_ms": {k: round(v, 3) for k, v in avg_ms.items()},

@@ -511,10 +511,10 @@ static int ensure_reads (pemap_dev * d, int n, int stride, int paired)
   return 0;
 }
 
-// W columns per lane: the smallest instantiation with 8 * W >= the longest staged read
+// W columns per lane: the smallest instantiation with PM_LPA * W >= the longest staged read
 static int pick_w (int L)
 {
-  return L <= 8 * 13 ? 13 : L <= 8 * 19 ? 19 : L <= 8 * 26 ? 26 : L <= 8 * 32 ? 32 : 38;
+  return L <= PM_LPA * 13 ? 13 : L <= PM_LPA * 19 ? 19 : L <= PM_LPA * 26 ? 26 : L <= PM_LPA * 32 ? 32 : 38;
 }
 
 // rows of one lane's region in a direction slab: window rows + the 7 skew steps, rounded up to the 16-step flush unit
@@ -688,9 +688,9 @@ static void launch_lookup (pemap_dev * d, const RunCtx & c, int slot, PmChunkCtr
   // the latency-bound vote kernel running beside it keeps its wave slots
   const char *padenv = getenv ("PEMAP_LOOKUP_LDS_PAD_KB");
   const unsigned pad = (padenv ? (unsigned) atoi (padenv) : 20u) * 1024u;    // 5 look-up workgroups per CU (swept: 8..44 KB)
-  // PEMAP_LOOKUP_WAVES=n (default 8): n persistent one-wave workgroups per CU; 0 = the workgroup-per-end kernel
+  // PEMAP_LOOKUP_WAVES=n (default 6, swept 2..24): n persistent one-wave workgroups per CU; 0 = the workgroup-per-end kernel
   const char *lwenv = getenv ("PEMAP_LOOKUP_WAVES");
-  const int lw = lwenv ? atoi (lwenv) : 8;
+  const int lw = lwenv ? atoi (lwenv) : 6;
   int lgrid = lw * d->n_cus;
   if (lgrid > c.b.n_ends)
     lgrid = c.b.n_ends;

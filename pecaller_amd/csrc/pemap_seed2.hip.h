@@ -231,7 +231,6 @@ template < int SMAX, int PM_LW_BATCH > __global__ __launch_bounds__ (64) void pm
 {
   typedef PmLookupWaveShared < SMAX > SH;
   __shared__ SH sh;
-  constexpr int NI = (SH::NITEMS + 63) / 64;
   const int lane = threadIdx.x;
   const int idepth = ix.idepth;
   const uint32_t pos_index_0 = ix.pos_index[0];

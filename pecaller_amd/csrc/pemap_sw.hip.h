@@ -190,12 +190,14 @@ template < int W > __device__ __noinline__ uint64_t pm_slow_mask (const uint8_t 
 // bytes each and each of them reaches HBM as its own partial-line write.  Instead PM_STAGE steps are collected in LDS
 // ([lane][step][DW]) and flushed with 16-byte-per-lane stores in which 4 (or more) adjacent lanes cover one lane's
 // chunk, i.e. whole 64-byte lines (chunks are 64-byte multiples because tstride is a multiple of 16).
-#define PM_STAGE 16
+// steps collected per flush: the smallest count that makes a lane's chunk a whole number of 64-byte lines
+#define PM_STAGE_OF(DW) ((DW) == 2 ? 8 : 16)
 
 template < int W > __device__ __forceinline__ void pm_flush_dirs (const uint32_t * stage, uint32_t * const *slab_of_group, int lane, int tstride,
                                                                   int t0)
 {
   constexpr int DW = PmSwGeom < W >::DW;
+  constexpr int PM_STAGE = PM_STAGE_OF (DW);
   constexpr int CHUNK = PM_STAGE * DW;            // dwords one lane owns per flush
   constexpr int NINSTR = (64 * CHUNK) / (64 * 4);   // 16-byte stores per lane
 #pragma unroll 2
@@ -204,7 +206,7 @@ template < int W > __device__ __forceinline__ void pm_flush_dirs (const uint32_t
       const int o = (k * 64 + lane) * 4;          // dword offset in the staged [64][CHUNK] image
       const int L = o / CHUNK, within = o - L * CHUNK;
       const uint4 v = *(const uint4 *) (stage + o);
-      uint32_t *dst = slab_of_group[L >> 3] + ((size_t) (L & 7) * tstride + t0) * DW + within;
+      uint32_t *dst = slab_of_group[L / PM_LPA] + ((size_t) (L % PM_LPA) * tstride + t0) * DW + within;
       *(uint4 *) dst = v;
     }
 }
@@ -214,6 +216,7 @@ __device__ __forceinline__ void pm_sw_forward (const PmSwTask & tk, int bis, int
                                                uint32_t * const *slab_of_group, int tstride, double &best, int &bk, int &bi)
 {
   constexpr int DW = PmSwGeom < W >::DW;
+  constexpr int PM_STAGE = PM_STAGE_OF (DW);
   int g = lane & (PM_LPA - 1);
   // opaque to the optimiser: otherwise the 2 W border doubles below are computed once per kernel, kept live across the
   // persistent task loop and double the register footprint
@@ -273,7 +276,6 @@ __device__ __forceinline__ void pm_sw_forward (const PmSwTask & tk, int bis, int
   double R2out = 0.0, Dout = 0.0;
   double bst = pm_border (mm);     // S[0][0][mm], pemapper.c:1701-1703
   int k_b = 0, i_b = 0;
-  const int nn1 = nn > 0 ? nn - 1 : 0;
   // The reference byte of row i is needed by lane g at step i + g: it enters at lane 0 of the group and moves one lane
   // per step with the DP values.  Lane 0 takes it from an 8-byte chunk loaded 8 steps ahead.
   uint32_t r_last = 0;
@@ -380,7 +382,7 @@ __device__ __forceinline__ int pm_wave_max (int v)
   return v;
 }
 
-// One persistent wave per 8 problems.  DIRS: the problems are traceable alignments (the only hit of an end, or the winner
+// One persistent wave per 64 / PM_LPA problems.  DIRS: the problems are traceable alignments (the only hit of an end, or the winner
 // of a multi-hit end) and write their nibbles to the end's slab.
 template < int W, bool DIRS > __global__ __launch_bounds__ (64, PM_WAVES_PER_EU (W)) void pm_sw_kernel (PmIndex ix, PmBatch b, PmParams prm, PmHits h,
                                                                                               const uint32_t * tasks,
@@ -388,13 +390,14 @@ template < int W, bool DIRS > __global__ __launch_bounds__ (64, PM_WAVES_PER_EU 
                                                                                               uint32_t * dirbuf, uint32_t * dump_slab, int tstride,
                                                                                               int mm_fill)
 {
-  __shared__ uint32_t stage[DIRS ? 64 * PM_STAGE * PmSwGeom < W >::DW : 4];
-  __shared__ uint32_t *slab_of_group[8];
+  constexpr int TPW = 64 / PM_LPA;        // tasks per wave
+  __shared__ uint32_t stage[DIRS ? 64 * PM_STAGE_OF (PmSwGeom < W >::DW) * PmSwGeom < W >::DW : 4];
+  __shared__ uint32_t *slab_of_group[TPW];
   const int lane = threadIdx.x;
-  const int q = lane >> 3;
+  const int q = lane / PM_LPA;
   const unsigned n_tasks = *n_tasks_p;
   const size_t slab_dwords = (size_t) PM_LPA * tstride * PmSwGeom < W >::DW;
-  for (unsigned base = blockIdx.x * 8u; base < n_tasks; base += gridDim.x * 8u)
+  for (unsigned base = blockIdx.x * (unsigned) TPW; base < n_tasks; base += gridDim.x * (unsigned) TPW)
     {
       __builtin_amdgcn_fence (__ATOMIC_SEQ_CST, "wavefront");
       __builtin_amdgcn_wave_barrier ();
@@ -424,7 +427,7 @@ template < int W, bool DIRS > __global__ __launch_bounds__ (64, PM_WAVES_PER_EU 
         {
           // groups without a task flush into the wave's last slab region that is valid: point them at group 0's slab
           // rows beyond the window (never read); simpler: give them the dump slab at the end of the direction buffer
-          if ((lane & 7) == 0)
+          if ((lane & (PM_LPA - 1)) == 0)
             slab_of_group[q] = tk.valid ? slab : dump_slab;
           __builtin_amdgcn_fence (__ATOMIC_SEQ_CST, "wavefront");
           __builtin_amdgcn_wave_barrier ();
@@ -433,7 +436,7 @@ template < int W, bool DIRS > __global__ __launch_bounds__ (64, PM_WAVES_PER_EU 
       double best;
       int bk, bi;
       pm_sw_forward < W, DIRS > (tk, prm.bisulfite, lane, nn_max, stage, slab_of_group, tstride, best, bk, bi);
-      if (tk.valid && (lane & 7) == 0)
+      if (tk.valid && (lane & (PM_LPA - 1)) == 0)
         {
           h.score[o] = best;
           h.stk[o] = (uint8_t) bk;

@@ -1,0 +1,18 @@
+#!/bin/bash
+# rocprofv3 passes behind profiles/: kernel-trace stats, then FETCH_SIZE and WRITE_SIZE in separate --pmc runs.
+# Run on the GPU box from the repo root:  tools/profile.sh <tag>   ->  gpurun_out/prof_<tag>/{stats.csv,pmc.json}
+set -e
+TAG=${1:-r01}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu > $OUT/stats.log 2>&1
+echo "stats pass done"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu > $OUT/fetch.log 2>&1
+echo "FETCH_SIZE pass done"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu > $OUT/write.log 2>&1
+echo "WRITE_SIZE pass done"
+cd $ROOT
+python3 tools/pmc_summary.py $OUT
+tail -1 $OUT/stats.log | cut -c1-400
