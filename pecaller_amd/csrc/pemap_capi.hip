@@ -41,6 +41,8 @@ struct pemap_dev
   int cap_ends;
   PmHits hits;
   uint32_t *d_tasks_s, *d_tasks_m, *d_redo, *d_wins;
+  uint32_t *d_tasks_s2, *d_tasks_m2;      // second set: the vote of the next chunk runs beside the SW of this one
+  bool vote_on_mem;
   // second set of the arrays the walk kernel reads, so that walk(chunk k) can run beside vote/SW(chunk k+1)
   PmHits hits2;
   uint32_t *d_wins2, *d_dirbuf2;
@@ -140,6 +142,8 @@ extern "C" int pemap_dev_create (pemap_dev ** out, int device_id)
   memset (&d->hits2, 0, sizeof (d->hits2));
   d->d_wins2 = d->d_dirbuf2 = nullptr;
   d->d_tasks_s = d->d_tasks_m = d->d_redo = d->d_wins = d->d_m1 = d->d_m2 = nullptr;
+  d->d_tasks_s2 = d->d_tasks_m2 = nullptr;
+  d->vote_on_mem = false;
   d->d_cur = nullptr;
   d->dirbuf_dwords = 0;
   memset (&d->last_cur, 0, sizeof (d->last_cur));
@@ -236,6 +240,9 @@ static void free_work (pemap_dev * d)
   free_hits (d->hits2);
   hipFree (d->d_tasks_s);
   hipFree (d->d_tasks_m);
+  hipFree (d->d_tasks_s2);
+  hipFree (d->d_tasks_m2);
+  d->d_tasks_s2 = d->d_tasks_m2 = nullptr;
   hipFree (d->d_redo);
   hipFree (d->d_wins);
   hipFree (d->d_wins2);
@@ -566,6 +573,8 @@ static int ensure_work (pemap_dev * d, int n_ends, bool two_sets)
         {
           TRY (alloc_hits (d, d->hits2, n_ends));
           TRY (dev_alloc (d, &d->d_wins2, (size_t) n_ends));
+          TRY (dev_alloc (d, &d->d_tasks_s2, (size_t) n_ends));
+          TRY (dev_alloc (d, &d->d_tasks_m2, nh));
         }
       TRY (dev_alloc (d, &d->d_tasks_s, (size_t) n_ends));
       TRY (dev_alloc (d, &d->d_tasks_m, nh));
@@ -712,32 +721,28 @@ static void launch_lookup (pemap_dev * d, const RunCtx & c, int slot, PmChunkCtr
   hipEventRecord (ev[1], st);
 }
 
-// ---- the ALU stream's work for one chunk.  split: the seed stage is vote + list-mode remainder on lists made by
-//      launch_lookup; otherwise the monolithic seed kernel does everything.
-template < int W > static void launch_chunk (pemap_dev * d, const RunCtx & c, uint32_t * m1, uint32_t * m2, int *mt, bool split, int slot,
-                                             PmChunkCtr * cc, hipEvent_t * ev)
+// ---- the seed stage after the look-ups, on stream `st`: vote + list-mode remainder on the slot's lists (split), or the
+//      monolithic seed kernel; then the emit kernel (windows, slab numbers, SW task lists).
+static void launch_vote (pemap_dev * d, const RunCtx & c, bool split, int slot, PmChunkCtr * cc, hipEvent_t * ev, hipStream_t st)
 {
-  // the arrays the walk reads alternate between two sets in the split pipeline
-  const PmHits & H = (split && slot) ? d->hits2 : d->hits;
-  uint32_t *wins = (split && slot) ? d->d_wins2 : d->d_wins;
-  uint32_t *dirbuf = (split && slot) ? d->d_dirbuf2 : d->d_dirbuf;
-  uint32_t *dump_slab = dirbuf + (c.dump_slab - d->d_dirbuf);
+  const bool set2 = split && slot;
+  const PmHits & H = set2 ? d->hits2 : d->hits;
+  uint32_t *tasks_s = set2 ? d->d_tasks_s2 : d->d_tasks_s, *tasks_m = set2 ? d->d_tasks_m2 : d->d_tasks_m;
   const int n_ends = c.b.n_ends;
   PmCounters *ctr = &cc->c;
   const char *pl = getenv ("PEMAP_SEED_PHASE");      // timing probe only: results are meaningless when set
   const int phase_limit = pl ? atoi (pl) : 0;
-  hipEventRecord (ev[2], d->stream);
+  hipEventRecord (ev[2], st);
   if (split)
     {
       static const int vote_probe = getenv ("PEMAP_VOTE_PROBE") ? atoi (getenv ("PEMAP_VOTE_PROBE")) : 0;     // timing experiments only
-
       PmLists L = d->lists[slot];
       L.n_big = &cc->n_big;
       L.positions = &cc->positions;
-#define PM_VT(SM) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_vote_kernel < SM >), dim3 (n_ends), dim3 (PM_SEED_THREADS), 0, d->stream, c.ix, c.b, c.prm, \
-                                      H, d->d_tasks_s, d->d_tasks_m, ctr, L, vote_probe)
-#define PM_SEEDL(SM) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_seed_kernel < SM >), dim3 (d->big_grid), dim3 (PM_SEED_THREADS), 0, d->stream, c.ix, c.b, \
-                                         c.prm, H, d->d_tasks_s, d->d_tasks_m, ctr, d->d_seed_scratch, 0, L.big_list, L.n_big)
+#define PM_VT(SM) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_vote_kernel < SM >), dim3 (n_ends), dim3 (PM_SEED_THREADS), 0, st, c.ix, c.b, c.prm, \
+                                      H, tasks_s, tasks_m, ctr, L, vote_probe)
+#define PM_SEEDL(SM) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_seed_kernel < SM >), dim3 (d->big_grid), dim3 (PM_SEED_THREADS), 0, st, c.ix, c.b, \
+                                         c.prm, H, tasks_s, tasks_m, ctr, d->d_seed_scratch, 0, L.big_list, L.n_big)
       switch (seg_template (c.L))
         {
         case 7: PM_VT (7); PM_SEEDL (7); break;
@@ -748,13 +753,13 @@ template < int W > static void launch_chunk (pemap_dev * d, const RunCtx & c, ui
         }
 #undef PM_VT
 #undef PM_SEEDL
-      hipEventRecord (d->ev_lists_free[slot], d->stream);      // the slot's lists are consumed
+      hipEventRecord (d->ev_lists_free[slot], st);      // the slot's lists are consumed
     }
   else
     {
       int sgrid = d->seed_grid < n_ends ? d->seed_grid : n_ends;
-#define PM_SEED(SM) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_seed_kernel < SM >), dim3 (sgrid), dim3 (PM_SEED_THREADS), 0, d->stream, c.ix, c.b, c.prm, \
-                                        H, d->d_tasks_s, d->d_tasks_m, ctr, d->d_seed_scratch, phase_limit, (const uint32_t *) nullptr, \
+#define PM_SEED(SM) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_seed_kernel < SM >), dim3 (sgrid), dim3 (PM_SEED_THREADS), 0, st, c.ix, c.b, c.prm, \
+                                        H, tasks_s, tasks_m, ctr, d->d_seed_scratch, phase_limit, (const uint32_t *) nullptr, \
                                         (const unsigned *) nullptr)
       switch (seg_template (c.L))
         {
@@ -766,13 +771,30 @@ template < int W > static void launch_chunk (pemap_dev * d, const RunCtx & c, ui
         }
 #undef PM_SEED
     }
-  hipLaunchKernelGGL (pm_emit_kernel, dim3 ((n_ends + 255) / 256), dim3 (256), 0, d->stream, c.ix, c.b, H, d->d_tasks_s, d->d_tasks_m, ctr);
-  hipEventRecord (ev[3], d->stream);
+  hipLaunchKernelGGL (pm_emit_kernel, dim3 ((n_ends + 255) / 256), dim3 (256), 0, st, c.ix, c.b, H, tasks_s, tasks_m, ctr);
+  hipEventRecord (ev[3], st);
+}
+
+// ---- the ALU stream's work for one chunk: (the seed stage unless it ran on the memory stream,) SW, selection, traceback.
+template < int W > static void launch_chunk (pemap_dev * d, const RunCtx & c, uint32_t * m1, uint32_t * m2, int *mt, bool split, int slot,
+                                             PmChunkCtr * cc, hipEvent_t * ev)
+{
+  // the arrays the walk reads alternate between two sets in the split pipeline
+  const bool set2 = split && slot;
+  const PmHits & H = set2 ? d->hits2 : d->hits;
+  uint32_t *wins = set2 ? d->d_wins2 : d->d_wins;
+  uint32_t *dirbuf = set2 ? d->d_dirbuf2 : d->d_dirbuf;
+  uint32_t *tasks_s = set2 ? d->d_tasks_s2 : d->d_tasks_s, *tasks_m = set2 ? d->d_tasks_m2 : d->d_tasks_m;
+  uint32_t *dump_slab = dirbuf + (c.dump_slab - d->d_dirbuf);
+  const int n_ends = c.b.n_ends;
+  PmCounters *ctr = &cc->c;
+  if (!(split && d->vote_on_mem))
+    launch_vote (d, c, split, slot, cc, ev, d->stream);
   hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, true >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, H,
-                      d->d_tasks_s, &ctr->n_tasks_s, ctr, dirbuf, dump_slab, c.tstride, c.L);
+                      tasks_s, &ctr->n_tasks_s, ctr, dirbuf, dump_slab, c.tstride, c.L);
   hipEventRecord (ev[4], d->stream);
   hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, false >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, H,
-                      d->d_tasks_m, &ctr->n_tasks_m, ctr, dirbuf, dump_slab, c.tstride, c.L);
+                      tasks_m, &ctr->n_tasks_m, ctr, dirbuf, dump_slab, c.tstride, c.L);
   hipEventRecord (ev[5], d->stream);
   hipLaunchKernelGGL (pm_select_kernel, dim3 ((c.b.n + 255) / 256), dim3 (256), 0, d->stream, c.b, c.prm, H, d->d_redo, wins, ctr,
                       m1, m2, mt);
@@ -796,7 +818,7 @@ template < int W > static void launch_chunk (pemap_dev * d, const RunCtx & c, ui
   hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_walk_kernel < W >), dim3 (wgrid), dim3 (256), 0, ws, c.b, H, wins, ctr, d->d_cur,
                       dirbuf, c.tstride, d->d_counts, d->d_ins_log, d->ins_cap);
   hipEventRecord (ev[8], ws);
-  if (ws != d->stream)
+  if (split)
     hipEventRecord (d->ev_walk_done[slot], ws);
 }
 
@@ -912,6 +934,8 @@ static int run_slice (pemap_dev * d, int first, int n, int sync)
   const bool split = !(pe && atoi (pe) == 0) && !getenv ("PEMAP_SEED_PHASE");
   d->serial_split = pe && atoi (pe) == 2;
   { const char *we = getenv ("PEMAP_WALK_ON_MEM_STREAM"); d->walk_on_mem = we && atoi (we) != 0; }
+  // PEMAP_VOTE_ON_MEM=1: the vote runs behind its look-ups on the memory stream, beside the SW / walk of the previous chunk
+  { const char *ve = getenv ("PEMAP_VOTE_ON_MEM"); d->vote_on_mem = split && !d->serial_split && ve && atoi (ve) != 0; }
   // chunk: one direction slab per read-end must fit the budget; the two-stream pipeline wants several chunks per run
   size_t slab_bytes = slab_dwords_for (L) * 4;
   long max_ends = (long) (dir_budget_bytes () / slab_bytes);
@@ -1003,6 +1027,13 @@ static int run_slice (pemap_dev * d, int first, int n, int sync)
     if (g >= 2)
       HIPCHK (d, hipStreamWaitEvent (d->serial_split ? d->stream : d->stream2, d->ev_lists_free[slot], 0));
     launch_lookup (d, cl, slot, d->d_chunk_ctr + g, &d->evs[(size_t) g * PM_NEV]);
+    if (d->vote_on_mem)
+      {
+        // the vote fills the array set that the SW / walk of chunk g-2 used
+        if (g >= 2)
+          HIPCHK (d, hipStreamWaitEvent (d->stream2, d->ev_walk_done[slot], 0));
+        launch_vote (d, cl, true, slot, d->d_chunk_ctr + g, &d->evs[(size_t) g * PM_NEV], d->stream2);
+      }
     HIPCHK (d, hipEventRecord (d->ev_lists_ready[slot], d->serial_split ? d->stream : d->stream2));
     return 0;
   };
