@@ -739,8 +739,14 @@ static void launch_vote (pemap_dev * d, const RunCtx & c, bool split, int slot, 
       PmLists L = d->lists[slot];
       L.n_big = &cc->n_big;
       L.positions = &cc->positions;
-#define PM_VT(SM) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_vote_kernel < SM >), dim3 (n_ends), dim3 (PM_SEED_THREADS), 0, st, c.ix, c.b, c.prm, \
-                                      H, tasks_s, tasks_m, ctr, L, vote_probe)
+      // PEMAP_VOTE_WAVES=n (default 12): n persistent one-wave workgroups per CU; 0 = the workgroup-per-end kernel
+      static const int vw = getenv ("PEMAP_VOTE_WAVES") ? atoi (getenv ("PEMAP_VOTE_WAVES")) : 12;
+      int vgrid = vw * d->n_cus;
+      if (vgrid > n_ends)
+        vgrid = n_ends;
+#define PM_VT(SM) do { if (vw > 0) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_vote_wave_kernel < SM >), dim3 (vgrid), dim3 (64), 0, st, c.ix, c.b, c.prm, H, L); \
+    else hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_vote_kernel < SM >), dim3 (n_ends), dim3 (PM_SEED_THREADS), 0, st, c.ix, c.b, c.prm, \
+                                      H, tasks_s, tasks_m, ctr, L, vote_probe); } while (0)
 #define PM_SEEDL(SM) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_seed_kernel < SM >), dim3 (d->big_grid), dim3 (PM_SEED_THREADS), 0, st, c.ix, c.b, \
                                          c.prm, H, tasks_s, tasks_m, ctr, d->d_seed_scratch, 0, L.big_list, L.n_big)
       switch (seg_template (c.L))
