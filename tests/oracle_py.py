@@ -139,14 +139,19 @@ def pecall_lib():
     global _plib
     if _plib is None:
         so = os.path.join(ROOT, "oracle", "liboracle_pecall.so")
-        src = os.path.join(ROOT, "oracle", "pecall_oracle.c")
-        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        srcs = [os.path.join(ROOT, "oracle", f) for f in ("pecall_oracle.c", "pecall_site_oracle.c")]
+        if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(x) for x in srcs):
             subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), so])
         L = C.CDLL(so)
         L.ora_site_like.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p,
                                     C.c_void_p]
         L.ora_factln.restype = C.c_double
         L.ora_factln.argtypes = [C.c_int]
+        L.ora_caller_create.restype = C.c_void_p
+        L.ora_caller_create.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double]
+        L.ora_caller_destroy.argtypes = [C.c_void_p]
+        L.ora_call_sites.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]
         _plib = L
     return _plib
 
@@ -161,3 +166,24 @@ def site_like(reads, alpha_mean, norm, max_gen=14, min_depth=2):
     margin = np.zeros((n_sites, indiv))
     L.ora_site_like(_p(reads), _p(alpha_mean), n_sites, indiv, max_gen, min_depth, norm, _p(like), _p(best), _p(margin))
     return like, best, margin
+
+
+def call_sites(reads, dom, threshold=0.95, theta=0.001, haploid=False, chrom_y=None):
+    """the per-site caller oracle (oracle/pecall_site_oracle.c): reads[n_sites][indiv][6], dom[n_sites] in 0..3 (else skipped)
+    -> call[n_sites][indiv] (0..13, 14 = N), p, site type, allele counts, passes"""
+    L = pecall_lib()
+    reads = np.ascontiguousarray(reads, np.uint16)
+    dom = np.ascontiguousarray(dom, np.uint8)
+    n_sites, indiv = reads.shape[:2]
+    cy = np.ascontiguousarray(chrom_y, np.uint8) if chrom_y is not None else np.zeros(n_sites, np.uint8)
+    call = np.zeros((n_sites, indiv), np.int8)
+    p = np.zeros((n_sites, indiv))
+    typ = np.zeros(n_sites, np.int8)
+    ac = np.zeros((n_sites, 6), np.int32)
+    npass = np.zeros(n_sites, np.int8)
+    h = L.ora_caller_create(indiv, int(haploid), float(threshold), float(theta))
+    try:
+        L.ora_call_sites(h, _p(reads), _p(dom), _p(cy), n_sites, _p(call), _p(p), _p(typ), _p(ac), _p(npass))
+    finally:
+        L.ora_caller_destroy(h)
+    return call, p, typ, ac, npass

@@ -1,0 +1,41 @@
+"""the per-site caller fixture (tests/golden/pecall_sites.*, made by tests/golden/make_golden_pecall_sites.py) and the
+reference's text format for calls (pecaller.c:1564, 1578, 1600, 1675-1680)"""
+import gzip
+import os
+import numpy as np
+import refio
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+GEN = "ACGTDIMRWSYKEHN"           # int_to_gen, pecaller.c:2910-2943
+TYPES = ["", "SNP", "DEL", "INS", "LOW", "MULTIALLELIC", "MESS"]
+
+
+def load():
+    z = np.load(os.path.join(GOLD, "pecall_sites.npz"))
+    names = [str(x) for x in z["names"]]
+    cols = [str(x) for x in z["columns"]]
+    perm = [names.index(c) for c in cols]          # the reference's sample order = its directory order
+    reads = z["reads"][:, perm, :]
+    pos = z["pos"]
+    _, seqs = refio.read_fasta(os.path.join(GOLD, "g1.fa.gz"))
+    seq = np.concatenate(seqs)
+    ref = seq[pos]
+    dom = np.full(len(pos), 14, np.uint8)
+    for k, ch in enumerate(b"ACGT"):
+        dom[ref == ch] = k
+    base = gzip.open(os.path.join(GOLD, "pecall_sites.base.txt.gz"), "rt").read().split("\n")
+    snp = open(os.path.join(GOLD, "pecall_sites.snp.txt")).read().split("\n")
+    base_rows = {int(r.split("\t")[1]): r for r in base[1:] if r}
+    snp_rows = {int(r.split("\t")[1]): r for r in snp[1:] if r}
+    return dict(reads=reads, pos=pos, ref=ref, dom=dom, base_rows=base_rows, snp_rows=snp_rows)
+
+
+def base_row(contig, pos1, refch, call, p):
+    return "%s\t%d\t%s" % (contig, pos1, refch) + "".join("\t%s\t%g" % (GEN[c], x) for c, x in zip(call, p))
+
+
+def snp_row(contig, pos1, refch, call, p, typ, ac):
+    alle = ",".join("ACGTDI"[a] for a in range(6) if ac[a] > 0)
+    cnts = ",".join("%d" % ac[a] for a in range(6) if ac[a] > 0)
+    return "%s\t%d\t%s\t%s\t%s\t%s" % (contig, pos1, refch, alle, cnts, TYPES[typ]) + "".join("\t%s\t%g" % (GEN[c], x) for c, x in zip(call, p))
