@@ -6,6 +6,7 @@
 #include <math.h>
 #include "../../include/pemap_hip.h"
 #include "pecall_kernels.hip.h"
+#include "pecall_site.hip.h"
 
 static char g_pc_err[512] = "";
 
@@ -20,6 +21,18 @@ struct pecall_dev
   int8_t *d_best;
   long cap_items, cap_sites;
   int grid;
+  // per-site caller
+  double *d_hw;
+  int *d_hw_off;
+  int hw_indiv;
+  char *d_scratch;
+  int site_grid;
+  uint16_t *d_sreads;
+  uint8_t *d_dom, *d_chromy;
+  int8_t *d_call, *d_type, *d_npass;
+  double *d_post;
+  int32_t *d_ac;
+  long cap_ssites, cap_sitems;
 };
 
 static int pc_fail (pecall_dev * d, const char *fmt, ...)
@@ -109,6 +122,17 @@ extern "C" void pecall_dev_destroy (pecall_dev * d)
   hipFree (d->d_like);
   hipFree (d->d_margin);
   hipFree (d->d_best);
+  hipFree (d->d_hw);
+  hipFree (d->d_hw_off);
+  hipFree (d->d_scratch);
+  hipFree (d->d_sreads);
+  hipFree (d->d_dom);
+  hipFree (d->d_chromy);
+  hipFree (d->d_call);
+  hipFree (d->d_type);
+  hipFree (d->d_npass);
+  hipFree (d->d_post);
+  hipFree (d->d_ac);
   hipStreamDestroy (d->stream);
   free (d);
 }
@@ -190,4 +214,136 @@ extern "C" int pecall_dev_site_like (pecall_dev * d, const uint16_t * reads, con
   if (rc)
     return rc;
   return pecall_dev_collect (d, n_sites, indiv, like, best, margin);
+}
+
+// ---- per-site caller (pecall_site.hip.h)
+
+// ln of the exact Hardy-Weinberg probabilities (fill_hardy_weinberg, pecaller.c:2791-2866) for n diploids: row = number of
+// minor alleles (0 .. 2n), column = heterozygotes; built with the host libm like the reference's table
+static void h_hardy_weinberg (int n, double *m)
+{
+  const int asize = 2 * n, cols = n + 1;
+  for (long x = 0; x < (long) (asize + 1) * cols; x++)
+    m[x] = 0.0;
+  for (int i = 1; i <= asize; i++)
+    {
+      double *row = m + (long) i * cols;
+      const int Na = 2 * n - i, Nb = i;
+      const double p = (double) i / (double) (Na + Nb);
+      const int expect = (int) ceil (i * (1.0 - p));
+      const int start = ((expect & 1) == (i & 1)) ? expect : expect - 1;
+      double sum = row[start] = 1.0;
+      int nbb = (Nb - start) / 2, naa = (Na - start) / 2;
+      for (int nab = start + 2; naa > 0 && nbb > 0; nab += 2, naa--, nbb--)
+        {
+          row[nab] = row[nab - 2] * 4.0 * ((double) naa * (double) nbb) / ((double) (nab) * (double) (nab - 1.0));
+          sum += row[nab];
+        }
+      nbb = (Nb - start) / 2;
+      naa = (Na - start) / 2;
+      for (int nab = start - 2; nab >= 0; nab -= 2, naa++, nbb++)
+        {
+          row[nab] = row[nab + 2] * ((double) (nab + 2.0) * (double) (nab + 1.0)) / ((double) 4.0 * ((double) (naa + 1.0) * (nbb + 1.0)));
+          sum += row[nab];
+        }
+      for (int j = 0; j <= n; j++)
+        row[j] /= sum;
+    }
+  for (long x = 0; x < (long) (asize + 1) * cols; x++)
+    m[x] = m[x] > 1e-50 ? log (m[x]) : -5000;
+}
+
+static int pcs_ensure (pecall_dev * d, long n_sites, int indiv)
+{
+  if (indiv != d->hw_indiv)
+    {
+      hipFree (d->d_hw);
+      hipFree (d->d_hw_off);
+      d->d_hw = nullptr;
+      d->d_hw_off = nullptr;
+      int *off = (int *) calloc (indiv + 2, sizeof (int));
+      long tot = 0;
+      for (int n = 1; n <= indiv; n++)
+        {
+          off[n] = (int) tot;
+          tot += (long) (2 * n + 1) * (n + 1);
+        }
+      double *hw = (double *) malloc (sizeof (double) * tot);
+      for (int n = 1; n <= indiv; n++)
+        h_hardy_weinberg (n, hw + off[n]);
+      PCCHK (d, hipMalloc ((void **) &d->d_hw, sizeof (double) * tot));
+      PCCHK (d, hipMalloc ((void **) &d->d_hw_off, sizeof (int) * (indiv + 2)));
+      PCCHK (d, hipMemcpy (d->d_hw, hw, sizeof (double) * tot, hipMemcpyHostToDevice));
+      PCCHK (d, hipMemcpy (d->d_hw_off, off, sizeof (int) * (indiv + 2), hipMemcpyHostToDevice));
+      free (hw);
+      free (off);
+      d->hw_indiv = indiv;
+    }
+  if (!d->d_scratch)
+    {
+      d->site_grid = d->grid * 4;       // 8 waves per CU; LDS admits 4 resident, the rest queue
+      PCCHK (d, hipMalloc ((void **) &d->d_scratch, (size_t) d->site_grid * (2 * PCS_BIG_BYTES + PCS_BIGCAP)));
+    }
+  long items = n_sites * indiv;
+  if (n_sites > d->cap_ssites || items > d->cap_sitems)
+    {
+      hipFree (d->d_sreads); hipFree (d->d_dom); hipFree (d->d_chromy); hipFree (d->d_call); hipFree (d->d_type);
+      hipFree (d->d_npass); hipFree (d->d_post); hipFree (d->d_ac);
+      PCCHK (d, hipMalloc ((void **) &d->d_sreads, items * PCS_NA * sizeof (uint16_t)));
+      PCCHK (d, hipMalloc ((void **) &d->d_dom, n_sites));
+      PCCHK (d, hipMalloc ((void **) &d->d_chromy, n_sites));
+      PCCHK (d, hipMalloc ((void **) &d->d_call, items));
+      PCCHK (d, hipMalloc ((void **) &d->d_post, items * sizeof (double)));
+      PCCHK (d, hipMalloc ((void **) &d->d_type, n_sites));
+      PCCHK (d, hipMalloc ((void **) &d->d_npass, n_sites));
+      PCCHK (d, hipMalloc ((void **) &d->d_ac, n_sites * PCS_NA * sizeof (int32_t)));
+      d->cap_ssites = n_sites;
+      d->cap_sitems = items;
+    }
+  return 0;
+}
+
+extern "C" int pecall_dev_call_sites (pecall_dev * d, const uint16_t * reads, const uint8_t * ref_base, const uint8_t * chrom_y, long n_sites,
+                                      int indiv, int haploid, double threshold, double theta, int8_t * call, double *posterior,
+                                      int8_t * site_type, int32_t * allele_count, int8_t * n_pass)
+{
+  PCCHK (d, hipSetDevice (d->device));
+  if (n_sites <= 0 || indiv <= 0 || indiv > PCS_MAXN)
+    return pc_fail (d, "call_sites: n_sites %ld, indiv %d (1..%d samples per call)", n_sites, indiv, PCS_MAXN);
+  if (!(theta >= 1e-10 && theta <= 0.5))
+    return pc_fail (d, "call_sites: theta %g outside [1e-10, 0.5] (pecaller.c:305-309)", theta);
+  int rc = pcs_ensure (d, n_sites, indiv);
+  if (rc)
+    return rc;
+  long items = n_sites * indiv;
+  PCCHK (d, hipMemcpyAsync (d->d_sreads, reads, items * PCS_NA * sizeof (uint16_t), hipMemcpyHostToDevice, d->stream));
+  PCCHK (d, hipMemcpyAsync (d->d_dom, ref_base, n_sites, hipMemcpyHostToDevice, d->stream));
+  if (chrom_y)
+    PCCHK (d, hipMemcpyAsync (d->d_chromy, chrom_y, n_sites, hipMemcpyHostToDevice, d->stream));
+  else
+    PCCHK (d, hipMemsetAsync (d->d_chromy, 0, n_sites, d->stream));
+  PcsParams P;
+  P.indiv = indiv;
+  P.haploid = haploid ? 1 : 0;
+  P.max_gen = haploid ? 6 : PCS_NG;     // pecaller.c:326-336
+  P.min_depth = haploid ? 1 : 2;
+  P.threshold = threshold;
+  P.ln_theta = log (theta);
+  P.tab = d->d_tab;
+  P.hw = d->d_hw;
+  P.hw_off = d->d_hw_off;
+  long grid = n_sites < d->site_grid ? n_sites : d->site_grid;
+  hipLaunchKernelGGL (pcs_call_kernel, dim3 ((unsigned) grid), dim3 (64), 0, d->stream, P, d->d_sreads, d->d_dom, d->d_chromy, n_sites, d->d_call,
+                      d->d_post, d->d_type, d->d_ac, d->d_npass, d->d_scratch);
+  PCCHK (d, hipGetLastError ());
+  PCCHK (d, hipMemcpyAsync (call, d->d_call, items, hipMemcpyDeviceToHost, d->stream));
+  PCCHK (d, hipMemcpyAsync (posterior, d->d_post, items * sizeof (double), hipMemcpyDeviceToHost, d->stream));
+  if (site_type)
+    PCCHK (d, hipMemcpyAsync (site_type, d->d_type, n_sites, hipMemcpyDeviceToHost, d->stream));
+  if (allele_count)
+    PCCHK (d, hipMemcpyAsync (allele_count, d->d_ac, n_sites * PCS_NA * sizeof (int32_t), hipMemcpyDeviceToHost, d->stream));
+  if (n_pass)
+    PCCHK (d, hipMemcpyAsync (n_pass, d->d_npass, n_sites, hipMemcpyDeviceToHost, d->stream));
+  PCCHK (d, hipStreamSynchronize (d->stream));
+  return 0;
 }

@@ -1,0 +1,913 @@
+// pecall_site.hip.h -- PECaller's per-site caller (the body of call_single_base, src/pecaller.c:1207-1691, without a
+// pedigree) on gfx950: ONE WAVE per pileup column, persistent over columns.
+//
+//   lane = sample (INDIV <= 64) for everything that is per sample: set-up (1230-1260), fill_sample_like (2448-2507),
+//          marginal posteriors and calls (1443-1468), classification counts (1575-1597);
+//   lane = joint configuration (or candidate configuration) for the beam: fill_config_like (2347-2360),
+//          fill_config_probs (2511-2788: every (configuration, genotype) candidate of a sample is priced by its own lane,
+//          then the reference's running best_like / best_post acceptance rule is replayed over them in order),
+//          clean_config_probs (2248-2344: stable rank sort by posterior, cut at 2.3 nats / 514, homozygous fallback);
+//   lane = (genotype, allele) cell for the Dirichlet re-estimation (1475-1553) and = genotype row for
+//          check_alpha_sanity (2076-2188).
+//
+// Every floating-point sum is taken in the reference's order by a single lane, so results agree with the CPU to the
+// last bit wherever libm agrees (exp / pow / log of the device are used in the normalisation, the re-estimation and
+// ln n! above 10000 only; the ln n! table and the Hardy-Weinberg table come from the host, built with its libm).
+//
+// Configurations live in two pools (current list / list being built).  Almost every column needs one to three
+// configurations, so the pools sit in LDS (64 entries); a column whose list outgrows that moves to per-wave pools in HBM
+// (flat pointers: the code is the same) for the rest of its passes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "pecall_kernels.hip.h"
+
+#define PCS_MAXN 64
+#define PCS_NA 6
+#define PCS_NG 14
+#define PCS_MAXCFG 514          // max_configs, pecaller.c:1180
+#define PCS_SMALL 64            // list length a pool in LDS takes
+#define PCS_SMALLCAP 72         // its slots (+1 for the homozygous fallback, padded)
+#define PCS_BIGCAP 7232         // >= max_gen * (max_configs + 1) + 1 (pecaller.c:1194), multiple of 8
+
+struct PcsParams
+{
+  int indiv, max_gen, min_depth, haploid;
+  double threshold, ln_theta;
+  const double *tab;            // ln n!, n <= 10000
+  const double *hw;             // ln_HW[n][minor][hets] flattened; hw_off[n] = start of the (2n+1) x (n+1) matrix
+  const int *hw_off;
+};
+
+struct PcsPool
+{
+  double *like, *prior, *post;
+  int16_t *acount;              // [cap][6]
+  int16_t *hets;
+  int8_t *nall;
+  int8_t *calls;                // [cap][64]
+  uint16_t *ord;                // list position -> slot
+  uint16_t *ord2;               // scratch of the sort
+  int cap;                      // longest list
+};
+
+struct __align__ (16) PcsSmallPool
+{
+  double like[PCS_SMALLCAP], prior[PCS_SMALLCAP], post[PCS_SMALLCAP];
+  int8_t calls[PCS_SMALLCAP][PCS_MAXN];
+  int16_t acount[PCS_SMALLCAP][PCS_NA];
+  int16_t hets[PCS_SMALLCAP];
+  uint16_t ord[PCS_SMALLCAP], ord2[PCS_SMALLCAP];
+  int8_t nall[PCS_SMALLCAP];
+};
+
+// bytes of one per-wave pool in HBM
+#define PCS_BIG_BYTES ((size_t) PCS_BIGCAP * (3 * 8 + PCS_MAXN + 2 * PCS_NA + 2 + 2 + 2 + 1 + 7))
+
+struct __align__ (16) PcsShared
+{
+  PcsSmallPool pool[2];
+  double like[PCS_MAXN][PCS_NG + 1];    // per-sample genotype log-likelihoods of the pass
+  double pp[PCS_MAXN][PCS_NG + 1];      // marginal posteriors
+  double mean[PCS_NG][PCS_NA], var[PCS_NG][PCS_NA], wt[PCS_NG][PCS_NA], fr[PCS_NG][PCS_NA];
+  int al[PCS_NG][PCS_NA], first[PCS_NG][PCS_NA];
+  int reads[PCS_MAXN][PCS_NA];
+  int tot[PCS_MAXN];
+  uint8_t sord[PCS_MAXN];               // samples by margin, descending
+  uint8_t dup[PCS_SMALLCAP];
+};
+
+__device__ __forceinline__ void pcs_sync ()
+{
+  __builtin_amdgcn_fence (__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier ();
+}
+
+__device__ __forceinline__ double pcs_shfl (double v, int l)
+{
+  return __hiloint2double (__shfl (__double2hiint (v), l), __shfl (__double2loint (v), l));
+}
+
+__device__ __forceinline__ void pcs_pool_small (PcsPool & p, PcsSmallPool * s)
+{
+  p.like = s->like;
+  p.prior = s->prior;
+  p.post = s->post;
+  p.acount = &s->acount[0][0];
+  p.hets = s->hets;
+  p.nall = s->nall;
+  p.calls = &s->calls[0][0];
+  p.ord = s->ord;
+  p.ord2 = s->ord2;
+  p.cap = PCS_SMALL;
+}
+
+__device__ __forceinline__ void pcs_pool_big (PcsPool & p, char *base)
+{
+  p.like = (double *) base;
+  p.prior = p.like + PCS_BIGCAP;
+  p.post = p.prior + PCS_BIGCAP;
+  p.calls = (int8_t *) (p.post + PCS_BIGCAP);
+  p.acount = (int16_t *) (p.calls + (size_t) PCS_BIGCAP * PCS_MAXN);
+  p.hets = p.acount + (size_t) PCS_BIGCAP * PCS_NA;
+  p.ord = (uint16_t *) (p.hets + PCS_BIGCAP);
+  p.ord2 = p.ord + PCS_BIGCAP;
+  p.nall = (int8_t *) (p.ord2 + PCS_BIGCAP);
+  p.cap = PCS_BIGCAP - 8;
+}
+
+// get_het_alleles, pecaller.c:2191-2245
+__device__ __forceinline__ void pcs_het (int g, int &a, int &b, int ref)
+{
+  if (g < PCS_NA)
+    a = b = g;
+  else if (g < 12)
+    {
+      const int k = g - 6;      // 01 02 03 12 13 23
+      a = k < 3 ? 0 : (k < 5 ? 1 : 2);
+      b = k < 3 ? k + 1 : (k < 5 ? k - 1 : 3);
+    }
+  else
+    {
+      a = ref;
+      b = g == 12 ? 4 : 5;
+    }
+}
+
+// allele_counts[ref][g][k], pecaller.c:725-737
+__device__ __forceinline__ int pcs_ac (int ref, int g, int k, int haploid)
+{
+  int a, b;
+  pcs_het (g, a, b, ref);
+  return (a == k ? 1 : 0) + ((!haploid && b == k) ? 1 : 0);
+}
+
+// genotype_order[ref][jj], pecaller.c:617-722 (diploid, then haploid)
+__constant__ unsigned char pcs_order_tab[2][4][PCS_NG] = {
+  {{0, 7, 6, 8, 12, 13, 1, 2, 3, 4, 5, 9, 10, 11}, {1, 10, 6, 9, 12, 13, 0, 2, 3, 4, 5, 7, 8, 11},
+   {2, 7, 9, 11, 12, 13, 0, 1, 3, 4, 5, 6, 8, 10}, {3, 10, 8, 11, 12, 13, 1, 0, 2, 4, 5, 6, 7, 9}},
+  {{0, 2, 1, 3, 4, 5}, {1, 3, 0, 2, 4, 5}, {2, 0, 1, 3, 4, 5}, {3, 1, 0, 2, 4, 5}}
+};
+
+__device__ __forceinline__ int pcs_order (int ref, int jj, int haploid)
+{
+  return pcs_order_tab[haploid ? 1 : 0][ref][jj];
+}
+
+// config_alloc, pecaller.c:2987-3027, into slot s: every sample above the depth floor called homozygous `dom`
+__device__ __forceinline__ void pcs_cfg_init (const PcsPool & p, int s, int dom, unsigned long long deep, int haploid, int lane)
+{
+  p.calls[(size_t) s * PCS_MAXN + lane] = ((deep >> lane) & 1ull) ? (int8_t) dom : (int8_t) PCS_NG;
+  if (lane < PCS_NA)
+    p.acount[s * PCS_NA + lane] = (lane == dom) ? (int16_t) (__popcll (deep) * (haploid ? 1 : 2)) : (int16_t) 0;
+  if (lane == 0)
+    {
+      p.hets[s] = 0;
+      p.nall[s] = deep ? 1 : 0;
+      p.like[s] = 0;
+      p.prior[s] = 0;
+      p.post[s] = 1;
+    }
+}
+
+// fill_config_like for slot s, by one lane
+__device__ __forceinline__ void pcs_cfg_like (const PcsPool & p, int s, const PcsShared & sh, unsigned long long deep, int N)
+{
+  double l = 0;
+  for (int i = 0; i < N; i++)
+    if ((deep >> i) & 1ull)
+      l += sh.like[i][p.calls[(size_t) s * PCS_MAXN + i]];
+  p.like[s] = l;
+  p.post[s] = l + p.prior[s];
+}
+
+// stable sort of the list's first n positions by posterior, descending (qsort + sort_configs; glibc's merge sort is stable)
+__device__ __forceinline__ void pcs_sort (PcsPool & p, int n, int lane)
+{
+  for (int pos = lane; pos < n; pos += 64)
+    {
+      const int s = p.ord[pos];
+      const double pe = p.post[s];
+      int rank = 0;
+      for (int j = 0; j < n; j++)
+        {
+          const double pj = p.post[p.ord[j]];
+          rank += (pj > pe) || (pj == pe && j < pos);
+        }
+      p.ord2[rank] = (uint16_t) s;
+    }
+  pcs_sync ();
+  for (int pos = lane; pos < n; pos += 64)
+    p.ord[pos] = p.ord2[pos];
+  pcs_sync ();
+}
+
+// clean_config_probs, pecaller.c:2248-2344; returns the new list length
+__device__ __forceinline__ int pcs_clean (PcsPool & p, int n, int ref, double ct, const PcsShared & sh, unsigned long long deep,
+                                         const PcsParams & P, int lane)
+{
+  pcs_sort (p, n, lane);
+  int mx = min (PCS_MAXCFG, n);
+  {
+    const double p0 = p.post[p.ord[0]];
+    // the first position whose posterior is more than ct below the best (the list is sorted)
+    int cut = mx;
+    for (int i0 = 1; i0 < mx && cut == mx; i0 += 64)
+      {
+        const int i = i0 + lane;
+        const unsigned long long m = __ballot (i < mx && p0 > p.post[p.ord[i < mx ? i : 0]] + ct);
+        if (m)
+          cut = i0 + __ffsll ((long long) m) - 1;
+      }
+    mx = cut;
+  }
+  bool found_hom = false;
+  for (int i0 = 0; i0 < mx && !found_hom; i0 += 64)
+    {
+      const int i = i0 + lane;
+      found_hom = __any (i < mx && p.nall[p.ord[i < mx ? i : 0]] == 1);
+    }
+  if (!found_hom)
+    {
+      const int s0 = p.ord[0];
+      int best_hom = 0;
+      for (int i = 1; i < PCS_NA; i++)
+        if (p.acount[s0 * PCS_NA + i] > p.acount[s0 * PCS_NA + best_hom])
+          best_hom = i;
+      if (best_hom > 3)
+        best_hom = ref;
+      const int s = n;          // slots 0 .. n-1 hold the list, slot n is free
+      pcs_cfg_init (p, s, best_hom, deep, P.haploid, lane);
+      pcs_sync ();
+      if (lane == 0)
+        {
+          pcs_cfg_like (p, s, sh, deep, P.indiv);
+          p.post[s] = p.like[s];
+          p.ord[mx] = (uint16_t) s;
+        }
+      pcs_sync ();
+      if (p.post[s] > p.post[p.ord[mx - 1]])
+        pcs_sort (p, mx + 1, lane);
+      mx++;
+    }
+  return mx;
+}
+
+// copy the first n slots of a pool (dense list, ord[i] = i) to another pool
+__device__ __forceinline__ void pcs_migrate (const PcsPool & from, const PcsPool & to, int n, int lane)
+{
+  for (int s = lane; s < n; s += 64)
+    {
+      to.like[s] = from.like[s];
+      to.prior[s] = from.prior[s];
+      to.post[s] = from.post[s];
+      to.hets[s] = from.hets[s];
+      to.nall[s] = from.nall[s];
+      to.ord[s] = from.ord[s];
+      for (int k = 0; k < PCS_NA; k++)
+        to.acount[s * PCS_NA + k] = from.acount[s * PCS_NA + k];
+    }
+  for (int s = 0; s < n; s++)
+    to.calls[(size_t) s * PCS_MAXN + lane] = from.calls[(size_t) s * PCS_MAXN + lane];
+  pcs_sync ();
+}
+
+// fill_config_probs, pecaller.c:2511-2788 (no pedigree): the configurations of `cur` re-decided for sample `who`.
+// dupbuf: one byte per list position (LDS for short lists, HBM for long ones).  Returns the length of the list built in nw;
+// nw may be switched to `big_nw` (the wave's pool in HBM) when it outgrows LDS: *went_big is set.
+__device__ int pcs_expand (const PcsPool & cur, PcsPool & nw, const PcsPool & big_nw, bool &went_big, int n, int who, int ref, double thres,
+                           const PcsShared & sh, uint8_t * dupbuf, int r4, int r5, const PcsParams & P, int lane)
+{
+  const int G = P.max_gen, N = P.indiv;
+  // ---- a configuration equal to an earlier one on every other sample is skipped (pecaller.c:2542-2558)
+  const int ww = who >> 3;
+  const unsigned long long wmask = ~(0xFFull << (8 * (who & 7)));
+  for (int i = lane; i < n; i += 64)
+    {
+      const unsigned long long *ci = (const unsigned long long *) (cur.calls + (size_t) cur.ord[i] * PCS_MAXN);
+      int dup = 0;
+      for (int ii = 0; ii < i && !dup; ii++)
+        {
+          const unsigned long long *cj = (const unsigned long long *) (cur.calls + (size_t) cur.ord[ii] * PCS_MAXN);
+          int same = 1;
+          for (int w = 0; w < (N + 7) / 8 && same; w++)
+            {
+              unsigned long long x = ci[w] ^ cj[w];
+              if (w == ww)
+                x &= wmask;
+              if (w == (N - 1) / 8 && (N & 7))
+                x &= (1ull << (8 * (N & 7))) - 1ull;
+              same = (x == 0);
+            }
+          dup = same;
+        }
+      dupbuf[i] = (uint8_t) dup;
+    }
+  pcs_sync ();
+  double best_post = cur.post[cur.ord[0]], best_like = cur.like[cur.ord[0]];
+  int newcount = 0;
+  const long total = (long) n * G;
+  for (long c0 = 0; c0 < total; c0 += 64)
+    {
+      // ---- every candidate (configuration, genotype) of this chunk priced by its own lane
+      const long c = c0 + lane;
+      const bool in = c < total;
+      const int pos = in ? (int) (c / G) : 0, jj = in ? (int) (c - (long) pos * G) : 0;
+      const int s = cur.ord[pos];
+      const bool valid = in && !dupbuf[pos];
+      const int j = pcs_order (ref, jj, P.haploid);
+      const int g_old = cur.calls[(size_t) s * PCS_MAXN + who];
+      double base = cur.like[s];
+      if (g_old < PCS_NG)
+        base -= sh.like[who][g_old];
+      double templ = base + sh.like[who][j];
+      // an indel genotype needs three supporting reads (pecaller.c:2622-2625)
+      if ((j == 4 || j == 12) && r4 < 3)
+        templ -= 1e10;
+      if ((j == 13 || j == 5) && r5 < 3)
+        templ -= 1e10;
+      int ac[PCS_NA], nall = 0;
+#pragma unroll
+      for (int k = 0; k < PCS_NA; k++)
+        {
+          ac[k] = cur.acount[s * PCS_NA + k] - (g_old < PCS_NG ? pcs_ac (ref, g_old, k, P.haploid) : 0) + pcs_ac (ref, j, k, P.haploid);
+          nall += ac[k] > 0;
+        }
+      const int hets = cur.hets[s] - ((g_old < PCS_NG && g_old >= PCS_NA) ? 1 : 0) + (j >= PCS_NA ? 1 : 0);
+      double prior = 0;
+      if (nall > 1)
+        prior = (nall - 1) * P.ln_theta;
+      if (!P.haploid && nall > 1)
+        {
+          int major = 0, minor = 0;
+#pragma unroll
+          for (int k = 1; k < PCS_NA; k++)
+            if (ac[k] > ac[major])
+              major = k;
+#pragma unroll
+          for (int k = 0; k < PCS_NA; k++)
+            if (k != major)
+              minor += ac[k];
+          int mj = 0;
+#pragma unroll
+          for (int k = 0; k < PCS_NA; k++)
+            mj = (k == major) ? ac[k] : mj;
+          major = mj;
+          if (minor > major)
+            {
+              const int sw = major;
+              major = minor;
+              minor = sw;
+            }
+          const int hh = min (minor, hets);
+          const int tot_n = (minor + major) / 2;
+          if ((minor - hh) % 2 == 1)
+            {
+              minor++;
+              major++;
+            }
+          if (valid)
+            prior += P.hw[P.hw_off[tot_n] + (long) minor * (tot_n + 1) + hh];
+        }
+      const double post = prior + templ;
+      // ---- the reference's acceptance rule, in candidate order (pecaller.c:2628, 2738-2758)
+      unsigned long long m = __ballot (valid);
+      while (m)
+        {
+          const int k = __ffsll ((long long) m) - 1;
+          m &= m - 1;
+          const double t = pcs_shfl (templ, k), po = pcs_shfl (post, k);
+          if (!((t + thres > best_post) || (t + 0.01 > best_like)))
+            continue;
+          best_like = (t > best_like) ? t : best_like;
+          best_post = (po > best_post) ? po : best_post;
+          if (!(po + thres > best_post))
+            continue;
+          if (newcount == nw.cap && !went_big)
+            {
+              pcs_migrate (nw, big_nw, newcount, lane);
+              nw = big_nw;
+              went_big = true;
+            }
+          const int sk = __shfl (s, k), jk = __shfl (j, k);
+          const int d = newcount;
+          nw.calls[(size_t) d * PCS_MAXN + lane] = (lane == who) ? (int8_t) jk : cur.calls[(size_t) sk * PCS_MAXN + lane];
+          const double pr = pcs_shfl (prior, k);
+          const int hk = __shfl (hets, k), nk = __shfl (nall, k);
+          int ak = 0;
+#pragma unroll
+          for (int q = 0; q < PCS_NA; q++)
+            {
+              const int v = __shfl (ac[q], k);
+              ak = (lane == q) ? v : ak;
+            }
+          if (lane < PCS_NA)
+            nw.acount[d * PCS_NA + lane] = (int16_t) ak;
+          if (lane == 0)
+            {
+              nw.like[d] = t;
+              nw.prior[d] = pr;
+              nw.post[d] = po;
+              nw.hets[d] = (int16_t) hk;
+              nw.nall[d] = (int8_t) nk;
+              nw.ord[d] = (uint16_t) d;
+            }
+          newcount++;
+        }
+    }
+  pcs_sync ();
+  return newcount;
+}
+
+// One wave per site.  Outputs are what the reference prints per row: call 0..13 or 14 (N), posterior,
+// site type (0 REF, 1 SNP, 2 DEL, 3 INS, 4 LOW, 5 MULTIALLELIC, 6 MESS; -1 = reference base not A/C/G/T, skipped),
+// Allele_Counts, passes.
+__global__ __launch_bounds__ (64) void pcs_call_kernel (PcsParams P, const uint16_t * reads, const uint8_t * dom_of, const uint8_t * chrom_y,
+                                                      long n_sites, int8_t * call, double *post_out, int8_t * type_out,
+                                                      int32_t * allele_count, int8_t * n_pass, char *scratch)
+{
+  __shared__ PcsShared sh;
+  const int lane = threadIdx.x;
+  const int N = P.indiv, G = P.max_gen, md = P.min_depth;
+  char *my = scratch + (size_t) blockIdx.x * (2 * PCS_BIG_BYTES + PCS_BIGCAP);
+  PcsPool bigp[2];
+  pcs_pool_big (bigp[0], my);
+  pcs_pool_big (bigp[1], my + PCS_BIG_BYTES);
+  uint8_t *big_dup = (uint8_t *) (my + 2 * PCS_BIG_BYTES);
+  for (long site = blockIdx.x; site < n_sites; site += gridDim.x)
+    {
+      const int dom = dom_of[site];
+      if (dom > 3)
+        {
+          if (lane < N)
+            {
+              call[site * N + lane] = PCS_NG;
+              post_out[site * N + lane] = 1.0;
+            }
+          if (lane < PCS_NA)
+            allele_count[site * PCS_NA + lane] = 0;
+          if (lane == 0)
+            {
+              type_out[site] = -1;
+              n_pass[site] = 0;
+            }
+          continue;
+        }
+      // ---- per-sample set-up (pecaller.c:1230-1260)
+      int r[PCS_NA], tot = 0;
+#pragma unroll
+      for (int a = 0; a < PCS_NA; a++)
+        r[a] = lane < N ? (int) reads[(site * N + lane) * PCS_NA + a] : 0;
+      tot = r[0] + r[1] + r[2] + r[3] + r[4];
+      double coef = pc_factln (P.tab, tot);
+#pragma unroll
+      for (int a = 0; a < PCS_NA; a++)
+        coef -= pc_factln (P.tab, r[a]);
+      int initial_call = tot > md ? dom : PCS_NG, final_call = initial_call;
+      double final_p = 1.0;
+      // average depth: the reference adds the integer totals into a double in sample order; integers add exactly
+      int tsum = tot;
+      for (int o = 32; o; o >>= 1)
+        tsum += __shfl_xor (tsum, o);
+      const double average_depth = (double) tsum / (double) N;
+      bool bad_base = average_depth < 8;
+      const int sample_count = __popcll (__ballot (lane < N && tot >= 8));
+      if (sample_count < (double) 0.5 * N && !(chrom_y && chrom_y[site]))
+        bad_base = true;
+      if (bad_base)
+        tot = 0;
+      const unsigned long long deep = __ballot (lane < N && tot > md);
+#pragma unroll
+      for (int a = 0; a < PCS_NA; a++)
+        sh.reads[lane][a] = r[a];
+      sh.tot[lane] = tot;
+      PcsPool pool[2];
+      pcs_pool_small (pool[0], &sh.pool[0]);
+      pcs_pool_small (pool[1], &sh.pool[1]);
+      int ci = 0;               // pool[ci] = current list
+      bool big = false;
+      int total = 1, pass = 0;
+      bool calls_changed = !bad_base;
+      const int normal_factor = 300;
+      if (!bad_base)
+        {
+          pcs_cfg_init (pool[0], 0, dom, deep, P.haploid, lane);
+          if (lane == 0)
+            pool[0].ord[0] = 0;
+          // ---- fill_alpha_prior (pecaller.c:3043-3139): lane = genotype row
+          if (lane < G)
+            {
+              const int hom = normal_factor, het = normal_factor / 2, g = lane;
+              const int hom_err = max (1, hom / 300), err = max (1, (2 * het) / 300);
+              int row[PCS_NA];
+              for (int k = 0; k < PCS_NA; k++)
+                row[k] = err;
+              if (g < 4)
+                for (int k = 0; k < PCS_NA; k++)
+                  row[k] = (g == k) ? hom : hom_err;
+              else if (g == 4 || g == 5)
+                {
+                  for (int k = 0; k < 4; k++)
+                    row[k] = (k == dom) ? (g == 4 ? hom / 5 : hom) : err;
+                  row[4] = g == 4 ? (4 * hom) / 5 : err;
+                  row[5] = g == 4 ? err : (4 * hom) / 5;
+                }
+              else if (g < 12)
+                {
+                  int a, b;
+                  pcs_het (g, a, b, dom);
+                  if (a == dom || b == dom)
+                    {
+                      for (int k = 0; k < PCS_NA; k++)
+                        row[k] = (k == dom) ? (51 * het) / 50 : (k == (a == dom ? b : a)) ? (49 * het) / 50 : (k == 4) ? max (1, het / 20) : err;
+                    }
+                  else
+                    for (int k = 0; k < PCS_NA; k++)
+                      row[k] = (k == a || k == b) ? het : err;
+                }
+              else if (g == 12)
+                for (int k = 0; k < PCS_NA; k++)
+                  row[k] = (k == 4) ? (4 * het) / 5 : (k == dom) ? (6 * het) / 5 : err;
+              else
+                for (int k = 0; k < PCS_NA; k++)
+                  row[k] = (k == 5) ? (2 * het) / 5 : (k == dom) ? (8 * het) / 5 : err;
+              for (int k = 0; k < PCS_NA; k++)
+                sh.al[g][k] = row[k];
+            }
+        }
+      pcs_sync ();
+      const double ct = 2.3;    // starting_threshold
+      while (calls_changed && pass < 5)
+        {
+          pass++;
+          // ---- Dirichlet means of the pass (pecaller.c:1354-1364)
+          if (lane < G)
+            {
+              int myt = 0;
+              for (int a = 0; a < PCS_NA; a++)
+                {
+                  myt += sh.al[lane][a];
+                  sh.first[lane][a] = sh.al[lane][a];
+                }
+              for (int a = 0; a < PCS_NA; a++)
+                sh.mean[lane][a] = (double) sh.al[lane][a] / (double) myt;
+            }
+          pcs_sync ();
+          // ---- fill_sample_like (pecaller.c:2448-2507), lane = sample
+          double norm = 1.0;
+          for (int i = 2; i <= pass; i++)
+            norm *= 2.5;        // new_norm[pass], pecaller.c:1339-1344
+          double initial_p = 0.0;
+          initial_call = PCS_NG;
+          if (lane < N && tot > md)
+            {
+              const double sc0 = (double) min (tot, 100) * norm;
+              const double sc1 = (10 > sc0) ? 10 : sc0;
+              const double scale = (1000 < sc1) ? 1000 : sc1;
+              double mx = -1e100;
+              int best = PCS_NG;
+              for (int g = 0; g < G; g++)
+                {
+                  int tot_a = 0, tot_tot = 0;
+                  double cf = coef, lk = 0.0;
+                  for (int a = 0; a < PCS_NA; a++)
+                    {
+                      const double cv = ceil (scale * sh.mean[g][a]);
+                      const int ta = (int) ((1 > cv) ? 1 : cv);
+                      tot_a += ta;
+                      tot_tot += ta + r[a];
+                      cf -= pc_factln (P.tab, ta - 1);
+                      lk += pc_factln (P.tab, ta + r[a] - 1);
+                    }
+                  cf += pc_factln (P.tab, tot_a - 1);
+                  lk += cf;
+                  lk -= pc_factln (P.tab, tot_tot - 1);
+                  sh.like[lane][g] = lk;
+                  if (lk > mx)
+                    {
+                      best = g;
+                      mx = lk;
+                    }
+                }
+              initial_p = 1e100;
+              initial_call = best;
+              for (int g = 0; g < G; g++)
+                if (g != best)
+                  {
+                    const double dlt = mx - sh.like[lane][g];
+                    initial_p = (dlt < initial_p) ? dlt : initial_p;
+                  }
+            }
+          // samples by margin, descending, stable (sort_compare_sample_pointer)
+          {
+            int rank = 0;
+            for (int jn = 0; jn < N; jn++)
+              {
+                const double pj = pcs_shfl (initial_p, jn);
+                rank += (pj > initial_p) || (pj == initial_p && jn < lane);
+              }
+            if (lane < N)
+              sh.sord[rank] = (uint8_t) lane;
+          }
+          pcs_sync ();
+          for (int i = lane; i < total; i += 64)
+            pcs_cfg_like (pool[ci], pool[ci].ord[i], sh, deep, N);
+          pcs_sync ();
+          total = pcs_clean (pool[ci], total, dom, ct, sh, deep, P, lane);
+          for (int k = 0; k < N; k++)
+            {
+              const int ind = sh.sord[k];
+              if ((deep >> ind) & 1ull)
+                {
+                  const int ni = ci ^ 1;
+                  if (big)
+                    pool[ni] = bigp[ni];
+                  bool went_big = big;
+                  const int r4 = __shfl (r[4], ind), r5 = __shfl (r[5], ind);
+                  const int cnt = pcs_expand (pool[ci], pool[ni], bigp[ni], went_big, total, ind, dom, ct, sh, (total <= PCS_SMALLCAP) ? sh.dup : big_dup,
+                                              r4, r5, P, lane);
+                  big = went_big;
+                  ci = ni;
+                  total = pcs_clean (pool[ci], cnt, dom, ct, sh, deep, P, lane);
+                }
+              else
+                {
+                  // a sample under the depth floor is 'N' in every configuration (pecaller.c:1408-1417)
+                  for (int i = lane; i < total; i += 64)
+                    pool[ci].calls[(size_t) pool[ci].ord[i] * PCS_MAXN + ind] = PCS_NG;
+                  if (lane == ind)
+                    {
+                      final_call = PCS_NG;
+                      final_p = 1.0;
+                    }
+                  pcs_sync ();
+                }
+            }
+          // ---- posteriors of the configurations (pecaller.c:1423-1441): exp of the difference to the best, normalised
+          const PcsPool & cp = pool[ci];
+          {
+            const double max_post = cp.post[cp.ord[0]];
+            for (int i = lane; i < total; i += 64)
+              {
+                const int s = cp.ord[i];
+                const double dlt = cp.post[s] - max_post;
+                cp.post[s] = dlt > -40 ? exp (dlt) : 0;
+              }
+            pcs_sync ();
+            double tot_post = 0;
+            for (int i = 0; i < total; i++)
+              tot_post += cp.post[cp.ord[i]];
+            pcs_sync ();
+            for (int i = lane; i < total; i += 64)
+              cp.post[cp.ord[i]] /= tot_post;
+            pcs_sync ();
+          }
+          // ---- marginal posteriors and calls (pecaller.c:1443-1468), lane = sample
+          calls_changed = false;
+          if (lane < N && tot > md)
+            {
+              for (int g = 0; g <= PCS_NG; g++)
+                sh.pp[lane][g] = 0;
+              for (int i = 0; i < total; i++)
+                {
+                  const int s = cp.ord[i];
+                  sh.pp[lane][cp.calls[(size_t) s * PCS_MAXN + lane]] += cp.post[s];
+                }
+              int besti = 0;
+              for (int g = 1; g < G; g++)
+                if (sh.pp[lane][g] > sh.pp[lane][besti])
+                  besti = g;
+              final_p = sh.pp[lane][besti];
+              final_call = besti;
+              if (final_call != initial_call || final_p < P.threshold)
+                calls_changed = true;
+            }
+          calls_changed = __any (calls_changed);
+          if (N < 4 || pass == 5)
+            calls_changed = false;
+          if (calls_changed)
+            {
+              // ---- moment-matched re-estimation of the Dirichlet parameters (pecaller.c:1475-1553), lane = (genotype, allele)
+              for (int it = lane; it < G * PCS_NA; it += 64)
+                {
+                  const int g = it / PCS_NA, a = it - g * PCS_NA;
+                  double m = 0, v = 0, w = 0;
+                  for (int i = 0; i < total; i++)
+                    {
+                      const int s = cp.ord[i];
+                      const double po = cp.post[s];
+                      for (int ind = 0; ind < N; ind++)
+                        if (((deep >> ind) & 1ull) && cp.calls[(size_t) s * PCS_MAXN + ind] == g)
+                          {
+                            const double f = (double) sh.reads[ind][a] / (double) sh.tot[ind];
+                            m += f * po;
+                            v += (f * f) * po;
+                            w += po;
+                          }
+                    }
+                  if (w > 1e-9)
+                    {
+                      m /= w;
+                      v /= w;
+                      v -= m * m;
+                    }
+                  sh.mean[g][a] = m;
+                  sh.var[g][a] = v;
+                  sh.wt[g][a] = w;
+                }
+              pcs_sync ();
+              if (lane < G)
+                {
+                  const int g = lane;
+                  const double var_eps = 1e-6;
+                  int non_zero_var = 0, this_min = 0, little_up = 0;
+                  for (int a = 1; a < PCS_NA; a++)
+                    if (sh.mean[g][a] > sh.mean[g][little_up])
+                      little_up = a;
+                  for (int a = 0; a < PCS_NA; a++)
+                    {
+                      if (sh.wt[g][a] >= 1.5 && sh.var[g][a] > var_eps * sh.mean[g][a])
+                        non_zero_var++;
+                      if (sh.mean[g][a] < sh.mean[g][this_min])
+                        this_min = a;
+                      if (sh.mean[g][a] > var_eps && sh.mean[g][a] < sh.mean[g][little_up])
+                        little_up = a;
+                    }
+                  bool use_first = true;
+                  if (non_zero_var > 1)
+                    {
+                      double s0 = 1.0;
+                      for (int a = 0; a < PCS_NA; a++)
+                        if (a != this_min && sh.var[g][a] > var_eps * sh.mean[g][a])
+                          s0 *= sh.mean[g][a] * (1.0 - sh.mean[g][a]) / sh.var[g][a];
+                      s0 = pow (s0 - 1.0, (double) 1.0 / (double) (non_zero_var - 1.0));
+                      const double lu = 1.0 / sh.mean[g][little_up];
+                      s0 = (s0 > lu) ? s0 : lu;
+                      if (s0 > 3.0)
+                        {
+                          use_first = false;
+                          for (int a = 0; a < PCS_NA; a++)
+                            {
+                              const int cv = (int) ceil (sh.mean[g][a] * s0);
+                              sh.al[g][a] = (1 > cv) ? 1 : cv;
+                            }
+                        }
+                    }
+                  if (use_first)
+                    for (int a = 0; a < PCS_NA; a++)
+                      sh.al[g][a] = sh.first[g][a];
+                }
+              pcs_sync ();
+              // ---- check_alpha_sanity (pecaller.c:2076-2188), lane = genotype row; rows only read the reference base's row
+              //      of the fractions, which no row modifies
+              if (lane < G)
+                {
+                  int tt = 0;
+                  for (int a = 0; a < PCS_NA; a++)
+                    tt += sh.al[lane][a];
+                  for (int a = 0; a < PCS_NA; a++)
+                    sh.fr[lane][a] = (double) sh.al[lane][a] / (double) tt;
+                }
+              pcs_sync ();
+              if (lane < G)
+                {
+                  const int i = lane;
+                  bool reset = false;
+                  if (i < 4)
+                    {
+                      int mxi = 0;
+                      for (int a = 1; a < PCS_NA; a++)
+                        if (sh.al[i][a] > sh.al[i][mxi])
+                          mxi = a;
+                      if (mxi != i)
+                        reset = true;
+                      else
+                        for (int a = 0; a < PCS_NA; a++)
+                          if (a != i && sh.fr[i][a] > 0.3)
+                            reset = true;
+                    }
+                  else if (i == 4)
+                    reset = sh.fr[4][4] - sh.fr[dom][4] < 0.5;
+                  else if (i == 5)
+                    reset = sh.fr[5][5] - sh.fr[dom][5] < -0.1;
+                  else
+                    {
+                      int a, b;
+                      pcs_het (i, a, b, dom);
+                      if (b == dom)
+                        {
+                          const int t = a;
+                          a = b;
+                          b = t;
+                        }
+                      if (sh.fr[i][b] - sh.fr[dom][b] < 0.25)
+                        reset = true;
+                      else
+                        {
+                          double fa = sh.fr[i][a], fb = sh.fr[i][b];
+                          if (dom == a)
+                            fa -= 0.05;
+                          else
+                            fa -= (sh.fr[dom][a] > 0.05) ? sh.fr[dom][a] : 0.05;
+                          fb -= (0.05 > sh.fr[dom][b]) ? 0.05 : sh.fr[dom][b];
+                          for (int q = 0; q < PCS_NA && !reset; q++)
+                            if (q != a && q != b)
+                              if (sh.fr[i][q] > fa || sh.fr[i][q] > fb)
+                                reset = true;
+                        }
+                    }
+                  if (reset)
+                    for (int a = 0; a < PCS_NA; a++)
+                      sh.al[i][a] = sh.first[i][a];
+                  double scale = sh.al[i][0];
+                  for (int a = 1; a < PCS_NA; a++)
+                    scale += sh.al[i][a];
+                  scale = (double) normal_factor / scale;
+                  for (int a = 0; a < PCS_NA; a++)
+                    if (sh.al[i][a] > 1)
+                      {
+                        const int cv = (int) ceil (scale * (double) sh.al[i][a]);
+                        sh.al[i][a] = (1 > cv) ? 1 : cv;
+                      }
+                }
+              pcs_sync ();
+            }
+          initial_call = final_call;
+        }
+      // ---- calls and site classification (pecaller.c:1565-1636)
+      const double low_base = (8 > 0.4 * average_depth) ? 8 : 0.4 * average_depth;
+      int ac6[PCS_NA] = { 0, 0, 0, 0, 0, 0 }, on_target = 0, off_target = 0, not_low = 0;
+      const bool called = lane < N && tot > md;
+      if (called && final_p >= P.threshold)
+        {
+#pragma unroll
+          for (int a = 0; a < PCS_NA; a++)
+            {
+              const int k = pcs_ac (dom, final_call, a, P.haploid);
+              if (k)
+                {
+                  ac6[a] = k;
+                  on_target += r[a];
+                }
+              else if (a != dom || final_call != PCS_NA - 1)
+                off_target += r[a];
+            }
+          if (tot > low_base && final_call != dom)
+            not_low = 1;
+        }
+      for (int o = 32; o; o >>= 1)
+        {
+#pragma unroll
+          for (int a = 0; a < PCS_NA; a++)
+            ac6[a] += __shfl_xor (ac6[a], o);
+          on_target += __shfl_xor (on_target, o);
+          off_target += __shfl_xor (off_target, o);
+          not_low += __shfl_xor (not_low, o);
+        }
+      if (lane < N)
+        {
+          call[site * N + lane] = called ? (int8_t) final_call : (int8_t) PCS_NG;
+          post_out[site * N + lane] = called ? final_p : 1.0;
+        }
+      int n_all = 0, isdel = 0, isins = 0, type = 0;
+#pragma unroll
+      for (int a = 0; a < PCS_NA; a++)
+        if (ac6[a] > 0)
+          {
+            n_all++;
+            if (a == 4)
+              isdel = 1;
+            else if (a == 5)
+              isins = 1;
+            else if (a != dom)
+              type = 1;
+          }
+      int dom_count = 0;
+#pragma unroll
+      for (int a = 0; a < PCS_NA; a++)
+        dom_count = (a == dom) ? ac6[a] : dom_count;
+      if (n_all > 1 || (n_all > 0 && dom_count < 1))
+        {
+          if ((double) off_target / (double) (on_target + off_target) > 0.15)
+            type = 6;
+          else if (n_all > 2)
+            type = 5;
+          else if (not_low > 0)
+            type = isdel ? 2 : isins ? 3 : 1;
+          else
+            type = 4;
+        }
+      int mine = 0;
+#pragma unroll
+      for (int a = 0; a < PCS_NA; a++)
+        mine = (lane == a) ? ac6[a] : mine;
+      if (lane < PCS_NA)
+        allele_count[site * PCS_NA + lane] = mine;
+      if (lane == 0)
+        {
+          type_out[site] = (int8_t) type;
+          n_pass[site] = (int8_t) pass;
+        }
+      pcs_sync ();
+    }
+}

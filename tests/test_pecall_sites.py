@@ -30,3 +30,59 @@ def test_site_oracle_matches_reference_text():
     assert n_base == len(f["base_rows"]) and n_snp == len(f["snp_rows"]), (n_base, len(f["base_rows"]), n_snp, len(f["snp_rows"]))
     assert not bad, bad[:3]
     assert npass.max() >= 2                      # the fixture exercises the alpha re-estimation
+
+
+@pytest.mark.gpu
+def test_gpu_site_caller_matches_reference_text_and_oracle():
+    from pecaller_amd.pecall import PecallDev
+    f = fx.load()
+    dev = PecallDev(0)
+    call, p, typ, ac, npass = dev.call_sites(f["reads"], f["dom"])
+    ocall, op, otyp, oac, onpass = oracle_py.call_sites(f["reads"], f["dom"])
+    assert np.array_equal(call, ocall)
+    assert np.array_equal(typ, otyp) and np.array_equal(ac, oac) and np.array_equal(npass, onpass)
+    assert np.max(np.abs(p - op)) <= 1e-6          # north_star: genotype posteriors within 1e-6
+    bad = []
+    for i, pos in enumerate(f["pos"]):
+        pos1 = int(pos) + 1
+        exp = f["base_rows"].get(pos1)
+        if exp is not None and fx.base_row("chr1", pos1, chr(f["ref"][i]), call[i], p[i]) != exp:
+            bad.append((pos1, exp))
+    # %g prints six significant digits: a posterior may differ from the CPU's in the last bits (device exp / pow)
+    assert len(bad) <= 2, bad[:3]
+    dev.close()
+
+
+@pytest.mark.gpu
+def test_gpu_site_caller_64_samples_and_haploid():
+    """BASELINE config 5's width (64 samples), and the haploid mode, against the oracle on seeded columns"""
+    from pecaller_amd.pecall import PecallDev
+    rng = np.random.default_rng(5)
+    n_sites, n = 600, 64
+    dom = rng.integers(0, 4, n_sites).astype(np.uint8)
+    dom[::97] = 14                                   # reference N: skipped
+    reads = np.zeros((n_sites, n, 6), np.uint16)
+    for s in range(n_sites):
+        var = rng.random() < 0.25
+        q = rng.uniform(0.02, 0.5)
+        alt = int(rng.integers(0, 6))
+        for i in range(n):
+            d = int(rng.poisson(30 if i % 9 else 4))
+            r = int(dom[s]) if dom[s] < 4 else 0
+            g = (alt if (var and rng.random() < q) else r, alt if (var and rng.random() < q) else r)
+            for _ in range(d):
+                al = g[int(rng.integers(0, 2))]
+                if rng.random() < 0.004:
+                    al = int(rng.integers(0, 4))
+                if al == 5:
+                    reads[s, i, r] += 1
+                reads[s, i, al] += 1
+    dev = PecallDev(0)
+    for hap in (False, True):
+        got = dev.call_sites(reads, dom, haploid=hap)
+        exp = oracle_py.call_sites(reads, dom, haploid=hap)
+        assert np.array_equal(got[0], exp[0]), ("calls", hap)
+        assert np.max(np.abs(got[1] - exp[1])) <= 1e-6
+        for a, b in zip(got[2:], exp[2:]):
+            assert np.array_equal(a, b)
+    dev.close()
