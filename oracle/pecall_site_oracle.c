@@ -59,6 +59,7 @@ typedef struct
   int8_t *calls_cur, *calls_nxt;
   int cap_cur, cap_nxt;
   int *idx, *tmp;
+  int max_list;                 /* longest list fill_config_probs has built (test coverage statistic) */
 } Caller;
 
 static void
@@ -180,6 +181,12 @@ ora_caller_destroy (void *p)
   free (c->idx);
   free (c->tmp);
   free (c);
+}
+
+int
+ora_caller_max_list (void *p)
+{
+  return ((Caller *) p)->max_list;
 }
 
 /* the caller's tables, for handing to the device implementation under test */
@@ -389,6 +396,8 @@ expand_cfgs (Caller * c, int n, int who, int ref, double thres, const int *reads
     }
   for (int i = 0; i < newcount; i++)
     cfg_copy (&cn[i], &nw[i], c->indiv);
+  if (newcount > c->max_list)
+    c->max_list = newcount;
   return newcount;
 }
 

@@ -150,6 +150,7 @@ def pecall_lib():
         L.ora_caller_create.restype = C.c_void_p
         L.ora_caller_create.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double]
         L.ora_caller_destroy.argtypes = [C.c_void_p]
+        L.ora_caller_max_list.argtypes = [C.c_void_p]
         L.ora_call_sites.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p]
         _plib = L
@@ -184,6 +185,7 @@ def call_sites(reads, dom, threshold=0.95, theta=0.001, haploid=False, chrom_y=N
     h = L.ora_caller_create(indiv, int(haploid), float(threshold), float(theta))
     try:
         L.ora_call_sites(h, _p(reads), _p(dom), _p(cy), n_sites, _p(call), _p(p), _p(typ), _p(ac), _p(npass))
+        call_sites.max_list = L.ora_caller_max_list(h)      # longest configuration list seen (coverage statistic)
     finally:
         L.ora_caller_destroy(h)
     return call, p, typ, ac, npass
