@@ -51,6 +51,9 @@ def main():
     q = rng.uniform(0.05, 0.6, n_sites)
     alt = rng.integers(0, 6, n_sites)
     reads = np.zeros((n_sites, n_samp, 6), np.uint16)
+    # special stretches: 3000-3300 a second alternative allele in some samples (MULTIALLELIC), 3300-3600 a fifth of the reads
+    # replaced by random bases (MESS), 3600-3900 variants private to one sample sequenced at depth ~9 (LOW)
+    alt2 = (alt + 1 + rng.integers(0, 3, n_sites)) % 4
     for i in range(n_sites):
         r = code.get(seq[first + i])
         if r is None:
@@ -62,10 +65,20 @@ def main():
             g = (r, r)
             if is_var[i]:
                 g = tuple(int(alt[i]) if rng.random() < q[i] else r for _ in range(2))
+            err = 0.004
+            if 3000 <= i < 3300 and i % 5 == 0:
+                g = tuple(int([alt[i] % 4, alt2[i], r][int(rng.integers(0, 3))]) for _ in range(2))
+            if 3300 <= i < 3600 and i % 7 == 0:
+                err = 0.2
+                g = (r, int(alt[i]) % 4) if s % 2 else (r, r)
+            if 3600 <= i < 3900 and i % 6 == 0:
+                g = (int(alt[i]) % 4, int(alt[i]) % 4) if s == 6 else (r, r)
+                if s == 6:
+                    d = int(rng.poisson(9))
             cnt = np.zeros(6, np.int64)
             for _ in range(d):
                 al = g[int(rng.integers(0, 2))]
-                if rng.random() < 0.004:
+                if rng.random() < err:
                     al = int(rng.integers(0, 4))
                 if al == 5:                    # an insertion is counted on top of the base it follows
                     cnt[r] += 1
