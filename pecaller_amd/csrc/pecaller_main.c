@@ -1,0 +1,453 @@
+/*
+ * pecaller_main.c -- host program (plain C) with the command line and on-disk formats of the reference's pecaller,
+ * calling the MI355X per-site caller through the C-ABI of include/pemap_hip.h (pecall_dev_call_sites).
+ *
+ *   pecaller_hip pileup_ext sdx no_files outfile Prob_to_call theta haploid[y,n] no_threads use_pedfile[n]
+ *
+ * (src/pecaller.c:227-257.)  It runs in the directory that holds the binary pileups, like the reference: every file
+ * whose name contains `pileup_ext` is a sample, in directory order, named by its file name up to the first '.'
+ * (pecaller.c:495-515).  Outputs, in the reference's formats: <outfile>.base.gz (a call and a posterior per sample and
+ * column), <outfile>.snp and <outfile>.piles.gz (the variant columns), <outfile>.dist (coverage statistics).
+ *
+ * What replaces what: the dispatcher loop of main (pecaller.c:865-923: the 64-way merge of the pileup streams by
+ * position, the reference base and contig of the column) stays here on the host and fills tiles of columns; the worker
+ * threads' call_single_base (1207-1691) is one pecall_dev_call_sites per tile; the worker's sprintf block (1564-1690) is
+ * emit_rows below.  Rows are written in genome order (the reference's order depends on thread timing).
+ *
+ * Not supported (an error, not a silent difference): a pedigree (use_pedfile = y) and the BED guide mode (argc 11 / 13),
+ * more than 64 samples.  `no_threads` is validated and unused.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ctype.h>
+#include <stdint.h>
+#include <dirent.h>
+#include <errno.h>
+#include <math.h>
+#include <zlib.h>
+#include "../../include/pemap_hip.h"
+
+#define NA 6
+#define MAX_DIST 501            /* pecaller.c:222 */
+#define TILE (1 << 18)          /* columns per device call */
+
+static void
+die (const char *fmt, const char *arg)
+{
+  printf (fmt, arg);
+  printf ("\n");
+  exit (1);
+}
+
+static const char GEN[16] = "ACGTDIMRWSYKEHN";  /* int_to_gen, pecaller.c:2910-2943 */
+static const char *TYPE_NAME[7] = { "", "SNP", "DEL", "INS", "LOW", "MULTIALLELIC", "MESS" };  /* pecaller.c:523-528 */
+
+static int
+gen_to_int (char c)             /* pecaller.c:2869-2907: an unknown letter ends the run */
+{
+  const char *p = c ? strchr (GEN, c) : NULL;
+  if (!p)
+    {
+      printf ("\n This is impossible\n Illegal character in gen_to_int %c\n\n", c);
+      exit (1);
+    }
+  return (int) (p - GEN);
+}
+
+/* pecaller's own find_chrom, pecaller.c:1793-1816 (not pemapper's) */
+static int
+find_chrom (const unsigned int *pos, int first, int last, int try, unsigned this)
+{
+  if (first == last)
+    return first;
+  if (first >= try)
+    return this > pos[first] ? first + 1 : first;
+  if (last <= try)
+    return last;
+  if (pos[try] < this)
+    return find_chrom (pos, try, last, (last + try) / 2, this);
+  if (pos[try] > this)
+    return find_chrom (pos, first, try, (try + first) / 2, this);
+  return try + 1;
+}
+
+typedef struct
+{
+  gzFile f;
+  unsigned int cur;             /* position of the pending record, 0 = exhausted (pecaller.c:840-849) */
+  unsigned short data[NA];
+  char name[256];
+  /* .dist statistics, pecaller.c:884-889, 1077-1140 */
+  double mean;
+  unsigned int base_count, max_coverage, counts[MAX_DIST];
+} sample_t;
+
+/* the pending record consumed: read the next one (pecaller.c:891-907) */
+static void
+advance (sample_t * s, int *running)
+{
+  if (!gzeof (s->f))
+    {
+      int n = gzread (s->f, &s->cur, sizeof (unsigned int));
+      if (n != 0)
+        gzread (s->f, s->data, sizeof (unsigned short) * NA);
+      else
+        {
+          s->cur = 0;
+          (*running)--;
+        }
+    }
+  else
+    {
+      s->cur = 0;
+      (*running)--;
+    }
+}
+
+typedef struct
+{
+  /* one tile of columns */
+  uint16_t *reads;              /* [TILE][indiv][6] */
+  uint8_t *ref_base, *chrom_y;
+  char *ref_char;
+  int *contig;
+  unsigned int *pos;
+  int8_t *call, *type;
+  double *post;
+  int32_t *ac;
+  long n;
+} tile_t;
+
+static void
+emit_rows (const tile_t * t, int indiv, char **contig_names, gzFile outfile, FILE * snpfile, gzFile pilefile)
+{
+  char minor[80], am_count[80], tmp[64];
+  for (long s = 0; s < t->n; s++)
+    {
+      if (t->type[s] < 0)
+        continue;               /* reference base not A/C/G/T: the worker skips the column (pecaller.c:1208, 1718) */
+      const char *frag = contig_names[t->contig[s]];
+      const int8_t *call = t->call + s * indiv;
+      const double *p = t->post + s * indiv;
+      gzprintf (outfile, "\n%s\t%d\t%c", frag, (int) t->pos[s], t->ref_char[s]);
+      for (int i = 0; i < indiv; i++)
+        if (call[i] < 14)
+          gzprintf (outfile, "\t%c\t%g", GEN[call[i]], p[i]);
+        else
+          gzprintf (outfile, "\tN\t1");
+      if (t->type[s] == 0)
+        continue;
+      minor[0] = am_count[0] = '\0';
+      for (int a = 0; a < NA; a++)
+        if (t->ac[s * NA + a] > 0)
+          {
+            sprintf (tmp, "%c,", GEN[a]);
+            strcat (minor, tmp);
+            sprintf (tmp, "%d,", t->ac[s * NA + a]);
+            strcat (am_count, tmp);
+          }
+      if (minor[0])
+        {
+          minor[strlen (minor) - 1] = '\0';
+          am_count[strlen (am_count) - 1] = '\0';
+        }
+      fprintf (snpfile, "\n%s\t%d\t%c\t%s\t%s\t%s", frag, (int) t->pos[s], t->ref_char[s], minor, am_count, TYPE_NAME[t->type[s]]);
+      gzprintf (pilefile, "\n%s\t%d\t%c", frag, (int) t->pos[s], t->ref_char[s]);
+      for (int i = 0; i < indiv; i++)
+        {
+          fprintf (snpfile, "\t%c\t%g", GEN[call[i]], p[i]);
+          const uint16_t *r = t->reads + ((size_t) s * indiv + i) * NA;
+          for (int a = 0; a < NA; a++)
+            gzprintf (pilefile, "\t%d", (int) r[a]);
+        }
+    }
+}
+
+int
+main (int argc, char *argv[])
+{
+  char ss[4096], sdxname[4096];
+  if (argc < 10 || argc > 13)
+    {
+      printf
+        ("\n Usage %s pileup_extension sdx_file no_files outfile Prob_to_call theta haploid[y,n] no_threads use_pedfile[y,n] [pedfilename] [denovo_mutation_rate] [guide_file_bed_format]\n",
+         argv[0]);
+      exit (1);
+    }
+  int no_threads = atoi (argv[8]);
+  if (no_threads < 2 || no_threads > 200)
+    {
+      printf ("\n Number of threads is limited to 2 to 200.   You entered %d \n\n", no_threads);
+      exit (1);
+    }
+  if (strchr (argv[9], 'Y') || strchr (argv[9], 'y'))
+    die ("\n pecaller_hip: a pedigree (use_pedfile = %s) is not supported by the device caller", argv[9]);
+  if (argc != 10)
+    die ("\n pecaller_hip: the BED guide mode (%s) is not supported", argv[argc - 1]);
+  const double threshold = atof (argv[5]), theta = atof (argv[6]);
+  if (theta < 1e-10 || theta > 0.5)
+    {
+      printf ("\n Encountered impossible value for theta = %g \n", theta);
+      exit (1);
+    }
+  const int haploid = (strchr (argv[7], 'Y') || strchr (argv[7], 'y')) ? 1 : 0;
+
+  gzFile outfile, pilefile;
+  FILE *snpfile, *distfile;
+  sprintf (ss, "%s.base.gz", argv[4]);
+  if (!(outfile = gzopen (ss, "w")))
+    die ("\n Can not open file %s", ss);
+  gzbuffer (outfile, 131072);
+  sprintf (ss, "%s.snp", argv[4]);
+  if (!(snpfile = fopen (ss, "w")))
+    die ("\n Can not open file %s for writing", ss);
+  sprintf (ss, "%s.dist", argv[4]);
+  if (!(distfile = fopen (ss, "w")))
+    die ("\n Can not open file %s for writing", ss);
+  sprintf (ss, "%s.piles.gz", argv[4]);
+  if (!(pilefile = gzopen (ss, "w")))
+    die ("\n Can not open file %s for writing", ss);
+  gzbuffer (pilefile, 131072);
+
+  /* ---- .sdx: contig ends in .seq coordinates (length + 15 each), names, the chrY flag (pecaller.c:447-483) */
+  strcpy (sdxname, argv[2]);
+  FILE *sfile = fopen (sdxname, "r");
+  if (!sfile)
+    die ("\n Can not open file %s", sdxname);
+  if (strstr (sdxname, ".sdx"))
+    for (int i = (int) strlen (sdxname) - 1; i > 0; i--)
+      if (sdxname[i] == '.')
+        {
+          sdxname[i] = '\0';
+          break;
+        }
+  if (!fgets (ss, 256, sfile))
+    die ("\n Empty file %s", argv[2]);
+  const int no_contigs = atoi (ss);
+  unsigned int *frag_store = (unsigned int *) calloc (no_contigs + 2, sizeof (unsigned int)), *frag_pos = frag_store + 1;
+  char **contig_names = (char **) calloc (no_contigs + 1, sizeof (char *));
+  uint8_t *is_chry = (uint8_t *) calloc (no_contigs + 1, 1);
+  frag_pos[-1] = 0;
+  for (int i = 0; i < no_contigs; i++)
+    {
+      if (!fgets (ss, 1024, sfile))
+        die ("\n Short file %s", argv[2]);
+      char *tok = strtok (ss, "\t \n");
+      frag_pos[i] = (unsigned int) atoi (tok) + 15 + frag_pos[i - 1];
+      tok = strtok (NULL, "\t \n");
+      contig_names[i] = strdup (tok);
+      char low[1024];
+      strcpy (low, tok);
+      char *pre = strtok (low, ":_- \n");
+      for (char *q = pre; q && *q; q++)
+        *q = (char) tolower (*q);
+      is_chry[i] = pre && strcmp (pre, "chry") == 0;
+    }
+  fclose (sfile);
+
+  /* ---- the reference letters: the whole .seq in memory (the reference pages 50 MB windows through gzseek, 1753-1789) */
+  sprintf (ss, "%s.seq", sdxname);
+  gzFile reffile = gzopen (ss, "r");
+  if (!reffile)
+    die ("\n Can not open file %s for reading", ss);
+  gzbuffer (reffile, 1 << 22);
+  const size_t gsize = frag_pos[no_contigs - 1];
+  char *genome = (char *) calloc (gsize + 1, 1);
+  for (size_t got = 0; got < gsize;)
+    {
+      int n = gzread (reffile, genome + got, (unsigned) ((gsize - got) > (1u << 30) ? (1u << 30) : (gsize - got)));
+      if (n <= 0)
+        break;
+      got += (size_t) n;
+    }
+  gzclose (reffile);
+
+  /* ---- the samples: directory order (pecaller.c:486-520) */
+  int no_files = atoi (argv[3]);
+  sample_t *sm = (sample_t *) calloc (no_files + 1, sizeof (sample_t));
+  DIR *dir = opendir (".");
+  if (!dir)
+    {
+      fprintf (stderr, "%s %d: opendir() failed (%s)\n", __FILE__, __LINE__, strerror (errno));
+      exit (-1);
+    }
+  int found = 0;
+  for (struct dirent * de = readdir (dir); de != NULL && found <= no_files; de = readdir (dir))
+    if (strstr (de->d_name, argv[1]) != NULL)
+      {
+        if (found == no_files)
+          {
+            found++;
+            break;
+          }
+        if (!(sm[found].f = gzopen (de->d_name, "rb")))
+          die ("\n Can not open file %s which should contain pileup information", de->d_name);
+        gzbuffer (sm[found].f, 1 << 20);
+        strncpy (ss, de->d_name, sizeof ss - 1);
+        char *tok = strtok (ss, "\n.\t ");
+        strncpy (sm[found].name, tok ? tok : "", sizeof sm[found].name - 1);
+        found++;
+      }
+  closedir (dir);
+  if (found > no_files)
+    die ("%s", "\n Found more files than you specified \n");
+  no_files = found;
+  const int indiv = no_files;
+  printf ("\n Found a total of %d individuals\n\n", indiv);
+  if (indiv < 1 || indiv > 64)
+    die ("\n pecaller_hip: %s samples; the device caller takes 1 to 64", argv[3]);
+
+  pecall_dev *pc;
+  if (pecall_dev_create (&pc, getenv ("PEMAP_DEVICE") ? atoi (getenv ("PEMAP_DEVICE")) : 0))
+    die ("\n pecaller_hip: %s", pecall_dev_last_error (NULL));
+
+  int running = no_files;
+  for (int i = 0; i < no_files; i++)
+    {
+      int n = gzread (sm[i].f, &sm[i].cur, sizeof (unsigned int));
+      if (n != 0)
+        gzread (sm[i].f, sm[i].data, sizeof (unsigned short) * NA);
+      else
+        sm[i].cur = 0;
+      if (sm[i].cur == 0)
+        running--;
+    }
+  fprintf (snpfile, "Fragment\tPosition\tReference\tAlleles\tAllele_Counts\tType");
+  gzprintf (outfile, "Fragment\tPosition\tReference");
+  gzprintf (pilefile, "Fragment\tPosition\tReference");
+  for (int i = 0; i < indiv; i++)
+    {
+      fprintf (snpfile, "\t%s\t", sm[i].name);
+      gzprintf (outfile, "\t%s\t", sm[i].name);
+      gzprintf (pilefile, "\t%s\t\t\t\t\t", sm[i].name);
+    }
+
+  tile_t t;
+  t.reads = (uint16_t *) malloc ((size_t) TILE * indiv * NA * sizeof (uint16_t));
+  t.ref_base = (uint8_t *) malloc (TILE);
+  t.chrom_y = (uint8_t *) malloc (TILE);
+  t.ref_char = (char *) malloc (TILE);
+  t.contig = (int *) malloc (TILE * sizeof (int));
+  t.pos = (unsigned int *) malloc (TILE * sizeof (unsigned int));
+  t.call = (int8_t *) malloc ((size_t) TILE * indiv);
+  t.post = (double *) malloc ((size_t) TILE * indiv * sizeof (double));
+  t.type = (int8_t *) malloc (TILE);
+  t.ac = (int32_t *) malloc ((size_t) TILE * NA * sizeof (int32_t));
+  t.n = 0;
+  unsigned int tot_bases = 0;
+  const int start_chrom = (no_contigs - 1) / 2 > 0 ? (no_contigs - 1) / 2 : 0;
+  while (running > 0 || t.n > 0)
+    {
+      if (running > 0)
+        {
+          /* find_lowest, pecaller.c:1820-1833 */
+          unsigned int lowest = 0;
+          int i = 0;
+          while (lowest < 1 && i < no_files)
+            lowest = sm[i++].cur;
+          for (; i < no_files; i++)
+            if (sm[i].cur > 0 && sm[i].cur < lowest)
+              lowest = sm[i].cur;
+          const int which = find_chrom (frag_pos, 0, no_contigs - 1, start_chrom, lowest);
+          const char ref = lowest < gsize ? genome[lowest] : '\0';
+          const long s = t.n++;
+          t.ref_char[s] = ref;
+          t.ref_base[s] = (uint8_t) gen_to_int (ref);
+          t.contig[s] = which;
+          t.pos[s] = 1 + lowest - frag_pos[which - 1];
+          t.chrom_y[s] = is_chry[which];
+          tot_bases++;
+          uint16_t *col = t.reads + (size_t) s * indiv * NA;
+          for (i = 0; i < no_files; i++)
+            if (sm[i].cur == lowest)
+              {
+                unsigned int cov = 0;
+                for (int a = 0; a < NA; a++)
+                  {
+                    col[i * NA + a] = sm[i].data[a];
+                    cov += sm[i].data[a];
+                  }
+                sm[i].mean += (double) cov;
+                if (cov > sm[i].max_coverage)
+                  sm[i].max_coverage = cov;
+                sm[i].counts[cov < MAX_DIST - 1 ? cov : MAX_DIST - 1]++;
+                sm[i].base_count++;
+                advance (&sm[i], &running);
+              }
+            else
+              for (int a = 0; a < NA; a++)
+                col[i * NA + a] = 0;
+        }
+      if (t.n == TILE || (running <= 0 && t.n > 0))
+        {
+          if (pecall_dev_call_sites (pc, t.reads, t.ref_base, t.chrom_y, t.n, indiv, haploid, threshold, theta, t.call, t.post, t.type, t.ac, NULL))
+            die ("\n pecaller_hip: %s", pecall_dev_last_error (pc));
+          emit_rows (&t, indiv, contig_names, outfile, snpfile, pilefile);
+          t.n = 0;
+        }
+    }
+
+  /* ---- <outfile>.dist, pecaller.c:1077-1140 */
+  unsigned int *tot_1x = (unsigned int *) calloc (no_files, sizeof (unsigned int)), *tot_8x = (unsigned int *) calloc (no_files, sizeof (unsigned int));
+  int *median = (int *) calloc (no_files, sizeof (int));
+  for (int i = 0; i < no_files; i++)
+    {
+      if (sm[i].base_count > 0)
+        sm[i].mean /= (double) sm[i].base_count;
+      for (int j = 8; j < MAX_DIST; j++)
+        tot_8x[i] += sm[i].counts[j];
+      tot_1x[i] = tot_8x[i];
+      for (int j = 1; j < 8; j++)
+        tot_1x[i] += sm[i].counts[j];
+      sm[i].counts[0] = tot_bases - tot_1x[i];
+      long median_count = sm[i].counts[0];
+      const long stop = tot_bases / 2;
+      for (int j = 1; j < MAX_DIST; j++)
+        {
+          if (median_count > stop)
+            break;
+          median_count += sm[i].counts[++median[i]];
+        }
+    }
+  fprintf (distfile, "Category");
+  for (int i = 0; i < no_files; i++)
+    fprintf (distfile, "\t%s", sm[i].name);
+  fprintf (distfile, "\nTotal Number of bases in target");
+  for (int i = 0; i < no_files; i++)
+    fprintf (distfile, "\t%u", tot_bases);
+  fprintf (distfile, "\nTotal Number of bases with at least 1x coverage");
+  for (int i = 0; i < no_files; i++)
+    fprintf (distfile, "\t%u", tot_1x[i]);
+  fprintf (distfile, "\nTotal Number of bases with at least 8x coverage");
+  for (int i = 0; i < no_files; i++)
+    fprintf (distfile, "\t%u", tot_8x[i]);
+  fprintf (distfile, "\nMean depth of coverage");
+  for (int i = 0; i < no_files; i++)
+    fprintf (distfile, "\t%g", sm[i].mean);
+  fprintf (distfile, "\nMedian depth of coverage");
+  for (int i = 0; i < no_files; i++)
+    fprintf (distfile, "\t%d", median[i]);
+  fprintf (distfile, "\nMaximum depth of coverage");
+  for (int i = 0; i < no_files; i++)
+    fprintf (distfile, "\t%d", (int) sm[i].max_coverage);
+  fprintf (distfile, "\n\nDepth");
+  for (int j = 0; j < MAX_DIST - 1; j++)
+    {
+      fprintf (distfile, "\n%d", j);
+      for (int i = 0; i < no_files; i++)
+        fprintf (distfile, "\t%u", sm[i].counts[j]);
+    }
+  fprintf (distfile, "\n%d+", MAX_DIST - 1);
+  for (int i = 0; i < no_files; i++)
+    fprintf (distfile, "\t%u", sm[i].counts[MAX_DIST - 1]);
+  fprintf (distfile, "\n");
+  fclose (distfile);
+  fclose (snpfile);
+  gzclose (outfile);
+  gzclose (pilefile);
+  for (int i = 0; i < no_files; i++)
+    gzclose (sm[i].f);
+  pecall_dev_destroy (pc);
+  return 0;
+}

@@ -7,6 +7,7 @@ one worker thread on synthetic binary pileups of 8 samples and stores, under tes
   pecall_sites.npz          inputs: reads[site][sample][6] (u16), pos[site] (0-based index into .seq), sample names
   pecall_sites.base.txt.gz  the reference's <out>.base.gz rows (one per site it processed), sorted
   pecall_sites.snp.txt      the reference's <out>.snp rows, sorted
+  pecall_sites.dist.txt     the reference's <out>.dist (coverage statistics of the dispatcher; includes the 40 padding columns)
 
 Only data is stored: inputs and the text the reference printed.
 
@@ -113,8 +114,9 @@ def main():
         f.write(hdr + "\n" + "\n".join(keep_rows) + "\n")
     with open(os.path.join(HERE, "pecall_sites.snp.txt"), "w") as f:
         f.write(snp[0] + "\n" + "\n".join(keep_snp) + "\n")
+    shutil.copy(os.path.join(rundir, "out.dist"), os.path.join(HERE, "pecall_sites.dist.txt"))
     np.savez_compressed(os.path.join(HERE, "pecall_sites.npz"), reads=reads, pos=pos.astype(np.uint32), names=np.array(names),
-                        columns=np.array(cols))
+                        columns=np.array(cols), pad=np.array([pad]))
     print("sites", n_sites, "base rows", len(keep_rows), "snp rows", len(keep_snp), "columns", cols)
 
 

@@ -76,6 +76,10 @@ def test_host_program_builds():
     assert os.path.exists(exe)
     r = subprocess.run([exe, "o", "x.sdx", "q", "f"], stdout=subprocess.PIPE)
     assert r.returncode == 1 and b"Usage" in r.stdout      # pemapper.c:226-232
+    exe = os.path.join(ROOT, "pecaller_amd", "pecaller_hip")
+    assert os.path.exists(exe)
+    r = subprocess.run([exe, "pileup", "x.sdx"], stdout=subprocess.PIPE)
+    assert r.returncode == 1 and b"Usage" in r.stdout      # pecaller.c:251-257
 
 
 def test_shard_ranges_cover_without_overlap():

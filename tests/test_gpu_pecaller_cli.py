@@ -1,0 +1,81 @@
+"""The C host program pecaller_amd/pecaller_hip run with the reference's pecaller command line on the site-caller fixture:
+its FILES against the oracle (for the column order the directory gave) and, where the order is the fixture's, the reference's text."""
+import gzip
+import os
+import shutil
+import struct
+import subprocess
+import numpy as np
+import pytest
+import oracle_py
+import pecall_sites_fixture as fx
+import refio
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "pecaller_amd", "pecaller_hip")
+
+
+def test_pecaller_cli_outputs(tmp_path):
+    assert os.path.exists(EXE), "build with make -C pecaller_amd/csrc"
+    z = np.load(os.path.join(fx.GOLD, "pecall_sites.npz"))
+    names = [str(x) for x in z["names"]]
+    reads, pos, pad = z["reads"], z["pos"], int(z["pad"][0])
+    _, seqs = refio.read_fasta(os.path.join(fx.GOLD, "g1.fa.gz"))
+    shutil.copy(os.path.join(fx.GOLD, "g1.sdx"), tmp_path / "g1.sdx")
+    with gzip.open(tmp_path / "g1.seq", "wb", compresslevel=1) as f:
+        f.write(np.concatenate(seqs).tobytes())
+    run = tmp_path / "run"
+    run.mkdir()
+    for s, nm in enumerate(names):              # the generator's files, padding columns included (the .dist counts them)
+        recs = [struct.pack("<I6H", int(pos[i]), *[int(x) for x in reads[i, s]]) for i in range(len(pos)) if reads[i, s].sum() > 0]
+        recs += [struct.pack("<I6H", int(pos[-1]) + 1 + k, 20, 0, 0, 0, 0, 0) for k in range(pad)]
+        with gzip.open(run / ("%s.pileup.gz" % nm), "wb", compresslevel=1) as f:
+            f.write(b"".join(recs))
+    subprocess.check_call([EXE, "pileup", str(tmp_path / "g1.sdx"), "20", "out", "0.95", "0.001", "n", "2", "n"], cwd=run, stdout=subprocess.DEVNULL)
+    base = gzip.open(run / "out.base.gz", "rt").read().split("\n")
+    cols = [c for c in base[0].split("\t")[3:] if c]
+    assert sorted(cols) == sorted(names)
+    perm = [names.index(c) for c in cols]
+    f = fx.load()
+    ref_order = [str(x) for x in z["columns"]]
+    # ---- against the oracle in the order this directory gave
+    r = reads[:, perm, :]
+    call, p, typ, ac, _ = oracle_py.call_sites(r, f["dom"])
+    rows = {int(x.split("\t")[1]): x for x in base[1:] if x}
+    snp = open(run / "out.snp").read().split("\n")
+    srows = {int(x.split("\t")[1]): x for x in snp[1:] if x}
+    n_base = n_snp = 0
+    for i, q in enumerate(pos):
+        pos1 = int(q) + 1
+        if f["dom"][i] > 3 or r[i].sum() == 0:
+            assert pos1 not in rows
+            continue
+        n_base += 1
+        assert rows[pos1] == fx.base_row("chr1", pos1, chr(f["ref"][i]), call[i], p[i]), pos1
+        if typ[i] > 0:
+            n_snp += 1
+            assert srows[pos1] == fx.snp_row("chr1", pos1, chr(f["ref"][i]), call[i], p[i], typ[i], ac[i]), pos1
+        else:
+            assert pos1 not in srows
+    assert n_base == len(f["base_rows"]) and n_snp > 100
+    piles = gzip.open(run / "out.piles.gz", "rt").read().split("\n")
+    prow = {int(x.split("\t")[1]): x for x in piles[1:] if x}
+    assert set(prow) == set(srows)
+    k = next(iter(sorted(prow)))
+    i = int(k - 1 - int(pos[0]))
+    assert prow[k] == "chr1\t%d\t%s" % (k, chr(f["ref"][i])) + "".join("\t%d" % v for v in r[i].ravel())
+    # ---- the dispatcher's statistics do not depend on the callers: the reference's .dist, column for column
+    got = [x.split("\t") for x in open(run / "out.dist").read().split("\n")]
+    exp = [x.split("\t") for x in open(os.path.join(fx.GOLD, "pecall_sites.dist.txt")).read().split("\n")]
+    assert len(got) == len(exp)
+    for g, e in zip(got, exp):
+        assert g[0] == e[0] and len(g) == len(e)
+        if len(g) > 1:
+            assert dict(zip(got[0][1:], g[1:])) == dict(zip(exp[0][1:], e[1:])), g[0]
+    # ---- same column order as the reference's run: its text, row for row
+    if cols == ref_order:
+        for pos1, row in f["base_rows"].items():
+            assert rows[pos1] == row
+        for pos1, row in f["snp_rows"].items():
+            assert srows[pos1] == row
