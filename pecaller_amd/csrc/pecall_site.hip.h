@@ -15,7 +15,7 @@
 // ln n! above 10000 only; the ln n! table and the Hardy-Weinberg table come from the host, built with its libm).
 //
 // Configurations live in two pools (current list / list being built).  Almost every column needs one to three
-// configurations, so the pools sit in LDS (64 entries); a column whose list outgrows that moves to per-wave pools in HBM
+// configurations, so the pools sit in LDS (32 entries); a column whose list outgrows that moves to per-wave pools in HBM
 // (flat pointers: the code is the same) for the rest of its passes.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -26,8 +26,8 @@
 #define PCS_NA 6
 #define PCS_NG 14
 #define PCS_MAXCFG 514          // max_configs, pecaller.c:1180
-#define PCS_SMALL 64            // list length a pool in LDS takes
-#define PCS_SMALLCAP 72         // its slots (+1 for the homozygous fallback, padded)
+#define PCS_SMALL 32            // list length a pool in LDS takes
+#define PCS_SMALLCAP 40         // its slots (+1 for the homozygous fallback, padded)
 #define PCS_BIGCAP 7232         // >= max_gen * (max_configs + 1) + 1 (pecaller.c:1194), multiple of 8
 
 struct PcsParams
@@ -68,7 +68,6 @@ struct __align__ (16) PcsShared
 {
   PcsSmallPool pool[2];
   double like[PCS_MAXN][PCS_NG + 1];    // per-sample genotype log-likelihoods of the pass
-  double pp[PCS_MAXN][PCS_NG + 1];      // marginal posteriors
   double mean[PCS_NG][PCS_NA], var[PCS_NG][PCS_NA], wt[PCS_NG][PCS_NA], fr[PCS_NG][PCS_NA];
   int al[PCS_NG][PCS_NA], first[PCS_NG][PCS_NA];
   int reads[PCS_MAXN][PCS_NA];
@@ -83,9 +82,15 @@ __device__ __forceinline__ void pcs_sync ()
   __builtin_amdgcn_wave_barrier ();
 }
 
-__device__ __forceinline__ double pcs_shfl (double v, int l)
+// value of lane l, l the same in every lane: v_readlane_b32 (an SGPR broadcast, no LDS round trip)
+__device__ __forceinline__ int pcs_bcast (int v, int l)
 {
-  return __hiloint2double (__shfl (__double2hiint (v), l), __shfl (__double2loint (v), l));
+  return __builtin_amdgcn_readlane (v, l);
+}
+
+__device__ __forceinline__ double pcs_bcast (double v, int l)
+{
+  return __hiloint2double (__builtin_amdgcn_readlane (__double2hiint (v), l), __builtin_amdgcn_readlane (__double2loint (v), l));
 }
 
 __device__ __forceinline__ void pcs_pool_small (PcsPool & p, PcsSmallPool * s)
@@ -376,7 +381,7 @@ __device__ int pcs_expand (const PcsPool & cur, PcsPool & nw, const PcsPool & bi
         {
           const int k = __ffsll ((long long) m) - 1;
           m &= m - 1;
-          const double t = pcs_shfl (templ, k), po = pcs_shfl (post, k);
+          const double t = pcs_bcast (templ, k), po = pcs_bcast (post, k);
           if (!((t + thres > best_post) || (t + 0.01 > best_like)))
             continue;
           best_like = (t > best_like) ? t : best_like;
@@ -389,16 +394,16 @@ __device__ int pcs_expand (const PcsPool & cur, PcsPool & nw, const PcsPool & bi
               nw = big_nw;
               went_big = true;
             }
-          const int sk = __shfl (s, k), jk = __shfl (j, k);
+          const int sk = pcs_bcast (s, k), jk = pcs_bcast (j, k);
           const int d = newcount;
           nw.calls[(size_t) d * PCS_MAXN + lane] = (lane == who) ? (int8_t) jk : cur.calls[(size_t) sk * PCS_MAXN + lane];
-          const double pr = pcs_shfl (prior, k);
-          const int hk = __shfl (hets, k), nk = __shfl (nall, k);
+          const double pr = pcs_bcast (prior, k);
+          const int hk = pcs_bcast (hets, k), nk = pcs_bcast (nall, k);
           int ak = 0;
 #pragma unroll
           for (int q = 0; q < PCS_NA; q++)
             {
-              const int v = __shfl (ac[q], k);
+              const int v = pcs_bcast (ac[q], k);
               ak = (lane == q) ? v : ak;
             }
           if (lane < PCS_NA)
@@ -603,7 +608,7 @@ __global__ __launch_bounds__ (64) void pcs_call_kernel (PcsParams P, const uint1
             int rank = 0;
             for (int jn = 0; jn < N; jn++)
               {
-                const double pj = pcs_shfl (initial_p, jn);
+                const double pj = pcs_bcast (initial_p, jn);
                 rank += (pj > initial_p) || (pj == initial_p && jn < lane);
               }
             if (lane < N)
@@ -623,7 +628,7 @@ __global__ __launch_bounds__ (64) void pcs_call_kernel (PcsParams P, const uint1
                   if (big)
                     pool[ni] = bigp[ni];
                   bool went_big = big;
-                  const int r4 = __shfl (r[4], ind), r5 = __shfl (r[5], ind);
+                  const int r4 = pcs_bcast (r[4], ind), r5 = pcs_bcast (r[5], ind);
                   const int cnt = pcs_expand (pool[ci], pool[ni], bigp[ni], went_big, total, ind, dom, ct, sh, (total <= PCS_SMALLCAP) ? sh.dup : big_dup,
                                               r4, r5, P, lane);
                   big = went_big;
@@ -666,18 +671,26 @@ __global__ __launch_bounds__ (64) void pcs_call_kernel (PcsParams P, const uint1
           calls_changed = false;
           if (lane < N && tot > md)
             {
-              for (int g = 0; g <= PCS_NG; g++)
-                sh.pp[lane][g] = 0;
-              for (int i = 0; i < total; i++)
-                {
-                  const int s = cp.ord[i];
-                  sh.pp[lane][cp.calls[(size_t) s * PCS_MAXN + lane]] += cp.post[s];
-                }
+              // post_prob[g] = sum of the posteriors of the configurations that call this sample g, in list order; the
+              // first largest one is the call
               int besti = 0;
-              for (int g = 1; g < G; g++)
-                if (sh.pp[lane][g] > sh.pp[lane][besti])
-                  besti = g;
-              final_p = sh.pp[lane][besti];
+              double bestp = 0;
+              for (int g = 0; g < G; g++)
+                {
+                  double acc = 0;
+                  for (int i = 0; i < total; i++)
+                    {
+                      const int s = cp.ord[i];
+                      if (cp.calls[(size_t) s * PCS_MAXN + lane] == g)
+                        acc += cp.post[s];
+                    }
+                  if (g == 0 || acc > bestp)
+                    {
+                      besti = g;
+                      bestp = acc;
+                    }
+                }
+              final_p = bestp;
               final_call = besti;
               if (final_call != initial_call || final_p < P.threshold)
                 calls_changed = true;
