@@ -2,7 +2,7 @@
  * pecall_site_oracle.c -- TEST INFRASTRUCTURE ONLY.
  *
  * CPU restatement of PECaller's per-site caller, i.e. the body of call_single_base (src/pecaller.c:1207-1691) for one
- * pileup column of INDIV samples, without a pedigree (use_ped = n: every add_denovo term is 0):
+ * pileup column of INDIV samples, with or without a pedigree (add_denovo 2396-2445, the trio / dyad tables of main 312-374):
  *
  *   site set-up and filters                      src/pecaller.c:1230-1337
  *   pass loop (at most 5 passes)                 src/pecaller.c:1349-1559
@@ -43,7 +43,7 @@ typedef struct
   double prior, like, post;
   int gcount[NG];
   int acount[NA];
-  int hets, homs, no_alleles;
+  int hets, homs, no_alleles, no_denovo;
   int8_t *calls;                /* [indiv] */
 } Cfg;
 
@@ -60,7 +60,19 @@ typedef struct
   int cap_cur, cap_nxt;
   int *idx, *tmp;
   int max_list;                 /* longest list fill_config_probs has built (test coverage statistic) */
+  /* pedigree (use_ped = y) */
+  int use_ped;
+  double ln_denovo;
+  int *dad, *mom, *sex;         /* [indiv], -1 = absent */
+  int *kid_off, *kid_list;      /* kids of sample i = kid_list[kid_off[i] .. kid_off[i + 1]), in ped-file order */
+  short dyad[4][NG + 1][NG + 1];
+  short trio[4][NG + 1][NG + 1][NG + 1];
 } Caller;
+
+#define AUTO 0
+#define CHRX 1
+#define CHRY 2
+#define CHRMT 3
 
 static void
 het_alleles (int g, int *a, int *b, int ref)    /* get_het_alleles, pecaller.c:2191-2245 */
@@ -180,6 +192,11 @@ ora_caller_destroy (void *p)
   free (c->calls_nxt);
   free (c->idx);
   free (c->tmp);
+  free (c->dad);
+  free (c->mom);
+  free (c->sex);
+  free (c->kid_off);
+  free (c->kid_list);
   free (c);
 }
 
@@ -187,6 +204,109 @@ int
 ora_caller_max_list (void *p)
 {
   return ((Caller *) p)->max_list;
+}
+
+/* use_ped = y: parents (-1 = none), sex and each sample's kids in ped-file order; denovo_rate = argv[11].
+ * The de-novo tables as main builds them (pecaller.c:312-374). */
+void
+ora_caller_set_ped (void *p, const int *dad, const int *mom, const int *sex, const int *kid_off, const int *kid_list, double denovo_rate)
+{
+  Caller *c = p;
+  const int N = c->indiv;
+  c->use_ped = 1;
+  c->ln_denovo = log (denovo_rate);
+  c->dad = malloc (N * sizeof (int));
+  c->mom = malloc (N * sizeof (int));
+  c->sex = malloc (N * sizeof (int));
+  c->kid_off = malloc ((N + 1) * sizeof (int));
+  memcpy (c->dad, dad, N * sizeof (int));
+  memcpy (c->mom, mom, N * sizeof (int));
+  memcpy (c->sex, sex, N * sizeof (int));
+  memcpy (c->kid_off, kid_off, (N + 1) * sizeof (int));
+  c->kid_list = malloc ((kid_off[N] + 1) * sizeof (int));
+  memcpy (c->kid_list, kid_list, kid_off[N] * sizeof (int));
+  memset (c->dyad, 0, sizeof c->dyad);
+  memset (c->trio, 0, sizeof c->trio);
+  for (int r = 0; r < 4; r++)
+    for (int i = 0; i < c->max_gen; i++)
+      for (int j = 0; j < c->max_gen; j++)
+        {
+          if (c->haploid)
+            {
+              c->dyad[r][i][j] = i != j;
+              continue;
+            }
+          int da, db, ka, kb;
+          het_alleles (i, &da, &db, r);
+          het_alleles (j, &ka, &kb, r);
+          if (ka != da && ka != db && kb != da && kb != db)
+            c->dyad[r][i][j] = 1;
+          for (int k = 0; k < c->max_gen; k++)
+            {
+              int ma, mb;
+              het_alleles (k, &ma, &mb, r);
+              /* one allele from each parent: nothing new; no allele explained by either: two events; else one */
+              if ((ka == ma && (kb == da || kb == db)) || (ka == mb && (kb == da || kb == db)) || (kb == ma && (ka == da || ka == db))
+                  || (kb == mb && (ka == da || ka == db)))
+                c->trio[r][i][k][j] = 0;
+              else if (ka != ma && kb != db && kb != ma && ka != db && ka != mb && kb != da && kb != mb && ka != da)
+                c->trio[r][i][k][j] = 2;
+              else
+                c->trio[r][i][k][j] = 1;
+            }
+        }
+}
+
+/* add_denovo, pecaller.c:2396-2445; genotype NG = not called */
+static int
+add_denovo (const Caller * c, int kid, int dad, int mom, int sex, int chrom, int ref)
+{
+  if (dad < NG)
+    {
+      if (mom < NG)
+        {
+          if (chrom == AUTO)
+            return c->trio[ref][dad][mom][kid];
+          if (chrom == CHRX)
+            return sex == 1 ? c->dyad[ref][mom][kid] : c->trio[ref][dad][mom][kid];
+          if (chrom == CHRY)
+            return sex == 1 ? c->dyad[ref][dad][kid] : 0;
+          if (chrom == CHRMT)
+            return c->dyad[ref][mom][kid];
+          return 0;
+        }
+      if (chrom == AUTO || (chrom == CHRX && sex == 2) || (chrom == CHRY && sex == 1))
+        return c->dyad[ref][dad][kid];
+      return 0;
+    }
+  if (mom < NG && chrom != CHRY)
+    return c->dyad[ref][mom][kid];
+  return 0;
+}
+
+/* the de-novo events sample `who` takes part in under the calls of one configuration (pecaller.c:2578-2603): as a child,
+ * and as a parent of each of its kids.  The reference carries dg / mg over from one kid to the next when a kid lacks that
+ * parent (they are initialised once, before the loop). */
+static int
+denovo_around (const Caller * c, const int8_t * calls, int who, int chrom, int ref)
+{
+  int n = 0;
+  const int j = calls[who];
+  if (c->dad[who] >= 0)
+    n += add_denovo (c, j, calls[c->dad[who]], c->mom[who] >= 0 ? calls[c->mom[who]] : NG, c->sex[who], chrom, ref);
+  else if (c->mom[who] >= 0)
+    n += add_denovo (c, j, NG, calls[c->mom[who]], c->sex[who], chrom, ref);
+  int dg = NG, mg = NG;
+  for (int q = c->kid_off[who]; q < c->kid_off[who + 1]; q++)
+    {
+      const int kid = c->kid_list[q];
+      if (c->dad[kid] >= 0)
+        dg = calls[c->dad[kid]];
+      if (c->mom[kid] >= 0)
+        mg = calls[c->mom[kid]];
+      n += add_denovo (c, calls[kid], dg, mg, c->sex[kid], chrom, ref);
+    }
+  return n;
 }
 
 /* the caller's tables, for handing to the device implementation under test */
@@ -226,6 +346,7 @@ cfg_init (const Caller * c, Cfg * t, int dom, const int *tot)
   t->like = 0;
   t->prior = 0;
   t->post = 1;
+  t->no_denovo = 0;
 }
 
 static void
@@ -303,7 +424,7 @@ clean_cfgs (Caller * c, int n, int ref, double ct, const int *tot, const double 
 
 /* fill_config_probs, pecaller.c:2511-2788, without the pedigree terms */
 static int
-expand_cfgs (Caller * c, int n, int who, int ref, double thres, const int *reads, const double *slike)
+expand_cfgs (Caller * c, int n, int who, int ref, int chrom, double thres, const int *reads, const double *slike)
 {
   Cfg *cn = c->cur, *nw = c->nxt;
   double best_post = cn[0].post, best_like = cn[0].like;
@@ -330,6 +451,8 @@ expand_cfgs (Caller * c, int n, int who, int ref, double thres, const int *reads
             old->hets--;
           else
             old->homs--;
+          if (c->use_ped)
+            old->no_denovo -= denovo_around (c, old->calls, who, chrom, ref);
           old->like -= slike[j];
           old->gcount[j]--;
         }
@@ -359,9 +482,13 @@ expand_cfgs (Caller * c, int n, int who, int ref, double thres, const int *reads
           for (int k = 0; k < NA; k++)
             if (t->acount[k] > 0)
               t->no_alleles++;
+          if (c->use_ped)
+            t->no_denovo += denovo_around (c, t->calls, who, chrom, ref);
           t->prior = 0;
           if (t->no_alleles > 1)
             t->prior = (t->no_alleles - 1) * c->ln_theta;
+          if (t->no_denovo > 0)
+            t->prior += t->no_denovo * c->ln_denovo;
           if (!c->haploid && t->no_alleles > 1)
             {
               int major = 0, minor = 0;
@@ -522,11 +649,11 @@ alpha_sanity (int (*al)[NA], int max_gen, int (*first)[NA], int ref, int normal_
     }
 }
 
-/* One site.  reads[indiv][6]; dom = reference base 0..3; chrom_y = the contig is "chry" (pecaller.c:1303).
+/* One site.  reads[indiv][6]; dom = reference base 0..3; chrom = AUTO / CHRX / CHRY / CHRMT of the contig (pecaller.c:474-482).
  * Out: call[indiv] (0..13, 14 = 'N'), p[indiv], allele_count[6] (Allele_Counts of the .snp row), returns the site type
- * (0 REF, 1 SNP, 2 DEL, 3 INS, 4 LOW, 5 MULTIALLELIC, 6 MESS); *n_pass = passes run. */
+ * (0 REF, 1 SNP, 2 DEL, 3 INS, 4 LOW, 5 MULTIALLELIC, 6 MESS); *n_pass = passes run; *denovo = d_count of the row. */
 static int
-call_site (Caller * c, const uint16_t * rd, int dom, int chrom_y, int8_t * call, double *p_out, int *allele_count, int *n_pass)
+call_site (Caller * c, const uint16_t * rd, int dom, int chrom, int8_t * call, double *p_out, int *allele_count, int *n_pass, int *denovo)
 {
   const int N = c->indiv, G = c->max_gen, md = c->min_depth;
   int reads[N][NA], tot[N], initial_call[N], final_call[N];
@@ -561,7 +688,7 @@ call_site (Caller * c, const uint16_t * rd, int dom, int chrom_y, int8_t * call,
   for (int i = 0; i < N; i++)
     if (tot[i] >= 8)
       sample_count++;
-  if (sample_count < (double) 0.5 * N && !chrom_y)
+  if (sample_count < (double) 0.5 * N && chrom != CHRY)
     bad_base = 1;
   int al[NG][NA], first[NG][NA];
   double mean[NG][NA], var[NG][NA], wt[NG][NA];
@@ -660,7 +787,7 @@ call_site (Caller * c, const uint16_t * rd, int dom, int chrom_y, int8_t * call,
           const int ind = ord[k];
           if (tot[ind] > md)
             {
-              total = expand_cfgs (c, total, ind, dom, ct, reads[ind], like[ind]);
+              total = expand_cfgs (c, total, ind, dom, chrom, ct, reads[ind], like[ind]);
               total = clean_cfgs (c, total, dom, ct, tot, (const double (*)[NG + 1]) like);
             }
           else
@@ -827,20 +954,38 @@ call_site (Caller * c, const uint16_t * rd, int dom, int chrom_y, int8_t * call,
       else
         type = 4;
     }
+  /* ---- de-novo events among the confident calls (pecaller.c:1650-1671): the row type gets a DENOVO_ prefix */
+  *denovo = 0;
+  if (type && c->use_ped)
+    for (int i = 0; i < N; i++)
+      {
+        const double fp = tot[i] > md ? final_p[i] : 1.0;
+        const int fc = tot[i] > md ? final_call[i] : NG;
+        if (fp >= c->threshold)
+          {
+            int dc = NG, mc = NG;
+            const int d = c->dad[i], m = c->mom[i];
+            if (d >= 0 && (tot[d] > md ? final_p[d] : 1.0) >= c->threshold)
+              dc = tot[d] > md ? final_call[d] : NG;
+            if (m >= 0 && (tot[m] > md ? final_p[m] : 1.0) >= c->threshold)
+              mc = tot[m] > md ? final_call[m] : NG;
+            *denovo += add_denovo (c, fc, dc, mc, c->sex[i], chrom, dom);
+          }
+      }
   *n_pass = pass;
   return type;
 }
 
 /* reads[n_sites][indiv][6], dom[n_sites] (0..3 = A C G T; anything else is a site the reference skips: outputs 'N'/1, type -1),
- * chrom_y[n_sites] -> call[n_sites][indiv], p[n_sites][indiv], type[n_sites], allele_count[n_sites][6], n_pass[n_sites] */
+ * chrom[n_sites] (0 autosome, 1 chrX, 2 chrY, 3 chrMT; NULL = all autosomal) -> call[n_sites][indiv], p[n_sites][indiv], type[n_sites], allele_count[n_sites][6], n_pass[n_sites] */
 void
-ora_call_sites (void *p, const uint16_t * reads, const uint8_t * dom, const uint8_t * chrom_y, long n_sites, int8_t * call, double *post,
-                int8_t * type, int32_t * allele_count, int8_t * n_pass)
+ora_call_sites (void *p, const uint16_t * reads, const uint8_t * dom, const uint8_t * chrom, long n_sites, int8_t * call, double *post,
+                int8_t * type, int32_t * allele_count, int8_t * n_pass, int32_t * denovo)
 {
   Caller *c = p;
   for (long s = 0; s < n_sites; s++)
     {
-      int ac[NA] = { 0, 0, 0, 0, 0, 0 }, np = 0;
+      int ac[NA] = { 0, 0, 0, 0, 0, 0 }, np = 0, dn = 0;
       if (dom[s] > 3)
         {
           for (int i = 0; i < c->indiv; i++)
@@ -851,10 +996,12 @@ ora_call_sites (void *p, const uint16_t * reads, const uint8_t * dom, const uint
           type[s] = -1;
         }
       else
-        type[s] = (int8_t) call_site (c, reads + (size_t) s * c->indiv * NA, dom[s], chrom_y ? chrom_y[s] : 0, call + s * c->indiv,
-                                      post + s * c->indiv, ac, &np);
+        type[s] = (int8_t) call_site (c, reads + (size_t) s * c->indiv * NA, dom[s], chrom ? chrom[s] : 0, call + s * c->indiv,
+                                      post + s * c->indiv, ac, &np, &dn);
       for (int a = 0; a < NA; a++)
         allele_count[s * NA + a] = ac[a];
       n_pass[s] = (int8_t) np;
+      if (denovo)
+        denovo[s] = dn;
     }
 }

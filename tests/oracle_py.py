@@ -152,7 +152,8 @@ def pecall_lib():
         L.ora_caller_destroy.argtypes = [C.c_void_p]
         L.ora_caller_max_list.argtypes = [C.c_void_p]
         L.ora_call_sites.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p,
-                                     C.c_void_p, C.c_void_p]
+                                     C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ora_caller_set_ped.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]
         _plib = L
     return _plib
 
@@ -169,23 +170,46 @@ def site_like(reads, alpha_mean, norm, max_gen=14, min_depth=2):
     return like, best, margin
 
 
-def call_sites(reads, dom, threshold=0.95, theta=0.001, haploid=False, chrom_y=None):
-    """the per-site caller oracle (oracle/pecall_site_oracle.c): reads[n_sites][indiv][6], dom[n_sites] in 0..3 (else skipped)
-    -> call[n_sites][indiv] (0..13, 14 = N), p, site type, allele counts, passes"""
+def kid_lists(dad, mom, order=None):
+    """kids of every sample in ped-file order (pecaller.c:574-590): CSR offsets and list"""
+    n = len(dad)
+    kids = [[] for _ in range(n)]
+    for i in (order if order is not None else range(n)):
+        if dad[i] >= 0:
+            kids[dad[i]].append(i)
+        if mom[i] >= 0:
+            kids[mom[i]].append(i)
+    off = np.zeros(n + 1, np.int32)
+    off[1:] = np.cumsum([len(k) for k in kids])
+    return off, np.array([x for k in kids for x in k] + [0], np.int32)
+
+
+def call_sites(reads, dom, threshold=0.95, theta=0.001, haploid=False, chrom=None, ped=None):
+    """the per-site caller oracle (oracle/pecall_site_oracle.c): reads[n_sites][indiv][6], dom[n_sites] in 0..3 (else skipped),
+    chrom[n_sites] 0 autosome / 1 X / 2 Y / 3 MT, ped = dict(dad, mom, sex, order, denovo_rate) or None
+    -> call[n_sites][indiv] (0..13, 14 = N), p, site type, allele counts, passes; call_sites.denovo = d_count per site"""
     L = pecall_lib()
     reads = np.ascontiguousarray(reads, np.uint16)
     dom = np.ascontiguousarray(dom, np.uint8)
     n_sites, indiv = reads.shape[:2]
-    cy = np.ascontiguousarray(chrom_y, np.uint8) if chrom_y is not None else np.zeros(n_sites, np.uint8)
+    cy = np.ascontiguousarray(chrom, np.uint8) if chrom is not None else np.zeros(n_sites, np.uint8)
     call = np.zeros((n_sites, indiv), np.int8)
     p = np.zeros((n_sites, indiv))
     typ = np.zeros(n_sites, np.int8)
     ac = np.zeros((n_sites, 6), np.int32)
     npass = np.zeros(n_sites, np.int8)
+    den = np.zeros(n_sites, np.int32)
     h = L.ora_caller_create(indiv, int(haploid), float(threshold), float(theta))
     try:
-        L.ora_call_sites(h, _p(reads), _p(dom), _p(cy), n_sites, _p(call), _p(p), _p(typ), _p(ac), _p(npass))
+        if ped is not None:
+            dad = np.ascontiguousarray(ped["dad"], np.int32)
+            mom = np.ascontiguousarray(ped["mom"], np.int32)
+            sex = np.ascontiguousarray(ped["sex"], np.int32)
+            off, lst = kid_lists(dad, mom, ped.get("order"))
+            L.ora_caller_set_ped(h, _p(dad), _p(mom), _p(sex), _p(off), _p(lst), float(ped["denovo_rate"]))
+        L.ora_call_sites(h, _p(reads), _p(dom), _p(cy), n_sites, _p(call), _p(p), _p(typ), _p(ac), _p(npass), _p(den))
         call_sites.max_list = L.ora_caller_max_list(h)      # longest configuration list seen (coverage statistic)
+        call_sites.denovo = den
     finally:
         L.ora_caller_destroy(h)
     return call, p, typ, ac, npass

@@ -11,8 +11,9 @@ GEN = "ACGTDIMRWSYKEHN"           # int_to_gen, pecaller.c:2910-2943
 TYPES = ["", "SNP", "DEL", "INS", "LOW", "MULTIALLELIC", "MESS"]
 
 
-def load():
-    z = np.load(os.path.join(GOLD, "pecall_sites.npz"))
+def load(tag="pecall_sites"):
+    """tag = "pecall_sites" (no pedigree) or "pecall_ped" (two trios, made by make_golden_pecall_ped.py; adds "ped")"""
+    z = np.load(os.path.join(GOLD, tag + ".npz"))
     names = [str(x) for x in z["names"]]
     cols = [str(x) for x in z["columns"]]
     perm = [names.index(c) for c in cols]          # the reference's sample order = its directory order
@@ -24,18 +25,25 @@ def load():
     dom = np.full(len(pos), 14, np.uint8)
     for k, ch in enumerate(b"ACGT"):
         dom[ref == ch] = k
-    base = gzip.open(os.path.join(GOLD, "pecall_sites.base.txt.gz"), "rt").read().split("\n")
-    snp = open(os.path.join(GOLD, "pecall_sites.snp.txt")).read().split("\n")
+    base = gzip.open(os.path.join(GOLD, tag + ".base.txt.gz"), "rt").read().split("\n")
+    snp = open(os.path.join(GOLD, tag + ".snp.txt")).read().split("\n")
     base_rows = {int(r.split("\t")[1]): r for r in base[1:] if r}
     snp_rows = {int(r.split("\t")[1]): r for r in snp[1:] if r}
-    return dict(reads=reads, pos=pos, ref=ref, dom=dom, base_rows=base_rows, snp_rows=snp_rows)
+    out = dict(reads=reads, pos=pos, ref=ref, dom=dom, base_rows=base_rows, snp_rows=snp_rows)
+    if "dad" in z:
+        # the pedigree in the reference's sample numbering (its column order); kids are listed in ped-file order
+        inv = {old: new for new, old in enumerate(perm)}
+        remap = lambda a: np.array([inv[int(a[o])] if a[o] >= 0 else -1 for o in perm], np.int32)
+        out["ped"] = dict(dad=remap(z["dad"]), mom=remap(z["mom"]), sex=np.array([int(z["sex"][o]) for o in perm], np.int32),
+                          order=[inv[o] for o in range(len(names))], denovo_rate=float(z["denovo_rate"][0]))
+    return out
 
 
 def base_row(contig, pos1, refch, call, p):
     return "%s\t%d\t%s" % (contig, pos1, refch) + "".join("\t%s\t%g" % (GEN[c], x) for c, x in zip(call, p))
 
 
-def snp_row(contig, pos1, refch, call, p, typ, ac):
+def snp_row(contig, pos1, refch, call, p, typ, ac, denovo=0):
     alle = ",".join("ACGTDI"[a] for a in range(6) if ac[a] > 0)
     cnts = ",".join("%d" % ac[a] for a in range(6) if ac[a] > 0)
-    return "%s\t%d\t%s\t%s\t%s\t%s" % (contig, pos1, refch, alle, cnts, TYPES[typ]) + "".join("\t%s\t%g" % (GEN[c], x) for c, x in zip(call, p))
+    return "%s\t%d\t%s\t%s\t%s\t%s" % (contig, pos1, refch, alle, cnts, ("DENOVO_" if denovo > 0 else "") + TYPES[typ]) + "".join("\t%s\t%g" % (GEN[c], x) for c, x in zip(call, p))

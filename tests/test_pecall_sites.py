@@ -5,9 +5,11 @@ import oracle_py
 import pecall_sites_fixture as fx
 
 
-def test_site_oracle_matches_reference_text():
-    f = fx.load()
-    call, p, typ, ac, npass = oracle_py.call_sites(f["reads"], f["dom"])
+@pytest.mark.parametrize("tag", ["pecall_sites", "pecall_ped"])
+def test_site_oracle_matches_reference_text(tag):
+    f = fx.load(tag)
+    call, p, typ, ac, npass = oracle_py.call_sites(f["reads"], f["dom"], ped=f.get("ped"))
+    den = oracle_py.call_sites.denovo
     n_base = n_snp = 0
     bad = []
     for i, pos in enumerate(f["pos"]):
@@ -22,7 +24,7 @@ def test_site_oracle_matches_reference_text():
         exp_s = f["snp_rows"].get(pos1)
         if typ[i] > 0:
             n_snp += 1
-            got_s = fx.snp_row("chr1", pos1, chr(f["ref"][i]), call[i], p[i], typ[i], ac[i])
+            got_s = fx.snp_row("chr1", pos1, chr(f["ref"][i]), call[i], p[i], typ[i], ac[i], den[i])
             if got_s != exp_s:
                 bad.append((pos1, exp_s, got_s))
         elif exp_s is not None:
@@ -30,6 +32,8 @@ def test_site_oracle_matches_reference_text():
     assert n_base == len(f["base_rows"]) and n_snp == len(f["snp_rows"]), (n_base, len(f["base_rows"]), n_snp, len(f["snp_rows"]))
     assert not bad, bad[:3]
     assert npass.max() >= 2                      # the fixture exercises the alpha re-estimation
+    if tag == "pecall_ped":
+        assert (den[typ > 0] > 0).sum() >= 10     # DENOVO_ rows
 
 
 @pytest.mark.gpu
