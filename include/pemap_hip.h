@@ -167,7 +167,7 @@ int pecall_dev_run (pecall_dev * dev, int n_sites, int indiv, int max_gen, int m
 int pecall_dev_collect (pecall_dev * dev, int n_sites, int indiv, double *like, int8_t * best, double *margin);
 
 /* ---- PECaller: the whole per-site caller ----
- * The body of call_single_base for one pileup column (pecaller.c:1207-1691) without a pedigree (use_ped = n): site filters,
+ * The body of call_single_base for one pileup column (pecaller.c:1207-1691), with or without a pedigree: site filters,
  * up to five passes of { Dirichlet means, fill_sample_like, confidence order, the beam over joint configurations
  * (fill_config_like / fill_config_probs / clean_config_probs with the exact Hardy-Weinberg prior), configuration
  * posteriors, per-sample marginal posteriors and calls, moment-matched alpha re-estimation + check_alpha_sanity }, then the
@@ -175,16 +175,24 @@ int pecall_dev_collect (pecall_dev * dev, int n_sites, int indiv, double *like, 
  *   reads[n_sites][indiv][6] u16     as above, samples in the reference's column order (it matters: ties, beam order)
  *   ref_base[n_sites]                0..3 = A C G T (gen_to_int of the .seq letter); anything else = a site the reference
  *                                    skips (pecaller.c:1208, 1718): calls 'N', posterior 1, site_type -1
- *   chrom_y[n_sites] (may be NULL)   1 where the contig name starts with "chry" (pecaller.c:474-482, 1303)
+ *   chrom_type[n_sites] (may be NULL) 0 autosome, 1 chrX, 2 chrY, 3 chrMT: the lower-cased contig-name prefix rule of
+ *                                    pecaller.c:474-482 (chrY lifts the half-the-samples filter, 1303; X/Y/MT change add_denovo)
  *   haploid / threshold / theta      argv[7] / argv[5] (Prob_to_call) / argv[6] of pecaller
  *   call[n_sites][indiv]             0..13 = A C G T D I M R W S Y K E H (int_to_gen), 14 = 'N'
  *   posterior[n_sites][indiv]        final_p, what the reference prints with %g
  *   site_type[n_sites]  (may be NULL) 0 reference, 1 SNP, 2 DEL, 3 INS, 4 LOW, 5 MULTIALLELIC, 6 MESS
  *   allele_count[n_sites][6], n_pass[n_sites]  (may be NULL) Allele_Counts of the .snp row; passes run
+ *   denovo[n_sites]     (may be NULL) d_count of the row (pecaller.c:1650-1671): > 0 = the type is printed as DENOVO_<type>
  * indiv <= 64 (one lane per sample).  Text formatting and the merge of the pileup streams stay on the host. */
-int pecall_dev_call_sites (pecall_dev * dev, const uint16_t * reads, const uint8_t * ref_base, const uint8_t * chrom_y, long n_sites,
+int pecall_dev_call_sites (pecall_dev * dev, const uint16_t * reads, const uint8_t * ref_base, const uint8_t * chrom_type, long n_sites,
                            int indiv, int haploid, double threshold, double theta, int8_t * call, double *posterior,
-                           int8_t * site_type, int32_t * allele_count, int8_t * n_pass);
+                           int8_t * site_type, int32_t * allele_count, int8_t * n_pass, int32_t * denovo);
+/* use_pedfile = y (pecaller.c:376-392, 561-604): parents as sample indices (-1 = not sampled), sex (1 male, 2 female), and each
+ * sample's kids in ped-file order: kids of i = kid_list[kid_off[i] .. kid_off[i + 1]).  denovo_rate = argv[11] (<= theta).
+ * The configuration prior then carries no_denovo * ln(denovo_rate) (add_denovo, 2396-2445, tables of main 312-374).
+ * dad == NULL clears the pedigree. */
+int pecall_dev_set_pedigree (pecall_dev * dev, int indiv, const int *dad, const int *mom, const int *sex, const int *kid_off,
+                             const int *kid_list, double denovo_rate);
 
 #ifdef __cplusplus
 }

@@ -31,8 +31,15 @@ struct pecall_dev
   uint8_t *d_dom, *d_chromy;
   int8_t *d_call, *d_type, *d_npass;
   double *d_post;
-  int32_t *d_ac;
+  int32_t *d_ac, *d_den;
   long cap_ssites, cap_sitems;
+  // pedigree
+  int ped_indiv, ped_haploid;
+  double denovo_rate;
+  int8_t h_dad[PCS_MAXN], h_mom[PCS_MAXN], h_sex[PCS_MAXN];
+  uint8_t h_kid_off[PCS_MAXN + 1], h_kid_list[2 * PCS_MAXN];
+  int8_t *d_ped;                // dad[64] mom[64] sex[64] kid_off[65 -> 72] kid_list[128]
+  short *d_dyad, *d_trio;
 };
 
 static int pc_fail (pecall_dev * d, const char *fmt, ...)
@@ -133,6 +140,10 @@ extern "C" void pecall_dev_destroy (pecall_dev * d)
   hipFree (d->d_npass);
   hipFree (d->d_post);
   hipFree (d->d_ac);
+  hipFree (d->d_den);
+  hipFree (d->d_ped);
+  hipFree (d->d_dyad);
+  hipFree (d->d_trio);
   hipStreamDestroy (d->stream);
   free (d);
 }
@@ -288,7 +299,7 @@ static int pcs_ensure (pecall_dev * d, long n_sites, int indiv)
   if (n_sites > d->cap_ssites || items > d->cap_sitems)
     {
       hipFree (d->d_sreads); hipFree (d->d_dom); hipFree (d->d_chromy); hipFree (d->d_call); hipFree (d->d_type);
-      hipFree (d->d_npass); hipFree (d->d_post); hipFree (d->d_ac);
+      hipFree (d->d_npass); hipFree (d->d_post); hipFree (d->d_ac); hipFree (d->d_den);
       PCCHK (d, hipMalloc ((void **) &d->d_sreads, items * PCS_NA * sizeof (uint16_t)));
       PCCHK (d, hipMalloc ((void **) &d->d_dom, n_sites));
       PCCHK (d, hipMalloc ((void **) &d->d_chromy, n_sites));
@@ -297,15 +308,129 @@ static int pcs_ensure (pecall_dev * d, long n_sites, int indiv)
       PCCHK (d, hipMalloc ((void **) &d->d_type, n_sites));
       PCCHK (d, hipMalloc ((void **) &d->d_npass, n_sites));
       PCCHK (d, hipMalloc ((void **) &d->d_ac, n_sites * PCS_NA * sizeof (int32_t)));
+      PCCHK (d, hipMalloc ((void **) &d->d_den, n_sites * sizeof (int32_t)));
       d->cap_ssites = n_sites;
       d->cap_sitems = items;
     }
   return 0;
 }
 
-extern "C" int pecall_dev_call_sites (pecall_dev * d, const uint16_t * reads, const uint8_t * ref_base, const uint8_t * chrom_y, long n_sites,
+// get_het_alleles, pecaller.c:2191-2245
+static void h_het (int g, int *a, int *b, int ref)
+{
+  static const int ha[6] = { 0, 0, 0, 1, 1, 2 }, hb[6] = { 1, 2, 3, 2, 3, 3 };
+  if (g < PCS_NA)
+    *a = *b = g;
+  else if (g < 12)
+    {
+      *a = ha[g - 6];
+      *b = hb[g - 6];
+    }
+  else
+    {
+      *a = ref;
+      *b = g == 12 ? 4 : 5;
+    }
+}
+
+// dyad_denovo / trio_denovo as main fills them (pecaller.c:312-374), for the four reference bases
+static void h_denovo_tables (int haploid, short *dyad, short *trio)
+{
+  memset (dyad, 0, sizeof (short) * 4 * 225);
+  memset (trio, 0, sizeof (short) * 4 * 3375);
+  const int G = haploid ? 6 : PCS_NG;
+  for (int r = 0; r < 4; r++)
+    for (int i = 0; i < G; i++)
+      for (int j = 0; j < G; j++)
+        {
+          if (haploid)
+            {
+              dyad[r * 225 + i * 15 + j] = i != j;
+              continue;
+            }
+          int da, db, ka, kb;
+          h_het (i, &da, &db, r);
+          h_het (j, &ka, &kb, r);
+          if (ka != da && ka != db && kb != da && kb != db)
+            dyad[r * 225 + i * 15 + j] = 1;
+          for (int k = 0; k < G; k++)
+            {
+              int ma, mb;
+              h_het (k, &ma, &mb, r);
+              short v;
+              if ((ka == ma && (kb == da || kb == db)) || (ka == mb && (kb == da || kb == db)) || (kb == ma && (ka == da || ka == db))
+                  || (kb == mb && (ka == da || ka == db)))
+                v = 0;          // one allele from each parent
+              else if (ka != ma && kb != db && kb != ma && ka != db && ka != mb && kb != da && kb != mb && ka != da)
+                v = 2;
+              else
+                v = 1;
+              trio[r * 3375 + (i * 15 + k) * 15 + j] = v;       // [dad][mom][kid]
+            }
+        }
+}
+
+extern "C" int pecall_dev_set_pedigree (pecall_dev * d, int indiv, const int *dad, const int *mom, const int *sex, const int *kid_off,
+                                        const int *kid_list, double denovo_rate)
+{
+  if (!dad)
+    {
+      d->ped_indiv = 0;
+      return 0;
+    }
+  if (indiv < 1 || indiv > PCS_MAXN)
+    return pc_fail (d, "set_pedigree: %d samples (1..%d)", indiv, PCS_MAXN);
+  if (!(denovo_rate >= 1e-30))
+    return pc_fail (d, "set_pedigree: de-novo mutation rate %g (pecaller.c:381-385)", denovo_rate);
+  if (kid_off[indiv] > 2 * PCS_MAXN)
+    return pc_fail (d, "set_pedigree: %d parent-child links", kid_off[indiv]);
+  for (int i = 0; i < indiv; i++)
+    {
+      if (dad[i] >= indiv || mom[i] >= indiv)
+        return pc_fail (d, "set_pedigree: parent index out of range for sample %d", i);
+      d->h_dad[i] = (int8_t) (dad[i] < 0 ? -1 : dad[i]);
+      d->h_mom[i] = (int8_t) (mom[i] < 0 ? -1 : mom[i]);
+      d->h_sex[i] = (int8_t) sex[i];
+    }
+  for (int i = 0; i <= indiv; i++)
+    d->h_kid_off[i] = (uint8_t) kid_off[i];
+  for (int i = 0; i < kid_off[indiv]; i++)
+    d->h_kid_list[i] = (uint8_t) kid_list[i];
+  d->ped_indiv = indiv;
+  d->denovo_rate = denovo_rate;
+  d->ped_haploid = -1;          // tables are made at the next call, for its ploidy
+  return 0;
+}
+
+static int pcs_ensure_ped (pecall_dev * d, int haploid)
+{
+  if (!d->d_ped)
+    {
+      PCCHK (d, hipMalloc ((void **) &d->d_ped, 3 * PCS_MAXN + 72 + 2 * PCS_MAXN));
+      PCCHK (d, hipMalloc ((void **) &d->d_dyad, sizeof (short) * 4 * 225));
+      PCCHK (d, hipMalloc ((void **) &d->d_trio, sizeof (short) * 4 * 3375));
+    }
+  if (d->ped_haploid != haploid)
+    {
+      short *dy = (short *) malloc (sizeof (short) * 4 * 225), *tr = (short *) malloc (sizeof (short) * 4 * 3375);
+      h_denovo_tables (haploid, dy, tr);
+      PCCHK (d, hipMemcpy (d->d_dyad, dy, sizeof (short) * 4 * 225, hipMemcpyHostToDevice));
+      PCCHK (d, hipMemcpy (d->d_trio, tr, sizeof (short) * 4 * 3375, hipMemcpyHostToDevice));
+      free (dy);
+      free (tr);
+      PCCHK (d, hipMemcpy (d->d_ped, d->h_dad, PCS_MAXN, hipMemcpyHostToDevice));
+      PCCHK (d, hipMemcpy (d->d_ped + PCS_MAXN, d->h_mom, PCS_MAXN, hipMemcpyHostToDevice));
+      PCCHK (d, hipMemcpy (d->d_ped + 2 * PCS_MAXN, d->h_sex, PCS_MAXN, hipMemcpyHostToDevice));
+      PCCHK (d, hipMemcpy (d->d_ped + 3 * PCS_MAXN, d->h_kid_off, PCS_MAXN + 1, hipMemcpyHostToDevice));
+      PCCHK (d, hipMemcpy (d->d_ped + 3 * PCS_MAXN + 72, d->h_kid_list, 2 * PCS_MAXN, hipMemcpyHostToDevice));
+      d->ped_haploid = haploid;
+    }
+  return 0;
+}
+
+extern "C" int pecall_dev_call_sites (pecall_dev * d, const uint16_t * reads, const uint8_t * ref_base, const uint8_t * chrom_type, long n_sites,
                                       int indiv, int haploid, double threshold, double theta, int8_t * call, double *posterior,
-                                      int8_t * site_type, int32_t * allele_count, int8_t * n_pass)
+                                      int8_t * site_type, int32_t * allele_count, int8_t * n_pass, int32_t * denovo)
 {
   PCCHK (d, hipSetDevice (d->device));
   if (n_sites <= 0 || indiv <= 0 || indiv > PCS_MAXN)
@@ -318,8 +443,14 @@ extern "C" int pecall_dev_call_sites (pecall_dev * d, const uint16_t * reads, co
   long items = n_sites * indiv;
   PCCHK (d, hipMemcpyAsync (d->d_sreads, reads, items * PCS_NA * sizeof (uint16_t), hipMemcpyHostToDevice, d->stream));
   PCCHK (d, hipMemcpyAsync (d->d_dom, ref_base, n_sites, hipMemcpyHostToDevice, d->stream));
-  if (chrom_y)
-    PCCHK (d, hipMemcpyAsync (d->d_chromy, chrom_y, n_sites, hipMemcpyHostToDevice, d->stream));
+  if (d->ped_indiv && d->ped_indiv != indiv)
+    return pc_fail (d, "call_sites: the pedigree was set for %d samples, this call has %d", d->ped_indiv, indiv);
+  if (d->ped_indiv && d->denovo_rate > theta)
+    return pc_fail (d, "call_sites: de-novo mutation rate %g above theta %g (pecaller.c:381-385)", d->denovo_rate, theta);
+  if (d->ped_indiv && (rc = pcs_ensure_ped (d, haploid ? 1 : 0)))
+    return rc;
+  if (chrom_type)
+    PCCHK (d, hipMemcpyAsync (d->d_chromy, chrom_type, n_sites, hipMemcpyHostToDevice, d->stream));
   else
     PCCHK (d, hipMemsetAsync (d->d_chromy, 0, n_sites, d->stream));
   PcsParams P;
@@ -332,9 +463,18 @@ extern "C" int pecall_dev_call_sites (pecall_dev * d, const uint16_t * reads, co
   P.tab = d->d_tab;
   P.hw = d->d_hw;
   P.hw_off = d->d_hw_off;
+  P.use_ped = d->ped_indiv ? 1 : 0;
+  P.ln_denovo = d->ped_indiv ? log (d->denovo_rate) : 0.0;
+  P.dad = d->d_ped;
+  P.mom = d->d_ped + PCS_MAXN;
+  P.sex = d->d_ped + 2 * PCS_MAXN;
+  P.kid_off = (const uint8_t *) d->d_ped + 3 * PCS_MAXN;
+  P.kid_list = (const uint8_t *) d->d_ped + 3 * PCS_MAXN + 72;
+  P.dyad = d->d_dyad;
+  P.trio = d->d_trio;
   long grid = n_sites < d->site_grid ? n_sites : d->site_grid;
   hipLaunchKernelGGL (pcs_call_kernel, dim3 ((unsigned) grid), dim3 (64), 0, d->stream, P, d->d_sreads, d->d_dom, d->d_chromy, n_sites, d->d_call,
-                      d->d_post, d->d_type, d->d_ac, d->d_npass, d->d_scratch);
+                      d->d_post, d->d_type, d->d_ac, d->d_npass, d->d_den, d->d_scratch);
   PCCHK (d, hipGetLastError ());
   PCCHK (d, hipMemcpyAsync (call, d->d_call, items, hipMemcpyDeviceToHost, d->stream));
   PCCHK (d, hipMemcpyAsync (posterior, d->d_post, items * sizeof (double), hipMemcpyDeviceToHost, d->stream));
@@ -344,6 +484,8 @@ extern "C" int pecall_dev_call_sites (pecall_dev * d, const uint16_t * reads, co
     PCCHK (d, hipMemcpyAsync (allele_count, d->d_ac, n_sites * PCS_NA * sizeof (int32_t), hipMemcpyDeviceToHost, d->stream));
   if (n_pass)
     PCCHK (d, hipMemcpyAsync (n_pass, d->d_npass, n_sites, hipMemcpyDeviceToHost, d->stream));
+  if (denovo)
+    PCCHK (d, hipMemcpyAsync (denovo, d->d_den, n_sites * sizeof (int32_t), hipMemcpyDeviceToHost, d->stream));
   PCCHK (d, hipStreamSynchronize (d->stream));
   return 0;
 }

@@ -1,5 +1,5 @@
-// pecall_site.hip.h -- PECaller's per-site caller (the body of call_single_base, src/pecaller.c:1207-1691, without a
-// pedigree) on gfx950: ONE WAVE per pileup column, persistent over columns.
+// pecall_site.hip.h -- PECaller's per-site caller (the body of call_single_base, src/pecaller.c:1207-1691, with or without
+// a pedigree) on gfx950: ONE WAVE per pileup column, persistent over columns.
 //
 //   lane = sample (INDIV <= 64) for everything that is per sample: set-up (1230-1260), fill_sample_like (2448-2507),
 //          marginal posteriors and calls (1443-1468), classification counts (1575-1597);
@@ -37,6 +37,13 @@ struct PcsParams
   const double *tab;            // ln n!, n <= 10000
   const double *hw;             // ln_HW[n][minor][hets] flattened; hw_off[n] = start of the (2n+1) x (n+1) matrix
   const int *hw_off;
+  // pedigree (use_ped = y): parents (-1 = none), sex, each sample's kids in ped-file order, the de-novo tables of main
+  int use_ped;
+  double ln_denovo;
+  const int8_t *dad, *mom, *sex;        // [64]
+  const uint8_t *kid_off, *kid_list;    // [65], [128]
+  const short *dyad;            // [4][15][15]
+  const short *trio;            // [4][15][15][15]
 };
 
 struct PcsPool
@@ -44,6 +51,7 @@ struct PcsPool
   double *like, *prior, *post;
   int16_t *acount;              // [cap][6]
   int16_t *hets;
+  int16_t *nden;                // no_denovo
   int8_t *nall;
   int8_t *calls;                // [cap][64]
   uint16_t *ord;                // list position -> slot
@@ -56,13 +64,13 @@ struct __align__ (16) PcsSmallPool
   double like[PCS_SMALLCAP], prior[PCS_SMALLCAP], post[PCS_SMALLCAP];
   int8_t calls[PCS_SMALLCAP][PCS_MAXN];
   int16_t acount[PCS_SMALLCAP][PCS_NA];
-  int16_t hets[PCS_SMALLCAP];
+  int16_t hets[PCS_SMALLCAP], nden[PCS_SMALLCAP];
   uint16_t ord[PCS_SMALLCAP], ord2[PCS_SMALLCAP];
   int8_t nall[PCS_SMALLCAP];
 };
 
 // bytes of one per-wave pool in HBM
-#define PCS_BIG_BYTES ((size_t) PCS_BIGCAP * (3 * 8 + PCS_MAXN + 2 * PCS_NA + 2 + 2 + 2 + 1 + 7))
+#define PCS_BIG_BYTES ((size_t) PCS_BIGCAP * (3 * 8 + PCS_MAXN + 2 * PCS_NA + 2 + 2 + 2 + 2 + 1 + 5))
 
 struct __align__ (16) PcsShared
 {
@@ -100,6 +108,7 @@ __device__ __forceinline__ void pcs_pool_small (PcsPool & p, PcsSmallPool * s)
   p.post = s->post;
   p.acount = &s->acount[0][0];
   p.hets = s->hets;
+  p.nden = s->nden;
   p.nall = s->nall;
   p.calls = &s->calls[0][0];
   p.ord = s->ord;
@@ -117,7 +126,8 @@ __device__ __forceinline__ void pcs_pool_big (PcsPool & p, char *base)
   p.hets = p.acount + (size_t) PCS_BIGCAP * PCS_NA;
   p.ord = (uint16_t *) (p.hets + PCS_BIGCAP);
   p.ord2 = p.ord + PCS_BIGCAP;
-  p.nall = (int8_t *) (p.ord2 + PCS_BIGCAP);
+  p.nden = (int16_t *) (p.ord2 + PCS_BIGCAP);
+  p.nall = (int8_t *) (p.nden + PCS_BIGCAP);
   p.cap = PCS_BIGCAP - 8;
 }
 
@@ -168,6 +178,7 @@ __device__ __forceinline__ void pcs_cfg_init (const PcsPool & p, int s, int dom,
   if (lane == 0)
     {
       p.hets[s] = 0;
+      p.nden[s] = 0;
       p.nall[s] = deep ? 1 : 0;
       p.like[s] = 0;
       p.prior[s] = 0;
@@ -267,6 +278,7 @@ __device__ __forceinline__ void pcs_migrate (const PcsPool & from, const PcsPool
       to.prior[s] = from.prior[s];
       to.post[s] = from.post[s];
       to.hets[s] = from.hets[s];
+      to.nden[s] = from.nden[s];
       to.nall[s] = from.nall[s];
       to.ord[s] = from.ord[s];
       for (int k = 0; k < PCS_NA; k++)
@@ -277,11 +289,65 @@ __device__ __forceinline__ void pcs_migrate (const PcsPool & from, const PcsPool
   pcs_sync ();
 }
 
-// fill_config_probs, pecaller.c:2511-2788 (no pedigree): the configurations of `cur` re-decided for sample `who`.
+// add_denovo, pecaller.c:2396-2445; genotype 14 = not called; chrom 0 autosome, 1 X, 2 Y, 3 MT
+__device__ __forceinline__ int pcs_add_denovo (const PcsParams & P, int kid, int dad, int mom, int sex, int chrom, int ref)
+{
+  const short *dy = P.dyad + (size_t) ref * 225, *tr = P.trio + (size_t) ref * 3375;
+  if (dad < PCS_NG)
+    {
+      if (mom < PCS_NG)
+        {
+          if (chrom == 0)
+            return tr[(dad * 15 + mom) * 15 + kid];
+          if (chrom == 1)
+            return sex == 1 ? dy[mom * 15 + kid] : tr[(dad * 15 + mom) * 15 + kid];
+          if (chrom == 2)
+            return sex == 1 ? dy[dad * 15 + kid] : 0;
+          if (chrom == 3)
+            return dy[mom * 15 + kid];
+          return 0;
+        }
+      if (chrom == 0 || (chrom == 1 && sex == 2) || (chrom == 2 && sex == 1))
+        return dy[dad * 15 + kid];
+      return 0;
+    }
+  if (mom < PCS_NG && chrom != 2)
+    return dy[mom * 15 + kid];
+  return 0;
+}
+
+// the de-novo events sample `who` takes part in under one configuration's calls with who's own call replaced by `mine`
+// (pecaller.c:2578-2603): as a child, and as a parent of each of its kids; dg / mg carry over from one kid to the next when
+// a kid lacks that parent, as in the reference (they are initialised once, before the loop)
+__device__ __forceinline__ int pcs_denovo_around (const PcsParams & P, const int8_t * calls, int who, int mine, int chrom, int ref)
+{
+#define PCS_CALL(x) ((x) == who ? mine : (int) calls[x])
+  int n = 0;
+  const int d = P.dad[who], m = P.mom[who];
+  if (d >= 0)
+    n += pcs_add_denovo (P, mine, PCS_CALL (d), m >= 0 ? PCS_CALL (m) : PCS_NG, P.sex[who], chrom, ref);
+  else if (m >= 0)
+    n += pcs_add_denovo (P, mine, PCS_NG, PCS_CALL (m), P.sex[who], chrom, ref);
+  int dg = PCS_NG, mg = PCS_NG;
+  for (int q = P.kid_off[who]; q < P.kid_off[who + 1]; q++)
+    {
+      const int kid = P.kid_list[q];
+      const int kd = P.dad[kid], km = P.mom[kid];
+      if (kd >= 0)
+        dg = PCS_CALL (kd);
+      if (km >= 0)
+        mg = PCS_CALL (km);
+      n += pcs_add_denovo (P, PCS_CALL (kid), dg, mg, P.sex[kid], chrom, ref);
+    }
+#undef PCS_CALL
+  return n;
+}
+
+// fill_config_probs, pecaller.c:2511-2788: the configurations of `cur` re-decided for sample `who`.
 // dupbuf: one byte per list position (LDS for short lists, HBM for long ones).  Returns the length of the list built in nw;
 // nw may be switched to `big_nw` (the wave's pool in HBM) when it outgrows LDS: *went_big is set.
 __device__ int pcs_expand (const PcsPool & cur, PcsPool & nw, const PcsPool & big_nw, bool &went_big, int n, int who, int ref, double thres,
-                           const PcsShared & sh, uint8_t * dupbuf, int r4, int r5, const PcsParams & P, int lane)
+                           const PcsShared & sh, uint8_t * dupbuf, int r4, int r5, int chrom, const PcsParams & P, int lane)
 {
   const int G = P.max_gen, N = P.indiv;
   // ---- a configuration equal to an earlier one on every other sample is skipped (pecaller.c:2542-2558)
@@ -339,9 +405,17 @@ __device__ int pcs_expand (const PcsPool & cur, PcsPool & nw, const PcsPool & bi
           nall += ac[k] > 0;
         }
       const int hets = cur.hets[s] - ((g_old < PCS_NG && g_old >= PCS_NA) ? 1 : 0) + (j >= PCS_NA ? 1 : 0);
+      int nden = 0;
+      if (P.use_ped && valid)
+        {
+          const int8_t *row = cur.calls + (size_t) s * PCS_MAXN;
+          nden = cur.nden[s] - (g_old < PCS_NG ? pcs_denovo_around (P, row, who, g_old, chrom, ref) : 0) + pcs_denovo_around (P, row, who, j, chrom, ref);
+        }
       double prior = 0;
       if (nall > 1)
         prior = (nall - 1) * P.ln_theta;
+      if (nden > 0)
+        prior += nden * P.ln_denovo;
       if (!P.haploid && nall > 1)
         {
           int major = 0, minor = 0;
@@ -398,7 +472,7 @@ __device__ int pcs_expand (const PcsPool & cur, PcsPool & nw, const PcsPool & bi
           const int d = newcount;
           nw.calls[(size_t) d * PCS_MAXN + lane] = (lane == who) ? (int8_t) jk : cur.calls[(size_t) sk * PCS_MAXN + lane];
           const double pr = pcs_bcast (prior, k);
-          const int hk = pcs_bcast (hets, k), nk = pcs_bcast (nall, k);
+          const int hk = pcs_bcast (hets, k), nk = pcs_bcast (nall, k), dk = pcs_bcast (nden, k);
           int ak = 0;
 #pragma unroll
           for (int q = 0; q < PCS_NA; q++)
@@ -414,6 +488,7 @@ __device__ int pcs_expand (const PcsPool & cur, PcsPool & nw, const PcsPool & bi
               nw.prior[d] = pr;
               nw.post[d] = po;
               nw.hets[d] = (int16_t) hk;
+              nw.nden[d] = (int16_t) dk;
               nw.nall[d] = (int8_t) nk;
               nw.ord[d] = (uint16_t) d;
             }
@@ -427,9 +502,9 @@ __device__ int pcs_expand (const PcsPool & cur, PcsPool & nw, const PcsPool & bi
 // One wave per site.  Outputs are what the reference prints per row: call 0..13 or 14 (N), posterior,
 // site type (0 REF, 1 SNP, 2 DEL, 3 INS, 4 LOW, 5 MULTIALLELIC, 6 MESS; -1 = reference base not A/C/G/T, skipped),
 // Allele_Counts, passes.
-__global__ __launch_bounds__ (64) void pcs_call_kernel (PcsParams P, const uint16_t * reads, const uint8_t * dom_of, const uint8_t * chrom_y,
+__global__ __launch_bounds__ (64) void pcs_call_kernel (PcsParams P, const uint16_t * reads, const uint8_t * dom_of, const uint8_t * chrom_of,
                                                       long n_sites, int8_t * call, double *post_out, int8_t * type_out,
-                                                      int32_t * allele_count, int8_t * n_pass, char *scratch)
+                                                      int32_t * allele_count, int8_t * n_pass, int32_t * denovo_out, char *scratch)
 {
   __shared__ PcsShared sh;
   const int lane = threadIdx.x;
@@ -442,6 +517,7 @@ __global__ __launch_bounds__ (64) void pcs_call_kernel (PcsParams P, const uint1
   for (long site = blockIdx.x; site < n_sites; site += gridDim.x)
     {
       const int dom = dom_of[site];
+      const int chrom = chrom_of[site];
       if (dom > 3)
         {
           if (lane < N)
@@ -455,6 +531,7 @@ __global__ __launch_bounds__ (64) void pcs_call_kernel (PcsParams P, const uint1
             {
               type_out[site] = -1;
               n_pass[site] = 0;
+              denovo_out[site] = 0;
             }
           continue;
         }
@@ -477,7 +554,7 @@ __global__ __launch_bounds__ (64) void pcs_call_kernel (PcsParams P, const uint1
       const double average_depth = (double) tsum / (double) N;
       bool bad_base = average_depth < 8;
       const int sample_count = __popcll (__ballot (lane < N && tot >= 8));
-      if (sample_count < (double) 0.5 * N && !(chrom_y && chrom_y[site]))
+      if (sample_count < (double) 0.5 * N && chrom != 2)
         bad_base = true;
       if (bad_base)
         tot = 0;
@@ -630,7 +707,7 @@ __global__ __launch_bounds__ (64) void pcs_call_kernel (PcsParams P, const uint1
                   bool went_big = big;
                   const int r4 = pcs_bcast (r[4], ind), r5 = pcs_bcast (r[5], ind);
                   const int cnt = pcs_expand (pool[ci], pool[ni], bigp[ni], went_big, total, ind, dom, ct, sh, (total <= PCS_SMALLCAP) ? sh.dup : big_dup,
-                                              r4, r5, P, lane);
+                                              r4, r5, chrom, P, lane);
                   big = went_big;
                   ci = ni;
                   total = pcs_clean (pool[ci], cnt, dom, ct, sh, deep, P, lane);
@@ -916,10 +993,27 @@ __global__ __launch_bounds__ (64) void pcs_call_kernel (PcsParams P, const uint1
         mine = (lane == a) ? ac6[a] : mine;
       if (lane < PCS_NA)
         allele_count[site * PCS_NA + lane] = mine;
+      // ---- de-novo events among the confident calls (pecaller.c:1650-1671): the row's type gets a DENOVO_ prefix
+      int dcount = 0;
+      if (type && P.use_ped)
+        {
+          const int fc = called ? final_call : PCS_NG;
+          const double fp = called ? final_p : 1.0;
+          const int d = lane < N ? P.dad[lane] : -1, m = lane < N ? P.mom[lane] : -1;
+          const int dfc = __shfl (fc, d >= 0 ? d : 0), mfc = __shfl (fc, m >= 0 ? m : 0);
+          const double dfp = __hiloint2double (__shfl (__double2hiint (fp), d >= 0 ? d : 0), __shfl (__double2loint (fp), d >= 0 ? d : 0));
+          const double mfp = __hiloint2double (__shfl (__double2hiint (fp), m >= 0 ? m : 0), __shfl (__double2loint (fp), m >= 0 ? m : 0));
+          if (lane < N && fp >= P.threshold)
+            dcount = pcs_add_denovo (P, fc, (d >= 0 && dfp >= P.threshold) ? dfc : PCS_NG, (m >= 0 && mfp >= P.threshold) ? mfc : PCS_NG, P.sex[lane],
+                                     chrom, dom);
+          for (int o = 32; o; o >>= 1)
+            dcount += __shfl_xor (dcount, o);
+        }
       if (lane == 0)
         {
           type_out[site] = (int8_t) type;
           n_pass[site] = (int8_t) pass;
+          denovo_out[site] = dcount;
         }
       pcs_sync ();
     }

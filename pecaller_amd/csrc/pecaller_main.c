@@ -2,7 +2,7 @@
  * pecaller_main.c -- host program (plain C) with the command line and on-disk formats of the reference's pecaller,
  * calling the MI355X per-site caller through the C-ABI of include/pemap_hip.h (pecall_dev_call_sites).
  *
- *   pecaller_hip pileup_ext sdx no_files outfile Prob_to_call theta haploid[y,n] no_threads use_pedfile[n]
+ *   pecaller_hip pileup_ext sdx no_files outfile Prob_to_call theta haploid[y,n] no_threads use_pedfile[y,n] [pedfile denovo_rate]
  *
  * (src/pecaller.c:227-257.)  It runs in the directory that holds the binary pileups, like the reference: every file
  * whose name contains `pileup_ext` is a sample, in directory order, named by its file name up to the first '.'
@@ -14,8 +14,8 @@
  * threads' call_single_base (1207-1691) is one pecall_dev_call_sites per tile; the worker's sprintf block (1564-1690) is
  * emit_rows below.  Rows are written in genome order (the reference's order depends on thread timing).
  *
- * Not supported (an error, not a silent difference): a pedigree (use_pedfile = y) and the BED guide mode (argc 11 / 13),
- * more than 64 samples.  `no_threads` is validated and unused.
+ * Not supported (an error, not a silent difference): the BED guide mode (argc 11 / 13), more than 64 samples.
+ * `no_threads` is validated and unused.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -109,13 +109,13 @@ typedef struct
 {
   /* one tile of columns */
   uint16_t *reads;              /* [TILE][indiv][6] */
-  uint8_t *ref_base, *chrom_y;
+  uint8_t *ref_base, *chrom;
   char *ref_char;
   int *contig;
   unsigned int *pos;
   int8_t *call, *type;
   double *post;
-  int32_t *ac;
+  int32_t *ac, *denovo;
   long n;
 } tile_t;
 
@@ -152,7 +152,8 @@ emit_rows (const tile_t * t, int indiv, char **contig_names, gzFile outfile, FIL
           minor[strlen (minor) - 1] = '\0';
           am_count[strlen (am_count) - 1] = '\0';
         }
-      fprintf (snpfile, "\n%s\t%d\t%c\t%s\t%s\t%s", frag, (int) t->pos[s], t->ref_char[s], minor, am_count, TYPE_NAME[t->type[s]]);
+      fprintf (snpfile, "\n%s\t%d\t%c\t%s\t%s\t%s%s", frag, (int) t->pos[s], t->ref_char[s], minor, am_count, t->denovo[s] > 0 ? "DENOVO_" : "",
+               TYPE_NAME[t->type[s]]);
       gzprintf (pilefile, "\n%s\t%d\t%c", frag, (int) t->pos[s], t->ref_char[s]);
       for (int i = 0; i < indiv; i++)
         {
@@ -181,16 +182,27 @@ main (int argc, char *argv[])
       printf ("\n Number of threads is limited to 2 to 200.   You entered %d \n\n", no_threads);
       exit (1);
     }
-  if (strchr (argv[9], 'Y') || strchr (argv[9], 'y'))
-    die ("\n pecaller_hip: a pedigree (use_pedfile = %s) is not supported by the device caller", argv[9]);
-  if (argc != 10)
-    die ("\n pecaller_hip: the BED guide mode (%s) is not supported", argv[argc - 1]);
   const double threshold = atof (argv[5]), theta = atof (argv[6]);
   if (theta < 1e-10 || theta > 0.5)
     {
       printf ("\n Encountered impossible value for theta = %g \n", theta);
       exit (1);
     }
+  const int use_ped = (strchr (argv[9], 'Y') || strchr (argv[9], 'y')) ? 1 : 0;
+  double denovo_rate = 0;
+  if (use_ped)
+    {
+      if (argc < 12)
+        die ("\n pecaller_hip: use_pedfile = %s needs the ped file name and the de-novo mutation rate", argv[9]);
+      denovo_rate = atof (argv[11]);
+      if (denovo_rate < 1e-30 || denovo_rate > theta)
+        {
+          printf ("\n Encounted impossible denovo mutation rate of %g with a theta of %g", denovo_rate, theta);
+          exit (1);
+        }
+    }
+  if (argc != (use_ped ? 12 : 10))
+    die ("\n pecaller_hip: the BED guide mode (%s) is not supported", argv[argc - 1]);
   const int haploid = (strchr (argv[7], 'Y') || strchr (argv[7], 'y')) ? 1 : 0;
 
   gzFile outfile, pilefile;
@@ -227,7 +239,7 @@ main (int argc, char *argv[])
   const int no_contigs = atoi (ss);
   unsigned int *frag_store = (unsigned int *) calloc (no_contigs + 2, sizeof (unsigned int)), *frag_pos = frag_store + 1;
   char **contig_names = (char **) calloc (no_contigs + 1, sizeof (char *));
-  uint8_t *is_chry = (uint8_t *) calloc (no_contigs + 1, 1);
+  uint8_t *chrom_type = (uint8_t *) calloc (no_contigs + 1, 1);   /* AUTO 0, CHRX 1, CHRY 2, CHRMT 3 (pecaller.c:98-101) */
   frag_pos[-1] = 0;
   for (int i = 0; i < no_contigs; i++)
     {
@@ -242,7 +254,7 @@ main (int argc, char *argv[])
       char *pre = strtok (low, ":_- \n");
       for (char *q = pre; q && *q; q++)
         *q = (char) tolower (*q);
-      is_chry[i] = pre && strcmp (pre, "chry") == 0;
+      chrom_type[i] = !pre ? 0 : !strcmp (pre, "chrx") ? 1 : !strcmp (pre, "chry") ? 2 : !strcmp (pre, "chrmt") ? 3 : 0;
     }
   fclose (sfile);
 
@@ -301,6 +313,61 @@ main (int argc, char *argv[])
   pecall_dev *pc;
   if (pecall_dev_create (&pc, getenv ("PEMAP_DEVICE") ? atoi (getenv ("PEMAP_DEVICE")) : 0))
     die ("\n pecaller_hip: %s", pecall_dev_last_error (NULL));
+  if (use_ped)
+    {
+      /* the ped file: family, individual, father, mother, sex per line (pecaller.c:561-604); parents that are not among the
+         samples are ignored; a parent's kids are numbered in the order of the lines */
+      int dad[64], mom[64], sex[64], nk[64], kid[64][128], off[65], list[128];
+      for (int i = 0; i < 64; i++)
+        {
+          dad[i] = mom[i] = -1;
+          sex[i] = nk[i] = 0;
+        }
+      FILE *pedfile = fopen (argv[10], "r");
+      if (!pedfile)
+        die ("\n Could Not open %s", argv[10]);
+      char line[8192];
+      while (fgets (line, sizeof line, pedfile) && strlen (line) > 5)
+        {
+          strtok (line, "\n\t ");
+          char *ind = strtok (NULL, "\n\t "), *tf = strtok (NULL, "\n\t "), *tm = strtok (NULL, "\n\t "), *ts = strtok (NULL, "\n\t ");
+          if (!ind || !tf || !tm || !ts)
+            die ("\n pecaller_hip: short line in %s", argv[10]);
+          for (int i = 0; i < indiv; i++)
+            if (strcmp (ind, sm[i].name) == 0)
+              {
+                if (strcmp (tf, "0") != 0)
+                  for (int j = 0; j < indiv; j++)
+                    if (strcmp (tf, sm[j].name) == 0)
+                      {
+                        dad[i] = j;
+                        kid[j][nk[j]++] = i;
+                        break;
+                      }
+                if (strcmp (tm, "0") != 0)
+                  for (int j = 0; j < indiv; j++)
+                    if (strcmp (tm, sm[j].name) == 0)
+                      {
+                        mom[i] = j;
+                        kid[j][nk[j]++] = i;
+                        break;
+                      }
+                sex[i] = atoi (ts);
+              }
+        }
+      fclose (pedfile);
+      off[0] = 0;
+      for (int i = 0; i < indiv; i++)
+        {
+          off[i + 1] = off[i] + nk[i];
+          if (off[i + 1] > 128)
+            die ("\n pecaller_hip: too many parent-child links in %s", argv[10]);
+          for (int k = 0; k < nk[i]; k++)
+            list[off[i] + k] = kid[i][k];
+        }
+      if (pecall_dev_set_pedigree (pc, indiv, dad, mom, sex, off, list, denovo_rate))
+        die ("\n pecaller_hip: %s", pecall_dev_last_error (pc));
+    }
 
   int running = no_files;
   for (int i = 0; i < no_files; i++)
@@ -326,7 +393,8 @@ main (int argc, char *argv[])
   tile_t t;
   t.reads = (uint16_t *) malloc ((size_t) TILE * indiv * NA * sizeof (uint16_t));
   t.ref_base = (uint8_t *) malloc (TILE);
-  t.chrom_y = (uint8_t *) malloc (TILE);
+  t.chrom = (uint8_t *) malloc (TILE);
+  t.denovo = (int32_t *) malloc (TILE * sizeof (int32_t));
   t.ref_char = (char *) malloc (TILE);
   t.contig = (int *) malloc (TILE * sizeof (int));
   t.pos = (unsigned int *) malloc (TILE * sizeof (unsigned int));
@@ -356,7 +424,7 @@ main (int argc, char *argv[])
           t.ref_base[s] = (uint8_t) gen_to_int (ref);
           t.contig[s] = which;
           t.pos[s] = 1 + lowest - frag_pos[which - 1];
-          t.chrom_y[s] = is_chry[which];
+          t.chrom[s] = chrom_type[which];
           tot_bases++;
           uint16_t *col = t.reads + (size_t) s * indiv * NA;
           for (i = 0; i < no_files; i++)
@@ -381,7 +449,7 @@ main (int argc, char *argv[])
         }
       if (t.n == TILE || (running <= 0 && t.n > 0))
         {
-          if (pecall_dev_call_sites (pc, t.reads, t.ref_base, t.chrom_y, t.n, indiv, haploid, threshold, theta, t.call, t.post, t.type, t.ac, NULL))
+          if (pecall_dev_call_sites (pc, t.reads, t.ref_base, t.chrom, t.n, indiv, haploid, threshold, theta, t.call, t.post, t.type, t.ac, NULL, t.denovo))
             die ("\n pecaller_hip: %s", pecall_dev_last_error (pc));
           emit_rows (&t, indiv, contig_names, outfile, snpfile, pilefile);
           t.n = 0;

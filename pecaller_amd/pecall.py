@@ -24,7 +24,8 @@ class PecallDev:
         L.pecall_dev_stage.argtypes = [vp, vp, vp, i, i]
         L.pecall_dev_run.argtypes = [vp, i, i, i, i, dbl, i]
         L.pecall_dev_collect.argtypes = [vp, i, i, vp, vp, vp]
-        L.pecall_dev_call_sites.argtypes = [vp, vp, vp, vp, C.c_long, i, i, dbl, dbl, vp, vp, vp, vp, vp]
+        L.pecall_dev_call_sites.argtypes = [vp, vp, vp, vp, C.c_long, i, i, dbl, dbl, vp, vp, vp, vp, vp, vp]
+        L.pecall_dev_set_pedigree.argtypes = [vp, i, vp, vp, vp, vp, vp, dbl]
         self.L = L
         h = vp()
         if L.pecall_dev_create(C.byref(h), device_id):
@@ -72,18 +73,28 @@ class PecallDev:
         self._ck(self.L.pecall_dev_collect(self.h, n_sites, indiv, _p(like), _p(best), _p(margin)))
         return like, best, margin
 
-    def call_sites(self, reads, ref_base, threshold=0.95, theta=0.001, haploid=False, chrom_y=None):
-        """the whole per-site caller (pecaller.c:1207-1691, no pedigree): reads [n_sites][indiv][6] u16, ref_base [n_sites]
-        (0..3 = ACGT, else skipped) -> call [n_sites][indiv] (0..13, 14 = 'N'), posterior, site_type, allele_count, n_pass"""
+    def set_pedigree(self, dad, mom, sex, kid_off, kid_list, denovo_rate):
+        """parents as sample indices (-1 = none), sex, kids of i = kid_list[kid_off[i]:kid_off[i+1]] in ped-file order; None clears"""
+        if dad is None:
+            self._ck(self.L.pecall_dev_set_pedigree(self.h, 0, None, None, None, None, None, 0.0))
+            return
+        a = [np.ascontiguousarray(x, np.int32) for x in (dad, mom, sex, kid_off, kid_list)]
+        self._ck(self.L.pecall_dev_set_pedigree(self.h, len(a[0]), _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(a[4]), float(denovo_rate)))
+
+    def call_sites(self, reads, ref_base, threshold=0.95, theta=0.001, haploid=False, chrom=None):
+        """the whole per-site caller (pecaller.c:1207-1691): reads [n_sites][indiv][6] u16, ref_base [n_sites] (0..3 = ACGT, else
+        skipped), chrom [n_sites] 0 autosome / 1 X / 2 Y / 3 MT -> call [n_sites][indiv] (0..13, 14 = 'N'), posterior, site_type,
+        allele_count, n_pass; self.denovo = d_count per site (with a pedigree)"""
         reads = np.ascontiguousarray(reads, np.uint16)
         ref_base = np.ascontiguousarray(ref_base, np.uint8)
         n_sites, indiv = reads.shape[:2]
-        cy = None if chrom_y is None else np.ascontiguousarray(chrom_y, np.uint8)
+        cy = None if chrom is None else np.ascontiguousarray(chrom, np.uint8)
         call = np.zeros((n_sites, indiv), np.int8)
         post = np.zeros((n_sites, indiv))
         typ = np.zeros(n_sites, np.int8)
         ac = np.zeros((n_sites, ALLELES), np.int32)
         npass = np.zeros(n_sites, np.int8)
+        self.denovo = np.zeros(n_sites, np.int32)
         self._ck(self.L.pecall_dev_call_sites(self.h, _p(reads), _p(ref_base), _p(cy), n_sites, indiv, int(haploid), float(threshold),
-                                              float(theta), _p(call), _p(post), _p(typ), _p(ac), _p(npass)))
+                                              float(theta), _p(call), _p(post), _p(typ), _p(ac), _p(npass), _p(self.denovo)))
         return call, post, typ, ac, npass

@@ -79,3 +79,51 @@ def test_pecaller_cli_outputs(tmp_path):
             assert rows[pos1] == row
         for pos1, row in f["snp_rows"].items():
             assert srows[pos1] == row
+
+
+def test_pecaller_cli_with_pedigree(tmp_path):
+    """use_pedfile = y: the ped file parsed by the host program, DENOVO_ rows"""
+    z = np.load(os.path.join(fx.GOLD, "pecall_ped.npz"))
+    names = [str(x) for x in z["names"]]
+    reads, pos = z["reads"], z["pos"]
+    _, seqs = refio.read_fasta(os.path.join(fx.GOLD, "g1.fa.gz"))
+    shutil.copy(os.path.join(fx.GOLD, "g1.sdx"), tmp_path / "g1.sdx")
+    with gzip.open(tmp_path / "g1.seq", "wb", compresslevel=1) as f:
+        f.write(np.concatenate(seqs).tobytes())
+    run = tmp_path / "run"
+    run.mkdir()
+    for s, nm in enumerate(names):
+        recs = [struct.pack("<I6H", int(pos[i]), *[int(x) for x in reads[i, s]]) for i in range(len(pos)) if reads[i, s].sum() > 0]
+        with gzip.open(run / ("%s.pileup.gz" % nm), "wb", compresslevel=1) as f:
+            f.write(b"".join(recs))
+    dad, mom, sex = z["dad"], z["mom"], z["sex"]
+    with open(tmp_path / "ped.txt", "w") as f:
+        for i, nm in enumerate(names):
+            f.write("fam\t%s\t%s\t%s\t%d\n" % (nm, names[dad[i]] if dad[i] >= 0 else "0", names[mom[i]] if mom[i] >= 0 else "0", sex[i]))
+    subprocess.check_call([EXE, "pileup", str(tmp_path / "g1.sdx"), "20", "out", "0.95", "0.001", "n", "2", "y", str(tmp_path / "ped.txt"), "1e-06"],
+                          cwd=run, stdout=subprocess.DEVNULL)
+    base = gzip.open(run / "out.base.gz", "rt").read().split("\n")
+    cols = [c for c in base[0].split("\t")[3:] if c]
+    perm = [names.index(c) for c in cols]
+    inv = {old: new for new, old in enumerate(perm)}
+    ped = dict(dad=np.array([inv[int(dad[o])] if dad[o] >= 0 else -1 for o in perm]), mom=np.array([inv[int(mom[o])] if mom[o] >= 0 else -1 for o in perm]),
+               sex=np.array([int(sex[o]) for o in perm]), order=[inv[o] for o in range(len(names))], denovo_rate=1e-6)
+    f = fx.load("pecall_ped")
+    r = reads[:, perm, :]
+    call, p, typ, ac, _ = oracle_py.call_sites(r, f["dom"], ped=ped)
+    den = oracle_py.call_sites.denovo
+    rows = {int(x.split("\t")[1]): x for x in base[1:] if x}
+    srows = {int(x.split("\t")[1]): x for x in open(run / "out.snp").read().split("\n")[1:] if x}
+    n_den = 0
+    for i, q in enumerate(pos):
+        pos1 = int(q) + 1
+        if f["dom"][i] > 3 or r[i].sum() == 0:
+            continue
+        assert rows[pos1] == fx.base_row("chr1", pos1, chr(f["ref"][i]), call[i], p[i]), pos1
+        if typ[i] > 0:
+            assert srows[pos1] == fx.snp_row("chr1", pos1, chr(f["ref"][i]), call[i], p[i], typ[i], ac[i], den[i]), pos1
+            n_den += den[i] > 0
+    assert n_den >= 10
+    if cols == [str(x) for x in z["columns"]]:
+        for pos1, row in f["snp_rows"].items():
+            assert srows[pos1] == row

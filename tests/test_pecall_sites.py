@@ -90,3 +90,34 @@ def test_gpu_site_caller_64_samples_and_haploid():
         for a, b in zip(got[2:], exp[2:]):
             assert np.array_equal(a, b)
     dev.close()
+
+
+@pytest.mark.gpu
+def test_gpu_site_caller_with_pedigree():
+    """two trios, a second child and a child without a sampled father: calls, posteriors, types and DENOVO_ counts"""
+    from pecaller_amd.pecall import PecallDev
+    f = fx.load("pecall_ped")
+    ped = f["ped"]
+    off, lst = oracle_py.kid_lists(ped["dad"], ped["mom"], ped["order"])
+    dev = PecallDev(0)
+    dev.set_pedigree(ped["dad"], ped["mom"], ped["sex"], off, lst, ped["denovo_rate"])
+    for chrom_code in (0, 1, 2, 3):                # autosome, X, Y, MT change which parent explains a child's allele
+        chrom = np.full(len(f["dom"]), chrom_code, np.uint8)
+        got = dev.call_sites(f["reads"], f["dom"], chrom=chrom)
+        exp = oracle_py.call_sites(f["reads"], f["dom"], chrom=chrom, ped=ped)
+        assert np.array_equal(got[0], exp[0]), chrom_code
+        assert np.max(np.abs(got[1] - exp[1])) <= 1e-6
+        for a, b in zip(got[2:], exp[2:]):
+            assert np.array_equal(a, b)
+        assert np.array_equal(dev.denovo, oracle_py.call_sites.denovo)
+        if chrom_code == 0:
+            assert (dev.denovo > 0).sum() >= 10
+            bad = [pos1 for i, pos1 in enumerate(f["pos"].astype(int) + 1)
+                   if got[2][i] > 0 and fx.snp_row("chr1", pos1, chr(f["ref"][i]), got[0][i], got[1][i], got[2][i], got[3][i], dev.denovo[i])
+                   != f["snp_rows"].get(pos1)]
+            assert len(bad) <= 1, bad[:3]          # the reference's own rows (a posterior may differ in the sixth digit)
+    dev.set_pedigree(None, None, None, None, None, 0)
+    got = dev.call_sites(f["reads"][:500], f["dom"][:500])
+    exp = oracle_py.call_sites(f["reads"][:500], f["dom"][:500])
+    assert np.array_equal(got[0], exp[0])
+    dev.close()
