@@ -809,9 +809,11 @@ template < int W > static void launch_chunk (pemap_dev * d, const RunCtx & c, ui
                       d->d_redo, &ctr->n_redo, ctr, dirbuf, dump_slab, c.tstride, c.L);
   hipEventRecord (ev[7], d->stream);
   hipEventRecord (ev[9], d->stream);
+  // PEMAP_WALK_BLOCKS_PER_CU: resident 256-lane blocks of the walk per CU (each lane strides over the winners)
+  static const int wbp = getenv ("PEMAP_WALK_BLOCKS_PER_CU") ? atoi (getenv ("PEMAP_WALK_BLOCKS_PER_CU")) : 16;
   int wgrid = (n_ends + 255) / 256;
-  if (wgrid > d->sw_grid)
-    wgrid = d->sw_grid;
+  if (wgrid > d->n_cus * wbp)
+    wgrid = d->n_cus * wbp;
   // the walk (dependent-load latency) goes to the memory stream in the split pipeline: it runs beside the next chunk's vote/SW
   // (measured on MI355X: 107 ms per step against 103 ms with the walk left on the ALU stream, so it is opt-in: PEMAP_WALK_ON_MEM_STREAM=1)
   hipStream_t ws = (split && !d->serial_split && d->walk_on_mem) ? d->stream2 : d->stream;
