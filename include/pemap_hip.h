@@ -176,7 +176,8 @@ int pecall_dev_collect (pecall_dev * dev, int n_sites, int indiv, double *like, 
  *   ref_base[n_sites]                0..3 = A C G T (gen_to_int of the .seq letter); anything else = a site the reference
  *                                    skips (pecaller.c:1208, 1718): calls 'N', posterior 1, site_type -1
  *   chrom_type[n_sites] (may be NULL) 0 autosome, 1 chrX, 2 chrY, 3 chrMT: the lower-cased contig-name prefix rule of
- *                                    pecaller.c:474-482 (chrY lifts the half-the-samples filter, 1303; X/Y/MT change add_denovo)
+ *                                    pecaller.c:474-482 (chrY lifts the half-the-samples filter, 1303; X/Y/MT change add_denovo);
+ *                                    + 16 = HAPLOID forced for the column, as the BED guide mode does on chrY / chrMT (955-957)
  *   haploid / threshold / theta      argv[7] / argv[5] (Prob_to_call) / argv[6] of pecaller
  *   call[n_sites][indiv]             0..13 = A C G T D I M R W S Y K E H (int_to_gen), 14 = 'N'
  *   posterior[n_sites][indiv]        final_p, what the reference prints with %g

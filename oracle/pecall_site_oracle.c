@@ -60,6 +60,7 @@ typedef struct
   int cap_cur, cap_nxt;
   int *idx, *tmp;
   int max_list;                 /* longest list fill_config_probs has built (test coverage statistic) */
+  int site_hap;                 /* HAPLOID of the column: the run's, or forced for chrY / chrMT in BED guide mode (pecaller.c:955-957) */
   /* pedigree (use_ped = y) */
   int use_ped;
   double ln_denovo;
@@ -337,7 +338,7 @@ cfg_init (const Caller * c, Cfg * t, int dom, const int *tot)
       {
         t->calls[i] = (int8_t) dom;
         t->gcount[dom]++;
-        t->acount[dom] += c->haploid ? 1 : 2;
+        t->acount[dom] += c->site_hap ? 1 : 2;
         t->homs++;
         t->no_alleles = 1;
       }
@@ -489,7 +490,7 @@ expand_cfgs (Caller * c, int n, int who, int ref, int chrom, double thres, const
             t->prior = (t->no_alleles - 1) * c->ln_theta;
           if (t->no_denovo > 0)
             t->prior += t->no_denovo * c->ln_denovo;
-          if (!c->haploid && t->no_alleles > 1)
+          if (!c->site_hap && t->no_alleles > 1)
             {
               int major = 0, minor = 0;
               for (int k = 1; k < NA; k++)
@@ -653,8 +654,12 @@ alpha_sanity (int (*al)[NA], int max_gen, int (*first)[NA], int ref, int normal_
  * Out: call[indiv] (0..13, 14 = 'N'), p[indiv], allele_count[6] (Allele_Counts of the .snp row), returns the site type
  * (0 REF, 1 SNP, 2 DEL, 3 INS, 4 LOW, 5 MULTIALLELIC, 6 MESS); *n_pass = passes run; *denovo = d_count of the row. */
 static int
-call_site (Caller * c, const uint16_t * rd, int dom, int chrom, int8_t * call, double *p_out, int *allele_count, int *n_pass, int *denovo)
+call_site (Caller * c, const uint16_t * rd, int dom, int chrom_in, int8_t * call, double *p_out, int *allele_count, int *n_pass, int *denovo)
 {
+  /* bit 4 of the chromosome byte: the column is called with HAPLOID forced (only the initial allele counts and the
+     Hardy-Weinberg term see it: max_gen, the depth floor and allele_counts stay the run's) */
+  const int chrom = chrom_in & 3;
+  c->site_hap = c->haploid || (chrom_in & 0x10);
   const int N = c->indiv, G = c->max_gen, md = c->min_depth;
   int reads[N][NA], tot[N], initial_call[N], final_call[N];
   double frac[N][NA], coef[N], like[N][NG + 1], initial_p[N], final_p[N], post_prob[N][NG + 1];
@@ -977,7 +982,7 @@ call_site (Caller * c, const uint16_t * rd, int dom, int chrom, int8_t * call, d
 }
 
 /* reads[n_sites][indiv][6], dom[n_sites] (0..3 = A C G T; anything else is a site the reference skips: outputs 'N'/1, type -1),
- * chrom[n_sites] (0 autosome, 1 chrX, 2 chrY, 3 chrMT; NULL = all autosomal) -> call[n_sites][indiv], p[n_sites][indiv], type[n_sites], allele_count[n_sites][6], n_pass[n_sites] */
+ * chrom[n_sites] (0 autosome, 1 chrX, 2 chrY, 3 chrMT, + 16 = HAPLOID forced for the column; NULL = all autosomal) -> call[n_sites][indiv], p[n_sites][indiv], type[n_sites], allele_count[n_sites][6], n_pass[n_sites] */
 void
 ora_call_sites (void *p, const uint16_t * reads, const uint8_t * dom, const uint8_t * chrom, long n_sites, int8_t * call, double *post,
                 int8_t * type, int32_t * allele_count, int8_t * n_pass, int32_t * denovo)

@@ -220,7 +220,7 @@ __device__ __forceinline__ void pcs_sort (PcsPool & p, int n, int lane)
 
 // clean_config_probs, pecaller.c:2248-2344; returns the new list length
 __device__ __forceinline__ int pcs_clean (PcsPool & p, int n, int ref, double ct, const PcsShared & sh, unsigned long long deep,
-                                         const PcsParams & P, int lane)
+                                         const PcsParams & P, int site_hap, int lane)
 {
   pcs_sort (p, n, lane);
   int mx = min (PCS_MAXCFG, n);
@@ -253,7 +253,7 @@ __device__ __forceinline__ int pcs_clean (PcsPool & p, int n, int ref, double ct
       if (best_hom > 3)
         best_hom = ref;
       const int s = n;          // slots 0 .. n-1 hold the list, slot n is free
-      pcs_cfg_init (p, s, best_hom, deep, P.haploid, lane);
+      pcs_cfg_init (p, s, best_hom, deep, site_hap, lane);
       pcs_sync ();
       if (lane == 0)
         {
@@ -347,7 +347,7 @@ __device__ __forceinline__ int pcs_denovo_around (const PcsParams & P, const int
 // dupbuf: one byte per list position (LDS for short lists, HBM for long ones).  Returns the length of the list built in nw;
 // nw may be switched to `big_nw` (the wave's pool in HBM) when it outgrows LDS: *went_big is set.
 __device__ int pcs_expand (const PcsPool & cur, PcsPool & nw, const PcsPool & big_nw, bool &went_big, int n, int who, int ref, double thres,
-                           const PcsShared & sh, uint8_t * dupbuf, int r4, int r5, int chrom, const PcsParams & P, int lane)
+                           const PcsShared & sh, uint8_t * dupbuf, int r4, int r5, int chrom, int site_hap, const PcsParams & P, int lane)
 {
   const int G = P.max_gen, N = P.indiv;
   // ---- a configuration equal to an earlier one on every other sample is skipped (pecaller.c:2542-2558)
@@ -416,7 +416,7 @@ __device__ int pcs_expand (const PcsPool & cur, PcsPool & nw, const PcsPool & bi
         prior = (nall - 1) * P.ln_theta;
       if (nden > 0)
         prior += nden * P.ln_denovo;
-      if (!P.haploid && nall > 1)
+      if (!site_hap && nall > 1)
         {
           int major = 0, minor = 0;
 #pragma unroll
@@ -517,7 +517,10 @@ __global__ __launch_bounds__ (64) void pcs_call_kernel (PcsParams P, const uint1
   for (long site = blockIdx.x; site < n_sites; site += gridDim.x)
     {
       const int dom = dom_of[site];
-      const int chrom = chrom_of[site];
+      const int chrom = chrom_of[site] & 3;
+      // bit 4: HAPLOID forced for this column (BED guide mode on chrY / chrMT, pecaller.c:955-957): only the initial allele
+      // counts and the Hardy-Weinberg term see it
+      const int site_hap = P.haploid | ((chrom_of[site] >> 4) & 1);
       if (dom > 3)
         {
           if (lane < N)
@@ -573,7 +576,7 @@ __global__ __launch_bounds__ (64) void pcs_call_kernel (PcsParams P, const uint1
       const int normal_factor = 300;
       if (!bad_base)
         {
-          pcs_cfg_init (pool[0], 0, dom, deep, P.haploid, lane);
+          pcs_cfg_init (pool[0], 0, dom, deep, site_hap, lane);
           if (lane == 0)
             pool[0].ord[0] = 0;
           // ---- fill_alpha_prior (pecaller.c:3043-3139): lane = genotype row
@@ -695,7 +698,7 @@ __global__ __launch_bounds__ (64) void pcs_call_kernel (PcsParams P, const uint1
           for (int i = lane; i < total; i += 64)
             pcs_cfg_like (pool[ci], pool[ci].ord[i], sh, deep, N);
           pcs_sync ();
-          total = pcs_clean (pool[ci], total, dom, ct, sh, deep, P, lane);
+          total = pcs_clean (pool[ci], total, dom, ct, sh, deep, P, site_hap, lane);
           for (int k = 0; k < N; k++)
             {
               const int ind = sh.sord[k];
@@ -707,10 +710,10 @@ __global__ __launch_bounds__ (64) void pcs_call_kernel (PcsParams P, const uint1
                   bool went_big = big;
                   const int r4 = pcs_bcast (r[4], ind), r5 = pcs_bcast (r[5], ind);
                   const int cnt = pcs_expand (pool[ci], pool[ni], bigp[ni], went_big, total, ind, dom, ct, sh, (total <= PCS_SMALLCAP) ? sh.dup : big_dup,
-                                              r4, r5, chrom, P, lane);
+                                              r4, r5, chrom, site_hap, P, lane);
                   big = went_big;
                   ci = ni;
-                  total = pcs_clean (pool[ci], cnt, dom, ct, sh, deep, P, lane);
+                  total = pcs_clean (pool[ci], cnt, dom, ct, sh, deep, P, site_hap, lane);
                 }
               else
                 {

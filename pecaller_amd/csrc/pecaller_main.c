@@ -2,7 +2,7 @@
  * pecaller_main.c -- host program (plain C) with the command line and on-disk formats of the reference's pecaller,
  * calling the MI355X per-site caller through the C-ABI of include/pemap_hip.h (pecall_dev_call_sites).
  *
- *   pecaller_hip pileup_ext sdx no_files outfile Prob_to_call theta haploid[y,n] no_threads use_pedfile[y,n] [pedfile denovo_rate]
+ *   pecaller_hip pileup_ext sdx no_files outfile Prob_to_call theta haploid[y,n] no_threads use_pedfile[y,n] [pedfile denovo_rate] [guide.bed]
  *
  * (src/pecaller.c:227-257.)  It runs in the directory that holds the binary pileups, like the reference: every file
  * whose name contains `pileup_ext` is a sample, in directory order, named by its file name up to the first '.'
@@ -14,8 +14,10 @@
  * threads' call_single_base (1207-1691) is one pecall_dev_call_sites per tile; the worker's sprintf block (1564-1690) is
  * emit_rows below.  Rows are written in genome order (the reference's order depends on thread timing).
  *
- * Not supported (an error, not a silent difference): the BED guide mode (argc 11 / 13), more than 64 samples.
- * `no_threads` is validated and unused.
+ * With a BED guide file (the last argument, pecaller.c:925-1068) every position of the listed intervals is called, covered
+ * or not, and columns on chrY / chrMT are called with HAPLOID forced (955-957).
+ *
+ * Not supported (an error, not a silent difference): more than 64 samples.  `no_threads` is validated and unused.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -201,8 +203,11 @@ main (int argc, char *argv[])
           exit (1);
         }
     }
-  if (argc != (use_ped ? 12 : 10))
-    die ("\n pecaller_hip: the BED guide mode (%s) is not supported", argv[argc - 1]);
+  if (argc != (use_ped ? 12 : 10) && argc != (use_ped ? 13 : 11))
+    die ("\n pecaller_hip: unexpected number of arguments (last: %s)", argv[argc - 1]);
+  FILE *guide_file = NULL;
+  if (argc == (use_ped ? 13 : 11) && !(guide_file = fopen (argv[argc - 1], "r")))
+    die ("\n Can not open file %s for writing which should contain the guide_file", argv[argc - 1]);
   const int haploid = (strchr (argv[7], 'Y') || strchr (argv[7], 'y')) ? 1 : 0;
 
   gzFile outfile, pilefile;
@@ -405,12 +410,38 @@ main (int argc, char *argv[])
   t.n = 0;
   unsigned int tot_bases = 0;
   const int start_chrom = (no_contigs - 1) / 2 > 0 ? (no_contigs - 1) / 2 : 0;
+  /* guide mode state: the current interval [lowest, end] of contig `gwhich` (pecaller.c:927-953, 1040-1066) */
+  unsigned int lowest = 0, gend = 0;
+  int gwhich = -1;
+  if (guide_file)
+    {
+      char line[4096];
+      if (!fgets (line, 4095, guide_file))
+        running = 0;
+      else
+        {
+          char *tok = strtok (line, "\t \n");
+          for (int i = 0; i < no_contigs && tok; i++)
+            if (strcmp (tok, contig_names[i]) == 0)
+              {
+                gwhich = i;
+                break;
+              }
+          if (gwhich < 0)
+            {
+              printf ("\n For line chrom %s \n", tok ? tok : "");
+              exit (1);
+            }
+          lowest = frag_pos[gwhich - 1] + (unsigned int) atoi (strtok (NULL, "\t \n")) - 1;
+          gend = frag_pos[gwhich - 1] + (unsigned int) atoi (strtok (NULL, "\t \n")) - 1;
+        }
+    }
   while (running > 0 || t.n > 0)
     {
-      if (running > 0)
+      if (running > 0 && !guide_file)
         {
           /* find_lowest, pecaller.c:1820-1833 */
-          unsigned int lowest = 0;
+          lowest = 0;
           int i = 0;
           while (lowest < 1 && i < no_files)
             lowest = sm[i++].cur;
@@ -446,6 +477,73 @@ main (int argc, char *argv[])
             else
               for (int a = 0; a < NA; a++)
                 col[i * NA + a] = 0;
+        }
+      else if (running > 0)
+        {
+          /* one position of the guide interval (pecaller.c:941-1039) */
+          const char ref = lowest < gsize ? genome[lowest] : '\0';
+          const long s = t.n++;
+          t.ref_char[s] = ref;
+          t.ref_base[s] = (uint8_t) gen_to_int (ref);
+          t.contig[s] = gwhich;
+          t.pos[s] = 1 + lowest - frag_pos[gwhich - 1];
+          t.chrom[s] = chrom_type[gwhich] | ((chrom_type[gwhich] == 2 || chrom_type[gwhich] == 3) ? 16 : 0);
+          tot_bases++;
+          uint16_t *col = t.reads + (size_t) s * indiv * NA;
+          for (int i = 0; i < no_files; i++)
+            {
+              while (sm[i].cur < lowest && sm[i].cur > 0)
+                advance (&sm[i], &running);
+              if (sm[i].cur == lowest)
+                {
+                  unsigned int cov = 0;
+                  for (int a = 0; a < NA; a++)
+                    {
+                      col[i * NA + a] = sm[i].data[a];
+                      cov += sm[i].data[a];
+                    }
+                  sm[i].mean += (double) cov;
+                  if (cov > sm[i].max_coverage)
+                    sm[i].max_coverage = cov;
+                  sm[i].counts[cov < MAX_DIST - 1 ? cov : MAX_DIST - 1]++;
+                  sm[i].base_count++;
+                  advance (&sm[i], &running);
+                }
+              else
+                {
+                  for (int a = 0; a < NA; a++)
+                    col[i * NA + a] = 0;
+                  sm[i].base_count++;
+                }
+            }
+          lowest++;
+          if (lowest > gend)
+            {
+              char line[4096];
+              line[0] = '\0';
+              if (!feof (guide_file))
+                fgets (line, 4095, guide_file);
+              if (strlen (line) < 5)
+                running = 0;
+              else
+                {
+                  char *tok = strtok (line, "\t \n");
+                  gwhich = -1;
+                  for (int i = 0; i < no_contigs; i++)
+                    if (strcmp (tok, contig_names[i]) == 0)
+                      {
+                        gwhich = i;
+                        break;
+                      }
+                  if (gwhich < 0)
+                    {
+                      printf ("\n For line chrom %s \n", tok);
+                      exit (1);
+                    }
+                  lowest = frag_pos[gwhich - 1] + (unsigned int) atoi (strtok (NULL, "\t \n")) - 1;
+                  gend = frag_pos[gwhich - 1] + (unsigned int) atoi (strtok (NULL, "\t \n")) - 1;
+                }
+            }
         }
       if (t.n == TILE || (running <= 0 && t.n > 0))
         {

@@ -127,3 +127,53 @@ def test_pecaller_cli_with_pedigree(tmp_path):
     if cols == [str(x) for x in z["columns"]]:
         for pos1, row in f["snp_rows"].items():
             assert srows[pos1] == row
+
+
+def test_pecaller_cli_guide_mode(tmp_path):
+    """a BED guide file: every position of the intervals is called (uncovered ones too), chrY / chrMT columns haploid; the
+    device caller itself on the same columns first (the + 16 chromosome flag)"""
+    from pecaller_amd.pecall import PecallDev
+    f = fx.load_guide()
+    dev = PecallDev(0)
+    got = dev.call_sites(f["reads"], f["dom"], chrom=f["chrom"])
+    exp = oracle_py.call_sites(f["reads"], f["dom"], chrom=f["chrom"])
+    assert np.array_equal(got[0], exp[0]) and np.max(np.abs(got[1] - exp[1])) <= 1e-6 and np.array_equal(got[2], exp[2])
+    dev.close()
+    z = f["z"]
+    names = f["names"]
+    _, seqs = refio.read_fasta(os.path.join(fx.GOLD, "g1.fa.gz"))
+    shutil.copy(os.path.join(fx.GOLD, "pecall_guide.sdx"), tmp_path / "g1.sdx")
+    with gzip.open(tmp_path / "g1.seq", "wb", compresslevel=1) as fh:
+        fh.write(np.concatenate(seqs).tobytes())
+    run = tmp_path / "run"
+    run.mkdir()
+    tail = int(z["tail"][0])
+    for s, nm in enumerate(names):
+        recs = [struct.pack("<I6H", int(z["pos"][i]), *[int(x) for x in z["reads"][i, s]]) for i in range(len(z["pos"])) if z["reads"][i, s].sum() > 0]
+        recs += [struct.pack("<I6H", tail + k, 20, 0, 0, 0, 0, 0) for k in range(40)]
+        with gzip.open(run / ("%s.pileup.gz" % nm), "wb", compresslevel=1) as fh:
+            fh.write(b"".join(recs))
+    subprocess.check_call([EXE, "pileup", str(tmp_path / "g1.sdx"), "20", "out", "0.95", "0.001", "n", "2", "n", os.path.join(fx.GOLD, "pecall_guide.bed")],
+                          cwd=run, stdout=subprocess.DEVNULL)
+    base = gzip.open(run / "out.base.gz", "rt").read().split("\n")
+    cols = [c for c in base[0].split("\t")[3:] if c]
+    rows = {(x.split("\t")[0], int(x.split("\t")[1])): x for x in base[1:] if x}
+    srows = {(x.split("\t")[0], int(x.split("\t")[1])): x for x in open(run / "out.snp").read().split("\n")[1:] if x}
+    assert len(rows) == len(f["base_rows"])
+    perm = [f["columns"].index(c) for c in cols]           # this directory's order relative to the fixture's
+    call, p, typ, ac, _ = oracle_py.call_sites(f["reads"][:, perm, :], f["dom"], chrom=f["chrom"])
+    for i, (c, p1, refch) in enumerate(f["key"]):
+        if f["dom"][i] > 3:
+            continue
+        assert rows[(c, p1)] == fx.base_row(c, p1, refch, call[i], p[i]), (c, p1)
+        if typ[i] > 0:
+            assert srows[(c, p1)] == fx.snp_row(c, p1, refch, call[i], p[i], typ[i], ac[i]), (c, p1)
+    got_d = [x.split("\t") for x in open(run / "out.dist").read().split("\n")]
+    exp_d = [x.split("\t") for x in open(os.path.join(fx.GOLD, "pecall_guide.dist.txt")).read().split("\n")]
+    assert len(got_d) == len(exp_d)
+    for g, e in zip(got_d, exp_d):
+        assert g[0] == e[0]
+        if len(g) > 1:
+            assert dict(zip(got_d[0][1:], g[1:])) == dict(zip(exp_d[0][1:], e[1:])), g[0]
+    if cols == f["columns"]:
+        assert rows == f["base_rows"] and srows == f["snp_rows"]

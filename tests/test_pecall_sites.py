@@ -121,3 +121,21 @@ def test_gpu_site_caller_with_pedigree():
     exp = oracle_py.call_sites(f["reads"][:500], f["dom"][:500])
     assert np.array_equal(got[0], exp[0])
     dev.close()
+
+
+def test_site_oracle_guide_mode_matches_reference_text():
+    """BED guide mode: every position of the intervals, uncovered ones included; chrY / chrMT columns with HAPLOID forced"""
+    f = fx.load_guide()
+    call, p, typ, ac, _ = oracle_py.call_sites(f["reads"], f["dom"], chrom=f["chrom"])
+    n = 0
+    for i, (c, p1, refch) in enumerate(f["key"]):
+        if f["dom"][i] > 3:
+            assert (c, p1) not in f["base_rows"]
+            continue
+        n += 1
+        assert fx.base_row(c, p1, refch, call[i], p[i]) == f["base_rows"][(c, p1)], (c, p1)
+        if typ[i] > 0:
+            assert fx.snp_row(c, p1, refch, call[i], p[i], typ[i], ac[i]) == f["snp_rows"][(c, p1)], (c, p1)
+        else:
+            assert (c, p1) not in f["snp_rows"]
+    assert n == len(f["base_rows"]) and len(f["snp_rows"]) > 30
