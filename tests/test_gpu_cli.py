@@ -73,3 +73,22 @@ def test_cli_array_mode_and_max_reads(tmp_path):
     assert r.returncode == 1 and b"Usage" in r.stdout
     r = subprocess.run([EXE, out, sdx, "s", f1, "N", "0.85", "1", "100"], stdout=subprocess.PIPE)
     assert r.returncode == 1 and b"Max_threads" in r.stdout
+
+
+def test_index_builder_cli_writes_reference_files(tmp_path):
+    """index_genome_hip: the reference builder's dialogue on stdin, its four files out (.sdx text, .seq letters, .mdx, .idx)"""
+    exe = os.path.join(ROOT, "pecaller_amd", "index_genome_hip")
+    assert os.path.exists(exe)
+    names, contigs = fixtures.genome()
+    fa = tmp_path / "g1.fa"
+    with gzip.open(os.path.join(fixtures.GOLD, "g1.fa.gz"), "rb") as f, open(fa, "wb") as o:
+        shutil.copyfileobj(f, o)
+    ans = "S\n%d\n%s\n%s\nN\n" % (len(names) + 2, fa, tmp_path / "out")
+    subprocess.run([exe], input=ans.encode(), stdout=subprocess.DEVNULL, check=True)
+    assert open(tmp_path / "out.sdx").read() == open(os.path.join(fixtures.GOLD, "g1.sdx")).read()
+    ix = fixtures.index()
+    assert gzip.open(tmp_path / "out.seq", "rb").read() == ix["genome"].tobytes()
+    assert np.array_equal(np.fromfile(tmp_path / "out.mdx", dtype="<u4"), ix["mers"])
+    assert refio.md5(np.fromfile(tmp_path / "out.mdx", dtype="<u4")) == fixtures.meta()["index"]["mdx_md5"]
+    uk, us = refio.idx_to_compact(str(tmp_path / "out.idx"))
+    assert np.array_equal(uk, ix["ukmer"]) and np.array_equal(us, ix["ustart"])
