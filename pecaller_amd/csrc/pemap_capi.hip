@@ -46,6 +46,9 @@ struct pemap_dev
   // second set of the arrays the walk kernel reads, so that walk(chunk k) can run beside vote/SW(chunk k+1)
   PmHits hits2;
   uint32_t *d_wins2, *d_dirbuf2;
+  unsigned long long *d_path, *d_path2;        // recorded traceback steps per winning alignment (two sets)
+  uint16_t *d_nsteps, *d_nsteps2;
+  int path_words, path_cap_ends;
   hipEvent_t ev_alu_done[2], ev_walk_done[2];
   uint32_t *d_m1, *d_m2;
   int *d_mtype;
@@ -141,6 +144,9 @@ extern "C" int pemap_dev_create (pemap_dev ** out, int device_id)
   memset (&d->hits, 0, sizeof (d->hits));
   memset (&d->hits2, 0, sizeof (d->hits2));
   d->d_wins2 = d->d_dirbuf2 = nullptr;
+  d->d_path = d->d_path2 = nullptr;
+  d->d_nsteps = d->d_nsteps2 = nullptr;
+  d->path_words = d->path_cap_ends = 0;
   d->d_tasks_s = d->d_tasks_m = d->d_redo = d->d_wins = d->d_m1 = d->d_m2 = nullptr;
   d->d_tasks_s2 = d->d_tasks_m2 = nullptr;
   d->vote_on_mem = false;
@@ -246,6 +252,13 @@ static void free_work (pemap_dev * d)
   hipFree (d->d_redo);
   hipFree (d->d_wins);
   hipFree (d->d_wins2);
+  hipFree (d->d_path);
+  hipFree (d->d_path2);
+  hipFree (d->d_nsteps);
+  hipFree (d->d_nsteps2);
+  d->d_path = d->d_path2 = nullptr;
+  d->d_nsteps = d->d_nsteps2 = nullptr;
+  d->path_words = d->path_cap_ends = 0;
   d->d_tasks_s = d->d_tasks_m = d->d_redo = d->d_wins = d->d_wins2 = nullptr;
   d->cap_ends = 0;
 }
@@ -595,6 +608,26 @@ static int ensure_work (pemap_dev * d, int n_ends, bool two_sets)
         TRY (dev_alloc (d, &d->d_dirbuf2, need));
       d->dirbuf_dwords = need;
     }
+  // recorded traceback steps: PM_PATH_WORDS words of 32 two-bit steps per read-end
+  const int pwords = PM_PATH_WORDS (d->max_len_staged);
+  if (!d->d_path || n_ends > d->path_cap_ends || pwords != d->path_words || (two_sets && !d->d_path2))
+    {
+      hipFree (d->d_path);
+      hipFree (d->d_path2);
+      hipFree (d->d_nsteps);
+      hipFree (d->d_nsteps2);
+      d->d_path = d->d_path2 = nullptr;
+      d->d_nsteps = d->d_nsteps2 = nullptr;
+      d->path_words = pwords;
+      d->path_cap_ends = n_ends;
+      TRY (dev_alloc (d, &d->d_path, (size_t) n_ends * pwords));
+      TRY (dev_alloc (d, &d->d_nsteps, (size_t) n_ends));
+      if (two_sets)
+        {
+          TRY (dev_alloc (d, &d->d_path2, (size_t) n_ends * pwords));
+          TRY (dev_alloc (d, &d->d_nsteps2, (size_t) n_ends));
+        }
+    }
   // insertion log: 64 bytes per read-end of a chunk is ample for real data; overflow is reported as an error
   size_t want = (size_t) n_ends * 64 + (1u << 20);
   if (want > 0xF0000000ull)
@@ -823,8 +856,18 @@ template < int W > static void launch_chunk (pemap_dev * d, const RunCtx & c, ui
       hipStreamWaitEvent (ws, d->ev_alu_done[slot], 0);
       hipEventRecord (ev[7], ws);
     }
+  unsigned long long *path = set2 ? d->d_path2 : d->d_path;
+  uint16_t *nsteps = set2 ? d->d_nsteps2 : d->d_nsteps;
   hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_walk_kernel < W >), dim3 (wgrid), dim3 (256), 0, ws, c.b, H, wins, ctr, d->d_cur,
-                      dirbuf, c.tstride, d->d_counts, d->d_ins_log, d->ins_cap);
+                      dirbuf, c.tstride, d->d_counts, d->d_ins_log, d->ins_cap, path, d->path_words, nsteps);
+  {
+    // one wave per winning alignment applies the recorded steps to the pileup
+    static const int pbp = getenv ("PEMAP_PILE_BLOCKS_PER_CU") ? atoi (getenv ("PEMAP_PILE_BLOCKS_PER_CU")) : 8;
+    int pgrid = (n_ends + 3) / 4;
+    if (pgrid > d->n_cus * pbp)
+      pgrid = d->n_cus * pbp;
+    hipLaunchKernelGGL (pm_pile_kernel, dim3 (pgrid), dim3 (256), 0, ws, c.b, H, wins, ctr, d->d_counts, path, d->path_words, nsteps);
+  }
   hipEventRecord (ev[8], ws);
   if (split)
     hipEventRecord (d->ev_walk_done[slot], ws);

@@ -653,9 +653,19 @@ __device__ __forceinline__ void pm_log_insertion (uint8_t * ins_log, unsigned in
     atomicExch (&cur->ins_overflow, 1u);
 }
 
+// The traceback in two kernels.  pm_walk_kernel only follows the direction nibbles and records the walk as 2-bit steps
+// (0 diagonal, 1 vertical = deletion, 2 horizontal = inserted base), 32 per 64-bit word, PM_PATH_WORDS(L) words per
+// alignment; insertions -- rare -- are logged there and then.  pm_pile_kernel replays the steps with one WAVE per
+// alignment, lane = step: row and read column of every step come from prefix popcounts, the pileup increments of an
+// alignment go out as a few wave-wide atomic instructions over consecutive positions.  A lane-per-alignment kernel that
+// did both had each of its half million walkers hold a direction line, a read line and a pileup line in L2 at once;
+// they did not fit, every step refetched its lines and the kernel ran at the HBM limit for random 64-byte lines.
+#define PM_PATH_WORDS(L) ((((2 * (L) + 21 + 31) / 32) + 1) & ~1)
+
 template < int W > __global__ __launch_bounds__ (256) void pm_walk_kernel (PmBatch b, PmHits h, const uint32_t * wins, PmCounters * ctr,
                                                                            PmInsCursor * cur, const uint32_t * dirbuf, int tstride,
-                                                                           uint32_t * counts, uint8_t * ins_log, unsigned ins_cap)
+                                                                           uint32_t * counts, uint8_t * ins_log, unsigned ins_cap,
+                                                                           unsigned long long *path, int path_words, uint16_t * n_steps)
 {
   constexpr int DW = PmSwGeom < W >::DW;
   const unsigned n_wins = ctr->n_wins;
@@ -673,6 +683,9 @@ template < int W > __global__ __launch_bounds__ (256) void pm_walk_kernel (PmBat
       const int pad = PM_LPA * W - mm;
       int k = h.stk[o], i = h.sti[o], j = mm;
       int i1 = 0, ins_len = 0;
+      unsigned long long *pw = path + (size_t) w * path_words;
+      unsigned long long acc = 0;
+      int ns = 0;
       while (i > 0 && j > 0)
         {
           i1 = i - 1;
@@ -697,28 +710,20 @@ template < int W > __global__ __launch_bounds__ (256) void pm_walk_kernel (PmBat
                 maxk = (nib & 4u) ? 1 : 0;
             }
           // on the borders the walk ends after this step (i or j becomes 0) and maxk is never used
-          uint32_t *cnt = counts + ((size_t) gpos + (size_t) i1) * 6;
+          const unsigned long long code = (maxi != i) ? ((maxj != j) ? 0ull : 1ull) : 2ull;
+          acc |= code << (2 * (ns & 31));
+          ns++;
+          if ((ns & 31) == 0)
+            {
+              pw[(ns >> 5) - 1] = acc;
+              acc = 0;
+            }
           if (maxi != i)
             {
-              if (maxj != j)
-                {
-                  const uint8_t ch = pm_oriented (read, mm, orient, j1);
-                  const int slot = (ch == 'A') ? 0 : (ch == 'C') ? 1 : (ch == 'G') ? 2 : (ch == 'T') ? 3 : -1;   // pemapper.c:1850-1857
-                  if (slot >= 0)
-                    {
-                      atomicAdd (&cnt[slot], 1u);
-                      incs++;
-                    }
-                }
-              else
-                {
-                  atomicAdd (&cnt[4], 1u);
-                  incs++;
-                }
               if (ins_len > 0)
                 {
                   pm_log_insertion (ins_log, ins_cap, cur, gpos + (uint32_t) i1, read, mm, orient, j, ins_len);
-                  atomicAdd (&cnt[5], 1u);
+                  atomicAdd (&counts[((size_t) gpos + (size_t) i1) * 6 + 5], 1u);
                   incs++;
                   nins++;
                 }
@@ -730,11 +735,13 @@ template < int W > __global__ __launch_bounds__ (256) void pm_walk_kernel (PmBat
           j = maxj;
           k = maxk;
         }
+      if (ns & 31)
+        pw[ns >> 5] = acc;
+      n_steps[w] = (uint16_t) ns;
       if (ins_len > 0 && i >= 1)    // pemapper.c:1918-1958: attached to base[i1] of the last step
         {
-          uint32_t *cnt = counts + ((size_t) gpos + (size_t) i1) * 6;
           pm_log_insertion (ins_log, ins_cap, cur, gpos + (uint32_t) i1, read, mm, orient, j, ins_len);
-          atomicAdd (&cnt[5], 1u);
+          atomicAdd (&counts[((size_t) gpos + (size_t) i1) * 6 + 5], 1u);
           incs++;
           nins++;
         }
@@ -743,4 +750,55 @@ template < int W > __global__ __launch_bounds__ (256) void pm_walk_kernel (PmBat
     atomicAdd (&ctr->pile_incs, incs);
   if (nins)
     atomicAdd (&ctr->n_ins, nins);
+}
+
+// second half: the recorded steps of every alignment applied to the pileup (pemapper.c:1840-1870), one wave per alignment
+__global__ __launch_bounds__ (256) void pm_pile_kernel (PmBatch b, PmHits h, const uint32_t * wins, PmCounters * ctr, uint32_t * counts,
+                                                       const unsigned long long *path, int path_words, const uint16_t * n_steps)
+{
+  const int lane = threadIdx.x & 63;
+  const unsigned n_wins = ctr->n_wins;
+  const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  unsigned long long incs = 0;
+  for (unsigned w = wave; w < n_wins; w += n_waves)
+    {
+      const size_t o = wins[w];
+      const int end = (int) (o / PM_MAX_HITS);
+      int mm;
+      const uint8_t *read = pm_read_ptr (b, end, &mm);
+      const int orient = h.orient[o];
+      const uint32_t gpos = h.gpos[o];
+      const int ns = n_steps[w];
+      const unsigned long long *pw = path + (size_t) w * path_words;
+      int i = h.sti[o], j = mm;
+      for (int s0 = 0; s0 < ns; s0 += 64)
+        {
+          const int s = s0 + lane;
+          int code = 3;
+          if (s < ns)
+            code = (int) ((pw[s >> 5] >> (2 * (s & 31))) & 3ull);
+          const unsigned long long mi = __ballot (code == 0 || code == 1), mj = __ballot (code == 0 || code == 2);
+          const int ib = i - __popcll (mi & below), jb = j - __popcll (mj & below);      // row and column before this step
+          if (code == 0)
+            {
+              const uint8_t ch = pm_oriented (read, mm, orient, jb - 1);
+              const int slot = (ch == 'A') ? 0 : (ch == 'C') ? 1 : (ch == 'G') ? 2 : (ch == 'T') ? 3 : -1;       // pemapper.c:1850-1857
+              if (slot >= 0)
+                atomicAdd (&counts[((size_t) gpos + (size_t) (ib - 1)) * 6 + slot], 1u);
+              incs += slot >= 0;
+            }
+          else if (code == 1)
+            {
+              atomicAdd (&counts[((size_t) gpos + (size_t) (ib - 1)) * 6 + 4], 1u);
+              incs++;
+            }
+          i -= __popcll (mi);
+          j -= __popcll (mj);
+        }
+    }
+  for (int o = 32; o; o >>= 1)
+    incs += __shfl_xor (incs, o);
+  if (lane == 0 && incs)
+    atomicAdd (&ctr->pile_incs, incs);
 }
