@@ -730,9 +730,9 @@ static void launch_lookup (pemap_dev * d, const RunCtx & c, int slot, PmChunkCtr
   // the latency-bound vote kernel running beside it keeps its wave slots
   const char *padenv = getenv ("PEMAP_LOOKUP_LDS_PAD_KB");
   const unsigned pad = (padenv ? (unsigned) atoi (padenv) : 20u) * 1024u;    // 5 look-up workgroups per CU (swept: 8..44 KB)
-  // PEMAP_LOOKUP_WAVES=n (default 6, swept 2..24): n persistent one-wave workgroups per CU; 0 = the workgroup-per-end kernel
+  // PEMAP_LOOKUP_WAVES=n (default 7, swept 2..24): n persistent one-wave workgroups per CU; 0 = the workgroup-per-end kernel
   const char *lwenv = getenv ("PEMAP_LOOKUP_WAVES");
-  const int lw = lwenv ? atoi (lwenv) : 6;
+  const int lw = lwenv ? atoi (lwenv) : 7;
   int lgrid = lw * d->n_cus;
   if (lgrid > c.b.n_ends)
     lgrid = c.b.n_ends;
@@ -842,8 +842,9 @@ template < int W > static void launch_chunk (pemap_dev * d, const RunCtx & c, ui
                       d->d_redo, &ctr->n_redo, ctr, dirbuf, dump_slab, c.tstride, c.L);
   hipEventRecord (ev[7], d->stream);
   hipEventRecord (ev[9], d->stream);
-  // PEMAP_WALK_BLOCKS_PER_CU: resident 256-lane blocks of the walk per CU (each lane strides over the winners)
-  static const int wbp = getenv ("PEMAP_WALK_BLOCKS_PER_CU") ? atoi (getenv ("PEMAP_WALK_BLOCKS_PER_CU")) : 16;
+  // PEMAP_WALK_BLOCKS_PER_CU (default 4, swept 1..16): resident 256-lane blocks of the walk per CU; few enough walkers that
+  // their direction lines stay in L2 between steps
+  static const int wbp = getenv ("PEMAP_WALK_BLOCKS_PER_CU") ? atoi (getenv ("PEMAP_WALK_BLOCKS_PER_CU")) : 4;
   int wgrid = (n_ends + 255) / 256;
   if (wgrid > d->n_cus * wbp)
     wgrid = d->n_cus * wbp;
