@@ -772,8 +772,10 @@ static void launch_vote (pemap_dev * d, const RunCtx & c, bool split, int slot, 
       PmLists L = d->lists[slot];
       L.n_big = &cc->n_big;
       L.positions = &cc->positions;
-      // PEMAP_VOTE_WAVES=n (default 12): n persistent one-wave workgroups per CU; 0 = the workgroup-per-end kernel
-      static const int vw = getenv ("PEMAP_VOTE_WAVES") ? atoi (getenv ("PEMAP_VOTE_WAVES")) : 12;
+      // PEMAP_VOTE_WAVES=n: at most n one-wave workgroups per CU, each striding over the ends; 0 = the workgroup-per-end kernel.
+      // Default 1024 = one wave per end: the dispatcher then places vote waves wherever the look-up and SW waves of the
+      // other stream leave room (measured 71.6 ms per step against 74.9 with 12 persistent waves per CU)
+      static const int vw = getenv ("PEMAP_VOTE_WAVES") ? atoi (getenv ("PEMAP_VOTE_WAVES")) : 1024;
       int vgrid = vw * d->n_cus;
       if (vgrid > n_ends)
         vgrid = n_ends;
