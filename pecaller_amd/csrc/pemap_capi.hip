@@ -938,7 +938,16 @@ static int ensure_pipeline (pemap_dev * d, int chunk_ends)
           HIPCHK (d, hipExtStreamCreateWithCUMask (&d->stream2, 8, mask));
         }
       else
-        HIPCHK (d, hipStreamCreateWithFlags (&d->stream2, hipStreamNonBlocking));
+        {
+          // PEMAP_MEM_PRIO=1 / -1: look-up stream at the highest / lowest priority the device offers (experiment)
+          const char *pe = getenv ("PEMAP_MEM_PRIO");
+          int lo = 0, hi = 0;
+          hipDeviceGetStreamPriorityRange (&lo, &hi);     // lo = least (numerically largest), hi = greatest
+          if (pe && atoi (pe) != 0)
+            HIPCHK (d, hipStreamCreateWithPriority (&d->stream2, hipStreamNonBlocking, atoi (pe) > 0 ? hi : lo));
+          else
+            HIPCHK (d, hipStreamCreateWithFlags (&d->stream2, hipStreamNonBlocking));
+        }
       for (int i = 0; i < 2; i++)
         {
           HIPCHK (d, hipEventCreateWithFlags (&d->ev_lists_ready[i], hipEventDisableTiming));
