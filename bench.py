@@ -181,8 +181,9 @@ def main():
         S = L // 16 + (0 if L % 16 == 0 else 1)
         n_single = (agg["sw_dirs"] - agg["redo"]) / ends      # problems scored once, with nibbles
         n_multi = (agg["sw_score"] - (agg["sw_dirs"] - agg["redo"])) / ends
-        W = 13 if L <= 104 else 19 if L <= 152 else 26 if L <= 208 else 32 if L <= 256 else 38
-        slab = 8 * ((L + 29 + 15) // 16 * 16) * ((W * 4 + 31) // 32) * 4
+        # SW geometry as pick_geom (pemap_capi.hip): lanes per alignment, columns per lane
+        lanes, W = (8, 13) if L <= 104 else (8, 19) if L <= 152 else (8, 26) if L <= 208 else (8, 32) if L <= 256 else (8, 38)
+        slab = lanes * ((L + 21 + lanes + 15) // 16 * 16) * ((W * 4 + 31) // 32) * 4
         per_end = {
             "seed": S * 49 * 2 * 8 + 4.0 * P_e + L,                     # pos_index pairs + bucket payload + the read
             "lookup": S * 49 * 2 * 8 + 4.0 * P_e + L + 5.0 * P_e,       # ... + the (key, segment) lists written for the vote

@@ -531,22 +531,34 @@ static int ensure_reads (pemap_dev * d, int n, int stride, int paired)
   return 0;
 }
 
-// W columns per lane: the smallest instantiation with PM_LPA * W >= the longest staged read
-static int pick_w (int L)
+// SW geometry for the longest staged read L: lanes per alignment and W columns per lane, the smallest instantiation with
+// lanes * W >= L.  8 lanes by default (13 / 19 / 26 / 32 / 38 columns).  PEMAP_SW_LANES=16 gives reads over 152 bases 16 lanes
+// x 13 / 16 / 19 columns instead (three waves per SIMD instead of two or one, more steps per cell): measured equal on
+// 2 x 250 bases (112 ms of SW per 1 M pairs either way), so it stays an option.
+static void pick_geom (int L, int *lanes, int *w)
 {
-  return L <= PM_LPA * 13 ? 13 : L <= PM_LPA * 19 ? 19 : L <= PM_LPA * 26 ? 26 : L <= PM_LPA * 32 ? 32 : 38;
+  static const int want16 = getenv ("PEMAP_SW_LANES") && atoi (getenv ("PEMAP_SW_LANES")) == 16;
+  if (L <= 8 * 13) { *lanes = 8; *w = 13; }
+  else if (L <= 8 * 19) { *lanes = 8; *w = 19; }
+  else if (!want16) { *lanes = 8; *w = L <= 8 * 26 ? 26 : L <= 8 * 32 ? 32 : 38; }
+  else if (L <= 16 * 13) { *lanes = 16; *w = 13; }
+  else if (L <= 16 * 16) { *lanes = 16; *w = 16; }
+  else { *lanes = 16; *w = 19; }
 }
 
-// rows of one lane's region in a direction slab: window rows + the 7 skew steps, rounded up to the 16-step flush unit
+// rows of one lane's region in a direction slab: window rows + the skew steps, rounded up to the 16-step flush unit
 static int tstride_for (int L)
 {
-  return (L + 21 + PM_LPA + 15) & ~15;
+  int lanes, w;
+  pick_geom (L, &lanes, &w);
+  return (L + 21 + lanes + 15) & ~15;
 }
 
 static size_t slab_dwords_for (int L)
 {
-  int W = pick_w (L);
-  return (size_t) PM_LPA * (size_t) tstride_for (L) * (size_t) ((W * 4 + 31) / 32);
+  int lanes, W;
+  pick_geom (L, &lanes, &W);
+  return (size_t) lanes * (size_t) tstride_for (L) * (size_t) ((W * 4 + 31) / 32);
 }
 
 // device bytes the direction slabs of one chunk may take (one slab per read-end); PEMAP_DIR_BUDGET_GB overrides
@@ -817,7 +829,7 @@ static void launch_vote (pemap_dev * d, const RunCtx & c, bool split, int slot, 
 }
 
 // ---- the ALU stream's work for one chunk: (the seed stage unless it ran on the memory stream,) SW, selection, traceback.
-template < int W > static void launch_chunk (pemap_dev * d, const RunCtx & c, uint32_t * m1, uint32_t * m2, int *mt, bool split, int slot,
+template < int W, int LPA > static void launch_chunk (pemap_dev * d, const RunCtx & c, uint32_t * m1, uint32_t * m2, int *mt, bool split, int slot,
                                              PmChunkCtr * cc, hipEvent_t * ev)
 {
   // the arrays the walk reads alternate between two sets in the split pipeline
@@ -831,16 +843,16 @@ template < int W > static void launch_chunk (pemap_dev * d, const RunCtx & c, ui
   PmCounters *ctr = &cc->c;
   if (!(split && d->vote_on_mem))
     launch_vote (d, c, split, slot, cc, ev, d->stream);
-  hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, true >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, H,
+  hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, LPA, true >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, H,
                       tasks_s, &ctr->n_tasks_s, ctr, dirbuf, dump_slab, c.tstride, c.L);
   hipEventRecord (ev[4], d->stream);
-  hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, false >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, H,
+  hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, LPA, false >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, H,
                       tasks_m, &ctr->n_tasks_m, ctr, dirbuf, dump_slab, c.tstride, c.L);
   hipEventRecord (ev[5], d->stream);
   hipLaunchKernelGGL (pm_select_kernel, dim3 ((c.b.n + 255) / 256), dim3 (256), 0, d->stream, c.b, c.prm, H, d->d_redo, wins, ctr,
                       m1, m2, mt);
   hipEventRecord (ev[6], d->stream);
-  hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, true >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, H,
+  hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, LPA, true >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, H,
                       d->d_redo, &ctr->n_redo, ctr, dirbuf, dump_slab, c.tstride, c.L);
   hipEventRecord (ev[7], d->stream);
   hipEventRecord (ev[9], d->stream);
@@ -861,7 +873,7 @@ template < int W > static void launch_chunk (pemap_dev * d, const RunCtx & c, ui
     }
   unsigned long long *path = set2 ? d->d_path2 : d->d_path;
   uint16_t *nsteps = set2 ? d->d_nsteps2 : d->d_nsteps;
-  hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_walk_kernel < W >), dim3 (wgrid), dim3 (256), 0, ws, c.b, H, wins, ctr, d->d_cur,
+  hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_walk_kernel < W, LPA >), dim3 (wgrid), dim3 (256), 0, ws, c.b, H, wins, ctr, d->d_cur,
                       dirbuf, c.tstride, d->d_counts, d->d_ins_log, d->ins_cap, path, d->path_words, nsteps);
   {
     // one wave per winning alignment applies the recorded steps to the pileup
@@ -1122,14 +1134,28 @@ static int run_slice (pemap_dev * d, int first, int n, int sync)
         }
       uint32_t *m1 = d->d_m1 + f, *m2 = d->paired ? d->d_m2 + f : nullptr;
       int *mt = d->d_mtype + f;
-      switch (pick_w (L))
-        {
-        case 13: launch_chunk < 13 > (d, c, m1, m2, mt, split, slot, cc, ev); break;
-        case 19: launch_chunk < 19 > (d, c, m1, m2, mt, split, slot, cc, ev); break;
-        case 26: launch_chunk < 26 > (d, c, m1, m2, mt, split, slot, cc, ev); break;
-        case 32: launch_chunk < 32 > (d, c, m1, m2, mt, split, slot, cc, ev); break;
-        default: launch_chunk < 38 > (d, c, m1, m2, mt, split, slot, cc, ev); break;
-        }
+      {
+        int lanes, w;
+        pick_geom (L, &lanes, &w);
+#define PM_CH(WW, LL) launch_chunk < WW, LL > (d, c, m1, m2, mt, split, slot, cc, ev)
+        if (lanes == 8)
+          switch (w)
+            {
+            case 13: PM_CH (13, 8); break;
+            case 19: PM_CH (19, 8); break;
+            case 26: PM_CH (26, 8); break;
+            case 32: PM_CH (32, 8); break;
+            default: PM_CH (38, 8); break;
+            }
+        else
+          switch (w)
+            {
+            case 13: PM_CH (13, 16); break;
+            case 16: PM_CH (16, 16); break;
+            default: PM_CH (19, 16); break;
+            }
+#undef PM_CH
+      }
       HIPCHK (d, hipGetLastError ());
       if (split && !d->serial_split && k + 2 < nch)
         TRY (enqueue_lookup (k + 2));

@@ -16,7 +16,7 @@
 #define PM_MAX_SEG 19              // segments of a 299-base read
 #define PM_SEED_CAP 1024           // positions per strand kept in LDS; larger lists go to the per-block global scratch
 #define PM_SEG_LIST_MAX 4851       // 48*99 + 99 positions per segment at most (every bucket < too_many_spots)
-#define PM_LPA 8                   // lanes per alignment in the SW kernels (8 or 16: half a DPP row or a whole one)
+// lanes per alignment in the SW kernels are a template parameter: 8 (half a DPP row) or 16 (a whole one)
 // register budget of the SW kernels: 4 VGPRs of state per owned column (two doubles) plus temporaries
 #define PM_WAVES_PER_EU(W) ((W) <= 13 ? 4 : (W) <= 19 ? 3 : (W) <= 32 ? 2 : 1)
 

@@ -193,7 +193,7 @@ template < int W > __device__ __noinline__ uint64_t pm_slow_mask (const uint8_t 
 // steps collected per flush: the smallest count that makes a lane's chunk a whole number of 64-byte lines
 #define PM_STAGE_OF(DW) ((DW) == 2 ? 8 : 16)
 
-template < int W > __device__ __forceinline__ void pm_flush_dirs (const uint32_t * stage, uint32_t * const *slab_of_group, int lane, int tstride,
+template < int W, int PM_LPA > __device__ __forceinline__ void pm_flush_dirs (const uint32_t * stage, uint32_t * const *slab_of_group, int lane, int tstride,
                                                                   int t0)
 {
   constexpr int DW = PmSwGeom < W >::DW;
@@ -211,7 +211,7 @@ template < int W > __device__ __forceinline__ void pm_flush_dirs (const uint32_t
     }
 }
 
-template < int W, bool DIRS >
+template < int W, int PM_LPA, bool DIRS >
 __device__ __forceinline__ void pm_sw_forward (const PmSwTask & tk, int bis, int lane, int nn_max, uint32_t * stage,
                                                uint32_t * const *slab_of_group, int tstride, double &best, int &bk, int &bi)
 {
@@ -351,7 +351,7 @@ __device__ __forceinline__ void pm_sw_forward (const PmSwTask & tk, int bis, int
         {
           __builtin_amdgcn_fence (__ATOMIC_SEQ_CST, "wavefront");
           __builtin_amdgcn_wave_barrier ();
-          pm_flush_dirs < W > (stage, slab_of_group, lane, tstride, t - PM_STAGE);
+          pm_flush_dirs < W, PM_LPA > (stage, slab_of_group, lane, tstride, t - PM_STAGE);
           __builtin_amdgcn_fence (__ATOMIC_SEQ_CST, "wavefront");
           __builtin_amdgcn_wave_barrier ();
         }
@@ -363,7 +363,7 @@ __device__ __forceinline__ void pm_sw_forward (const PmSwTask & tk, int bis, int
         {
           __builtin_amdgcn_fence (__ATOMIC_SEQ_CST, "wavefront");
           __builtin_amdgcn_wave_barrier ();
-          pm_flush_dirs < W > (stage, slab_of_group, lane, tstride, t_end & ~(PM_STAGE - 1));
+          pm_flush_dirs < W, PM_LPA > (stage, slab_of_group, lane, tstride, t_end & ~(PM_STAGE - 1));
           __builtin_amdgcn_fence (__ATOMIC_SEQ_CST, "wavefront");
           __builtin_amdgcn_wave_barrier ();
         }
@@ -384,7 +384,7 @@ __device__ __forceinline__ int pm_wave_max (int v)
 
 // One persistent wave per 64 / PM_LPA problems.  DIRS: the problems are traceable alignments (the only hit of an end, or the winner
 // of a multi-hit end) and write their nibbles to the end's slab.
-template < int W, bool DIRS > __global__ __launch_bounds__ (64, PM_WAVES_PER_EU (W)) void pm_sw_kernel (PmIndex ix, PmBatch b, PmParams prm, PmHits h,
+template < int W, int PM_LPA, bool DIRS > __global__ __launch_bounds__ (64, PM_WAVES_PER_EU (W)) void pm_sw_kernel (PmIndex ix, PmBatch b, PmParams prm, PmHits h,
                                                                                               const uint32_t * tasks,
                                                                                               const unsigned *n_tasks_p, PmCounters * ctr,
                                                                                               uint32_t * dirbuf, uint32_t * dump_slab, int tstride,
@@ -435,7 +435,7 @@ template < int W, bool DIRS > __global__ __launch_bounds__ (64, PM_WAVES_PER_EU 
       int nn_max = pm_wave_max (tk.nn);
       double best;
       int bk, bi;
-      pm_sw_forward < W, DIRS > (tk, prm.bisulfite, lane, nn_max, stage, slab_of_group, tstride, best, bk, bi);
+      pm_sw_forward < W, PM_LPA, DIRS > (tk, prm.bisulfite, lane, nn_max, stage, slab_of_group, tstride, best, bk, bi);
       if (tk.valid && (lane & (PM_LPA - 1)) == 0)
         {
           h.score[o] = best;
@@ -662,7 +662,7 @@ __device__ __forceinline__ void pm_log_insertion (uint8_t * ins_log, unsigned in
 // they did not fit, every step refetched its lines and the kernel ran at the HBM limit for random 64-byte lines.
 #define PM_PATH_WORDS(L) ((((2 * (L) + 21 + 31) / 32) + 1) & ~1)
 
-template < int W > __global__ __launch_bounds__ (256) void pm_walk_kernel (PmBatch b, PmHits h, const uint32_t * wins, PmCounters * ctr,
+template < int W, int PM_LPA > __global__ __launch_bounds__ (256) void pm_walk_kernel (PmBatch b, PmHits h, const uint32_t * wins, PmCounters * ctr,
                                                                            PmInsCursor * cur, const uint32_t * dirbuf, int tstride,
                                                                            uint32_t * counts, uint8_t * ins_log, unsigned ins_cap,
                                                                            unsigned long long *path, int path_words, uint16_t * n_steps)
