@@ -21,6 +21,7 @@
 #include <ctype.h>
 #include <stdint.h>
 #include <zlib.h>
+#include <pthread.h>
 #include "../../include/pemap_hip.h"
 
 #define MAX_FILES 2000
@@ -45,14 +46,60 @@ ck (pemap_dev * dev, int rc)
     }
 }
 
-/* ---- line reader over a gz stream: my_gzgets (pemapper.c:2447-2483) without its 1.2 GB slab */
+/* ---- line reader over a gz stream: my_gzgets (pemapper.c:2447-2483) without its 1.2 GB slab.  The stream is inflated by
+        a thread of its own into a ring of blocks, so the two mate files inflate in parallel with each other, with the line
+        scan and with the GPU batch in flight (the reference inflates on the main thread, pemapper.c:626) */
+#define LR_BLOCK (1 << 22)
+#define LR_RING 8
 typedef struct
 {
   gzFile f;
   char *buf;
   size_t cap, len, pos;
   int eof;
+  pthread_t th;
+  pthread_mutex_t mu;
+  pthread_cond_t cv;
+  char *ring[LR_RING];
+  int ring_len[LR_RING];
+  int head, count, done, stop;
 } lreader;
+
+static void *
+lr_inflate (void *arg)
+{
+  lreader *r = (lreader *) arg;
+  int tail = 0;
+  for (;;)
+    {
+      pthread_mutex_lock (&r->mu);
+      while (r->count == LR_RING && !r->stop)
+        pthread_cond_wait (&r->cv, &r->mu);
+      const int stop = r->stop;
+      if (stop)
+        {
+          r->done = 1;
+          pthread_cond_broadcast (&r->cv);
+        }
+      pthread_mutex_unlock (&r->mu);
+      if (stop)
+        return NULL;
+      int got = gzread (r->f, r->ring[tail], LR_BLOCK);
+      pthread_mutex_lock (&r->mu);
+      if (got <= 0)
+        r->done = 1;
+      else
+        {
+          r->ring_len[tail] = got;
+          r->count++;
+        }
+      pthread_cond_broadcast (&r->cv);
+      pthread_mutex_unlock (&r->mu);
+      if (got <= 0)
+        return NULL;
+      tail = (tail + 1) % LR_RING;
+    }
+}
 
 static void
 lr_open (lreader * r, const char *path)
@@ -60,17 +107,34 @@ lr_open (lreader * r, const char *path)
   r->f = gzopen (path, "r");
   if (!r->f)
     die ("\n Can not open file %s for reading", path);
-  gzbuffer (r->f, 1 << 22);
-  r->cap = 1 << 22;
+  gzbuffer (r->f, 1 << 20);
+  r->cap = 2 * LR_BLOCK;
   r->buf = (char *) malloc (r->cap + 1);
   r->len = r->pos = 0;
   r->eof = 0;
+  r->head = r->count = r->done = r->stop = 0;
+  for (int i = 0; i < LR_RING; i++)
+    r->ring[i] = (char *) malloc (LR_BLOCK);
+  pthread_mutex_init (&r->mu, NULL);
+  pthread_cond_init (&r->cv, NULL);
+  if (pthread_create (&r->th, NULL, lr_inflate, r))
+    die ("\n Can not start the reader thread for %s", path);
 }
 
 static void
 lr_close (lreader * r)
 {
+  /* the caller may stop before the end of the file (max_reads) */
+  pthread_mutex_lock (&r->mu);
+  r->stop = 1;
+  pthread_cond_broadcast (&r->cv);
+  pthread_mutex_unlock (&r->mu);
+  pthread_join (r->th, NULL);
   gzclose (r->f);
+  for (int i = 0; i < LR_RING; i++)
+    free (r->ring[i]);
+  pthread_mutex_destroy (&r->mu);
+  pthread_cond_destroy (&r->cv);
   free (r->buf);
 }
 
@@ -93,16 +157,28 @@ lr_gets (lreader * r)
       memmove (r->buf, r->buf + r->pos, r->len - r->pos);
       r->len -= r->pos;
       r->pos = 0;
-      if (r->len == r->cap)
+      if (r->len + LR_BLOCK > r->cap)
         {
-          r->cap *= 2;
+          r->cap = 2 * (r->len + LR_BLOCK);
           r->buf = (char *) realloc (r->buf, r->cap + 1);
         }
-      int got = gzread (r->f, r->buf + r->len, (unsigned) (r->cap - r->len));
-      if (got <= 0)
-        r->eof = 1;
-      else
-        r->len += (size_t) got;
+      pthread_mutex_lock (&r->mu);
+      while (r->count == 0 && !r->done)
+        pthread_cond_wait (&r->cv, &r->mu);
+      if (r->count == 0)
+        {
+          pthread_mutex_unlock (&r->mu);
+          r->eof = 1;
+          continue;
+        }
+      pthread_mutex_unlock (&r->mu);
+      memcpy (r->buf + r->len, r->ring[r->head], (size_t) r->ring_len[r->head]);
+      r->len += (size_t) r->ring_len[r->head];
+      r->head = (r->head + 1) % LR_RING;
+      pthread_mutex_lock (&r->mu);
+      r->count--;
+      pthread_cond_broadcast (&r->cv);
+      pthread_mutex_unlock (&r->mu);
     }
 }
 
