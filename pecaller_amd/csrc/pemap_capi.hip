@@ -538,6 +538,10 @@ static int ensure_reads (pemap_dev * d, int n, int stride, int paired)
 static void pick_geom (int L, int *lanes, int *w)
 {
   static const int want16 = getenv ("PEMAP_SW_LANES") && atoi (getenv ("PEMAP_SW_LANES")) == 16;
+  static const int want12 = getenv ("PEMAP_SW_LANES") && atoi (getenv ("PEMAP_SW_LANES")) == 12;
+  // experiment: 12 lanes x 13 columns, 5 alignments per wave, 128 VGPRs -> 4 waves per SIMD; measured 33 ms of SW per step
+  // alone against 27.5 for 8 x 19 and much worse beside the look-up waves (27 spilled VGPRs): not the default
+  if (want12 && L > 8 * 13 && L <= 12 * 13) { *lanes = 12; *w = 13; return; }
   if (L <= 8 * 13) { *lanes = 8; *w = 13; }
   else if (L <= 8 * 19) { *lanes = 8; *w = 19; }
   else if (!want16) { *lanes = 8; *w = L <= 8 * 26 ? 26 : L <= 8 * 32 ? 32 : 38; }
@@ -1138,7 +1142,9 @@ static int run_slice (pemap_dev * d, int first, int n, int sync)
         int lanes, w;
         pick_geom (L, &lanes, &w);
 #define PM_CH(WW, LL) launch_chunk < WW, LL > (d, c, m1, m2, mt, split, slot, cc, ev)
-        if (lanes == 8)
+        if (lanes == 12)
+          PM_CH (13, 12);
+        else if (lanes == 8)
           switch (w)
             {
             case 13: PM_CH (13, 8); break;

@@ -136,16 +136,18 @@ template < bool DIRS > __device__ __forceinline__ void pm_cell (const double s0,
     }
 }
 
-// value of lane - 1 (row_shr:1 inside rows of 16 lanes; the first lane of a row reads 0).  The first lane of every
-// 8-lane alignment group overrides what it receives, so the row boundary never shows.
-__device__ __forceinline__ uint32_t pm_from_left (uint32_t v)
+// value of lane - 1.  Alignment groups of 8 or 16 lanes never straddle a DPP row: row_shr:1 (the first lane of a row reads
+// 0).  Other group sizes (12) do: wave_shr:1.  The first lane of every group overrides what it receives either way.
+template < int LPA > __device__ __forceinline__ uint32_t pm_from_left (uint32_t v)
 {
-  return (uint32_t) __builtin_amdgcn_update_dpp (0, (int) v, 0x111, 0xF, 0xF, true);
+  if (LPA == 8 || LPA == 16)
+    return (uint32_t) __builtin_amdgcn_update_dpp (0, (int) v, 0x111, 0xF, 0xF, true);
+  return (uint32_t) __builtin_amdgcn_update_dpp (0, (int) v, 0x138, 0xF, 0xF, true);
 }
 
-__device__ __forceinline__ double pm_from_left (double v)
+template < int LPA > __device__ __forceinline__ double pm_from_left (double v)
 {
-  const uint32_t lo = pm_from_left ((uint32_t) __double2loint (v)), hi = pm_from_left ((uint32_t) __double2hiint (v));
+  const uint32_t lo = pm_from_left < LPA > ((uint32_t) __double2loint (v)), hi = pm_from_left < LPA > ((uint32_t) __double2hiint (v));
   return __hiloint2double ((int) hi, (int) lo);
 }
 
@@ -217,7 +219,7 @@ __device__ __forceinline__ void pm_sw_forward (const PmSwTask & tk, int bis, int
 {
   constexpr int DW = PmSwGeom < W >::DW;
   constexpr int PM_STAGE = PM_STAGE_OF (DW);
-  int g = lane & (PM_LPA - 1);
+  int g = lane % PM_LPA;
   // opaque to the optimiser: otherwise the 2 W border doubles below are computed once per kernel, kept live across the
   // persistent task loop and double the register footprint
   asm volatile ("":"+v" (g));
@@ -284,9 +286,9 @@ __device__ __forceinline__ void pm_sw_forward (const PmSwTask & tk, int bis, int
   for (int t = 1; t <= nn_max + PM_LPA - 1; t++)
     {
       const int i = t - g;
-      double R2in = pm_from_left (R2out);
-      double Dimp = pm_from_left (Dout);
-      const uint32_t r_in = pm_from_left (r_last);
+      double R2in = pm_from_left < PM_LPA > (R2out);
+      double Dimp = pm_from_left < PM_LPA > (Dout);
+      const uint32_t r_in = pm_from_left < PM_LPA > (r_last);
       if (((t - 1) & 7) == 0)
         {
           rw = rw_next;
@@ -369,7 +371,7 @@ __device__ __forceinline__ void pm_sw_forward (const PmSwTask & tk, int bis, int
         }
     }
   // hand the tracker's result to lane g == 0 of the group
-  const int srcl = lane | (PM_LPA - 1);
+  const int srcl = min ((lane / PM_LPA) * PM_LPA + PM_LPA - 1, 63);
   best = __shfl (bst, srcl);
   bk = __shfl (k_b, srcl);
   bi = __shfl (i_b, srcl);
@@ -392,7 +394,7 @@ template < int W, int PM_LPA, bool DIRS > __global__ __launch_bounds__ (64, PM_W
 {
   constexpr int TPW = 64 / PM_LPA;        // tasks per wave
   __shared__ uint32_t stage[DIRS ? 64 * PM_STAGE_OF (PmSwGeom < W >::DW) * PmSwGeom < W >::DW : 4];
-  __shared__ uint32_t *slab_of_group[TPW];
+  __shared__ uint32_t *slab_of_group[TPW + 1];       // + 1: the lanes left over when PM_LPA does not divide 64
   const int lane = threadIdx.x;
   const int q = lane / PM_LPA;
   const unsigned n_tasks = *n_tasks_p;
@@ -402,7 +404,7 @@ template < int W, int PM_LPA, bool DIRS > __global__ __launch_bounds__ (64, PM_W
       __builtin_amdgcn_fence (__ATOMIC_SEQ_CST, "wavefront");
       __builtin_amdgcn_wave_barrier ();
       PmSwTask tk;
-      tk.valid = (base + q) < n_tasks;
+      tk.valid = q < TPW && (base + q) < n_tasks;
       size_t o = 0;
       tk.mm = mm_fill;
       tk.nn = 0;
@@ -427,7 +429,7 @@ template < int W, int PM_LPA, bool DIRS > __global__ __launch_bounds__ (64, PM_W
         {
           // groups without a task flush into the wave's last slab region that is valid: point them at group 0's slab
           // rows beyond the window (never read); simpler: give them the dump slab at the end of the direction buffer
-          if ((lane & (PM_LPA - 1)) == 0)
+          if ((lane % PM_LPA) == 0)
             slab_of_group[q] = tk.valid ? slab : dump_slab;
           __builtin_amdgcn_fence (__ATOMIC_SEQ_CST, "wavefront");
           __builtin_amdgcn_wave_barrier ();
@@ -436,7 +438,7 @@ template < int W, int PM_LPA, bool DIRS > __global__ __launch_bounds__ (64, PM_W
       double best;
       int bk, bi;
       pm_sw_forward < W, PM_LPA, DIRS > (tk, prm.bisulfite, lane, nn_max, stage, slab_of_group, tstride, best, bk, bi);
-      if (tk.valid && (lane & (PM_LPA - 1)) == 0)
+      if (tk.valid && (lane % PM_LPA) == 0)
         {
           h.score[o] = best;
           h.stk[o] = (uint8_t) bk;
