@@ -70,6 +70,9 @@ struct pemap_dev
   hipEvent_t ev[7];
   // two-stream pipeline: the look-up kernel of chunk k+1 (memory stream) runs beside vote/SW/walk of chunk k
   hipStream_t stream2;
+  hipStream_t stream3;          // the vote's own stream (PEMAP_VOTE_ON_MEM=2)
+  hipEvent_t ev_lookup_done[2];
+  int vote_stream;
   int n_cus;
   hipEvent_t ev_lists_ready[2], ev_lists_free[2];
   PmLists lists[2];
@@ -150,6 +153,8 @@ extern "C" int pemap_dev_create (pemap_dev ** out, int device_id)
   d->d_tasks_s = d->d_tasks_m = d->d_redo = d->d_wins = d->d_m1 = d->d_m2 = nullptr;
   d->d_tasks_s2 = d->d_tasks_m2 = nullptr;
   d->vote_on_mem = false;
+  d->stream3 = nullptr;
+  d->vote_stream = 0;
   d->d_cur = nullptr;
   d->dirbuf_dwords = 0;
   memset (&d->last_cur, 0, sizeof (d->last_cur));
@@ -304,6 +309,14 @@ extern "C" void pemap_dev_destroy (pemap_dev * d)
         hipEventDestroy (d->evs[i]);
       hipFree (d->d_chunk_ctr);
       hipStreamDestroy (d->stream2);
+      if (d->stream3)
+        {
+          hipStreamSynchronize (d->stream3);
+          hipStreamDestroy (d->stream3);
+          hipEventDestroy (d->ev_lookup_done[0]);
+          hipEventDestroy (d->ev_lookup_done[1]);
+          d->stream3 = nullptr;
+        }
     }
   hipStreamDestroy (d->stream);
   delete d;
@@ -896,6 +909,8 @@ template < int W, int LPA > static void launch_chunk (pemap_dev * d, const RunCt
 static int absorb_run (pemap_dev * d)
 {
   HIPCHK (d, hipStreamSynchronize (d->stream2));
+  if (d->stream3)
+    HIPCHK (d, hipStreamSynchronize (d->stream3));
   HIPCHK (d, hipStreamSynchronize (d->stream));
   const int nch = d->run_chunks;
   std::vector < PmChunkCtr > hc (nch);
@@ -1014,7 +1029,16 @@ static int run_slice (pemap_dev * d, int first, int n, int sync)
   d->serial_split = pe && atoi (pe) == 2;
   { const char *we = getenv ("PEMAP_WALK_ON_MEM_STREAM"); d->walk_on_mem = we && atoi (we) != 0; }
   // PEMAP_VOTE_ON_MEM=1: the vote runs behind its look-ups on the memory stream, beside the SW / walk of the previous chunk
-  { const char *ve = getenv ("PEMAP_VOTE_ON_MEM"); d->vote_on_mem = split && !d->serial_split && ve && atoi (ve) != 0; }
+  // PEMAP_VOTE_ON_MEM=1: the vote runs behind its look-ups on the memory stream; 2: on a third stream of its own, beside
+  // the SW / walk of the previous chunk and the look-ups of the next
+  { const char *ve = getenv ("PEMAP_VOTE_ON_MEM"); d->vote_on_mem = split && !d->serial_split && ve && atoi (ve) != 0;
+    d->vote_stream = (d->vote_on_mem && atoi (ve) == 2) ? 3 : 2; }
+  if (d->vote_on_mem && d->vote_stream == 3 && !d->stream3)
+    {
+      HIPCHK (d, hipStreamCreateWithFlags (&d->stream3, hipStreamNonBlocking));
+      for (int i = 0; i < 2; i++)
+        HIPCHK (d, hipEventCreateWithFlags (&d->ev_lookup_done[i], hipEventDisableTiming));
+    }
   // chunk: one direction slab per read-end must fit the budget; the two-stream pipeline wants several chunks per run
   size_t slab_bytes = slab_dwords_for (L) * 4;
   long max_ends = (long) (dir_budget_bytes () / slab_bytes);
@@ -1109,9 +1133,17 @@ static int run_slice (pemap_dev * d, int first, int n, int sync)
     if (d->vote_on_mem)
       {
         // the vote fills the array set that the SW / walk of chunk g-2 used
+        hipStream_t vs = d->vote_stream == 3 ? d->stream3 : d->stream2;
+        if (vs != d->stream2)
+          {
+            HIPCHK (d, hipEventRecord (d->ev_lookup_done[slot], d->stream2));
+            HIPCHK (d, hipStreamWaitEvent (vs, d->ev_lookup_done[slot], 0));
+          }
         if (g >= 2)
-          HIPCHK (d, hipStreamWaitEvent (d->stream2, d->ev_walk_done[slot], 0));
-        launch_vote (d, cl, true, slot, d->d_chunk_ctr + g, &d->evs[(size_t) g * PM_NEV], d->stream2);
+          HIPCHK (d, hipStreamWaitEvent (vs, d->ev_walk_done[slot], 0));
+        launch_vote (d, cl, true, slot, d->d_chunk_ctr + g, &d->evs[(size_t) g * PM_NEV], vs);
+        HIPCHK (d, hipEventRecord (d->ev_lists_ready[slot], vs));
+        return 0;
       }
     HIPCHK (d, hipEventRecord (d->ev_lists_ready[slot], d->serial_split ? d->stream : d->stream2));
     return 0;
