@@ -1295,8 +1295,48 @@ extern "C" int pemap_dev_collect (pemap_dev * d, uint32_t * m1, uint32_t * m2, i
 extern "C" int pemap_dev_map_batch (pemap_dev * d, const char *reads1, const int *len1, const char *reads2, const int *len2,
                                     int n, int stride, uint32_t * m1, uint32_t * m2, int *mapping_type)
 {
-  TRY (pemap_dev_stage_reads (d, reads1, len1, reads2, len2, n, stride));
-  TRY (pemap_dev_run (d, 1));
+  // The reads go to the device slice by slice, each slice queued behind the previous one (asynchronous runs continue the same
+  // two-stream pipeline), so the host-to-device copy of slice i + 1 overlaps the kernels of slice i.
+  HIPCHK (d, hipSetDevice (d->device));
+  if (n <= 0)
+    return fail (d, "map_batch: n = %d", n);
+  if (d->paired && (!reads2 || !len2))
+    return fail (d, "map_batch: paired mode needs reads2/len2");
+  if (stride < PEMAP_MIN_READ)
+    return fail (d, "map_batch: stride %d", stride);
+  int mx = 0, mn = 1 << 30;
+  TRY (check_lengths (d, len1, n, &mx, &mn));
+  if (d->paired)
+    TRY (check_lengths (d, len2, n, &mx, &mn));
+  if (mx > stride)
+    return fail (d, "map_batch: a read is longer than the row stride %d", stride);
+  TRY (pemap_dev_sync (d));
+  TRY (ensure_reads (d, n, stride, d->paired));
+  HIPCHK (d, hipMemcpy (d->d_len1, len1, (size_t) n * sizeof (int), hipMemcpyHostToDevice));
+  d->h_len1.assign (len1, len1 + n);
+  d->h_len2.clear ();
+  if (d->paired)
+    {
+      HIPCHK (d, hipMemcpy (d->d_len2, len2, (size_t) n * sizeof (int), hipMemcpyHostToDevice));
+      d->h_len2.assign (len2, len2 + n);
+    }
+  d->n_staged = n;
+  d->staged_paired = d->paired;
+  d->max_len_staged = mx;
+  d->min_len_staged = mn;
+  const char *ce = getenv ("PEMAP_CHUNK_PAIRS");
+  const int slice = (ce && atoi (ce) > 0) ? atoi (ce) : 131072;
+  for (int first = 0; first < n; first += slice)
+    {
+      const int m = n - first < slice ? n - first : slice;
+      HIPCHK (d, hipMemcpy (d->d_reads1 + (size_t) first * stride, reads1 + (size_t) first * stride, (size_t) m * stride, hipMemcpyHostToDevice));
+      if (d->paired)
+        HIPCHK (d, hipMemcpy (d->d_reads2 + (size_t) first * stride, reads2 + (size_t) first * stride, (size_t) m * stride, hipMemcpyHostToDevice));
+      TRY (run_slice (d, first, m, 0));
+    }
+  TRY (pemap_dev_sync (d));
+  d->run_first = 0;
+  d->run_n = n;
   return pemap_dev_collect (d, m1, m2, mapping_type);
 }
 
