@@ -139,3 +139,36 @@ def test_site_oracle_guide_mode_matches_reference_text():
         else:
             assert (c, p1) not in f["snp_rows"]
     assert n == len(f["base_rows"]) and len(f["snp_rows"]) > 30
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 3, 5, 13, 33])
+def test_gpu_site_caller_odd_sample_counts(n):
+    """sample counts that are not multiples of 8 (and below 4: the single-pass rule, pecaller.c:1470), against the oracle"""
+    from pecaller_amd.pecall import PecallDev
+    rng = np.random.default_rng(100 + n)
+    n_sites = 1500
+    dom = rng.integers(0, 4, n_sites).astype(np.uint8)
+    reads = np.zeros((n_sites, n, 6), np.uint16)
+    for s in range(n_sites):
+        var = rng.random() < 0.3
+        q = rng.uniform(0.05, 0.6)
+        alt = int(rng.integers(0, 6))
+        r = int(dom[s])
+        for i in range(n):
+            d = int(rng.poisson(28))
+            g = tuple(alt if (var and rng.random() < q) else r for _ in range(2))
+            cnt = np.bincount(rng.integers(0, 2, d), minlength=2)
+            for k in (0, 1):
+                al = g[k]
+                if al == 5:
+                    reads[s, i, r] += cnt[k]
+                reads[s, i, al] += cnt[k]
+    dev = PecallDev(0)
+    got = dev.call_sites(reads, dom)
+    exp = oracle_py.call_sites(reads, dom)
+    assert np.array_equal(got[0], exp[0])
+    assert np.max(np.abs(got[1] - exp[1])) <= 1e-6
+    for a, b in zip(got[2:], exp[2:]):
+        assert np.array_equal(a, b)
+    dev.close()
