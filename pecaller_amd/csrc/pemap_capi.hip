@@ -767,7 +767,8 @@ static void launch_lookup (pemap_dev * d, const RunCtx & c, int slot, PmChunkCtr
     lgrid = c.b.n_ends;
   const char *lbenv = getenv ("PEMAP_LOOKUP_BATCH");     // look-up rounds (x 64 lanes) a wave keeps in flight: 4, 8 or 16
   const int lb = lbenv ? atoi (lbenv) : 4;
-#define PM_LKW(SM, B) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_lookup_wave_kernel < SM, B >), dim3 (lgrid), dim3 (64), 0, st, c.ix, c.b, c.prm, L)
+  static const int lprio = getenv ("PEMAP_LOOKUP_PRIO") ? atoi (getenv ("PEMAP_LOOKUP_PRIO")) : 0;
+#define PM_LKW(SM, B) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_lookup_wave_kernel < SM, B >), dim3 (lgrid), dim3 (64), 0, st, c.ix, c.b, c.prm, L, lprio)
 #define PM_LK(SM) do { if (lw > 0 && lb >= 16) PM_LKW (SM, 16); else if (lw > 0 && lb >= 8) PM_LKW (SM, 8); else if (lw > 0) PM_LKW (SM, 4); \
     else hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_lookup_kernel < SM >), dim3 (c.b.n_ends), dim3 (PM_SEED_THREADS), pad, st, c.ix, c.b, c.prm, L); } while (0)
   switch (seg_template (c.L))
@@ -805,10 +806,11 @@ static void launch_vote (pemap_dev * d, const RunCtx & c, bool split, int slot, 
       // Default 1024 = one wave per end: the dispatcher then places vote waves wherever the look-up and SW waves of the
       // other stream leave room (measured 71.6 ms per step against 74.9 with 12 persistent waves per CU)
       static const int vw = getenv ("PEMAP_VOTE_WAVES") ? atoi (getenv ("PEMAP_VOTE_WAVES")) : 1024;
+      static const int vprio = getenv ("PEMAP_VOTE_PRIO") ? atoi (getenv ("PEMAP_VOTE_PRIO")) : 0;
       int vgrid = vw * d->n_cus;
       if (vgrid > n_ends)
         vgrid = n_ends;
-#define PM_VT(SM) do { if (vw > 0) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_vote_wave_kernel < SM >), dim3 (vgrid), dim3 (64), 0, st, c.ix, c.b, c.prm, H, L); \
+#define PM_VT(SM) do { if (vw > 0) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_vote_wave_kernel < SM >), dim3 (vgrid), dim3 (64), 0, st, c.ix, c.b, c.prm, H, L, vprio); \
     else hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_vote_kernel < SM >), dim3 (n_ends), dim3 (PM_SEED_THREADS), 0, st, c.ix, c.b, c.prm, \
                                       H, tasks_s, tasks_m, ctr, L, vote_probe); } while (0)
 #define PM_SEEDL(SM) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_seed_kernel < SM >), dim3 (d->big_grid), dim3 (PM_SEED_THREADS), 0, st, c.ix, c.b, \
@@ -850,6 +852,7 @@ template < int W, int LPA > static void launch_chunk (pemap_dev * d, const RunCt
                                              PmChunkCtr * cc, hipEvent_t * ev)
 {
   // the arrays the walk reads alternate between two sets in the split pipeline
+  static const int swprio = getenv ("PEMAP_SW_PRIO") ? atoi (getenv ("PEMAP_SW_PRIO")) : 0;
   const bool set2 = split && slot;
   const PmHits & H = set2 ? d->hits2 : d->hits;
   uint32_t *wins = set2 ? d->d_wins2 : d->d_wins;
@@ -861,16 +864,16 @@ template < int W, int LPA > static void launch_chunk (pemap_dev * d, const RunCt
   if (!(split && d->vote_on_mem))
     launch_vote (d, c, split, slot, cc, ev, d->stream);
   hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, LPA, true >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, H,
-                      tasks_s, &ctr->n_tasks_s, ctr, dirbuf, dump_slab, c.tstride, c.L);
+                      tasks_s, &ctr->n_tasks_s, ctr, dirbuf, dump_slab, c.tstride, c.L, swprio);
   hipEventRecord (ev[4], d->stream);
   hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, LPA, false >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, H,
-                      tasks_m, &ctr->n_tasks_m, ctr, dirbuf, dump_slab, c.tstride, c.L);
+                      tasks_m, &ctr->n_tasks_m, ctr, dirbuf, dump_slab, c.tstride, c.L, swprio);
   hipEventRecord (ev[5], d->stream);
   hipLaunchKernelGGL (pm_select_kernel, dim3 ((c.b.n + 255) / 256), dim3 (256), 0, d->stream, c.b, c.prm, H, d->d_redo, wins, ctr,
                       m1, m2, mt);
   hipEventRecord (ev[6], d->stream);
   hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, LPA, true >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, H,
-                      d->d_redo, &ctr->n_redo, ctr, dirbuf, dump_slab, c.tstride, c.L);
+                      d->d_redo, &ctr->n_redo, ctr, dirbuf, dump_slab, c.tstride, c.L, swprio);
   hipEventRecord (ev[7], d->stream);
   hipEventRecord (ev[9], d->stream);
   // PEMAP_WALK_BLOCKS_PER_CU (default 4, swept 1..16): resident 256-lane blocks of the walk per CU; few enough walkers that

@@ -173,6 +173,17 @@ __device__ __forceinline__ uint32_t pm_neighbour (uint32_t k, int j)
   return (k & ~(3u << sh)) + (alt << sh);
 }
 
+// s_setprio takes an immediate: wave issue priority 0 (default) .. 3 among the waves of a SIMD
+__device__ __forceinline__ void pm_set_prio (int p)
+{
+  if (p == 1)
+    __builtin_amdgcn_s_setprio (1);
+  else if (p == 2)
+    __builtin_amdgcn_s_setprio (2);
+  else if (p == 3)
+    __builtin_amdgcn_s_setprio (3);
+}
+
 #include "pemap_seed.hip.h"
 #include "pemap_seed2.hip.h"
 #include "pemap_sw.hip.h"

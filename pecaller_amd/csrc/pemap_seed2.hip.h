@@ -227,8 +227,9 @@ template < int SMAX > struct __align__ (8) PmLookupWaveShared
   uint8_t seq[2][320];
 };
 
-template < int SMAX, int PM_LW_BATCH > __global__ __launch_bounds__ (64) void pm_lookup_wave_kernel (PmIndex ix, PmBatch b, PmParams prm, PmLists out)
+template < int SMAX, int PM_LW_BATCH > __global__ __launch_bounds__ (64) void pm_lookup_wave_kernel (PmIndex ix, PmBatch b, PmParams prm, PmLists out, int prio)
 {
+  pm_set_prio (prio);
   typedef PmLookupWaveShared < SMAX > SH;
   __shared__ SH sh;
   const int lane = threadIdx.x;
@@ -576,8 +577,9 @@ __device__ __forceinline__ void pm_vote_prefetch (PmVotePre & r, const PmLists &
       }
 }
 
-template < int SMAX > __global__ __launch_bounds__ (64) void pm_vote_wave_kernel (PmIndex ix, PmBatch b, PmParams prm, PmHits h, PmLists in)
+template < int SMAX > __global__ __launch_bounds__ (64) void pm_vote_wave_kernel (PmIndex ix, PmBatch b, PmParams prm, PmHits h, PmLists in, int prio)
 {
+  pm_set_prio (prio);
   __shared__ PmVoteWaveShared sh;
   const int lane = threadIdx.x;
   const int idepth = ix.idepth;

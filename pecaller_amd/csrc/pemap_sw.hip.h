@@ -390,11 +390,13 @@ template < int W, int PM_LPA, bool DIRS > __global__ __launch_bounds__ (64, PM_W
                                                                                               const uint32_t * tasks,
                                                                                               const unsigned *n_tasks_p, PmCounters * ctr,
                                                                                               uint32_t * dirbuf, uint32_t * dump_slab, int tstride,
-                                                                                              int mm_fill)
+                                                                                              int mm_fill, int prio)
 {
   constexpr int TPW = 64 / PM_LPA;        // tasks per wave
   __shared__ uint32_t stage[DIRS ? 64 * PM_STAGE_OF (PmSwGeom < W >::DW) * PmSwGeom < W >::DW : 4];
   __shared__ uint32_t *slab_of_group[TPW + 1];       // + 1: the lanes left over when PM_LPA does not divide 64
+  // issue priority among the waves sharing the SIMD (PEMAP_SW_PRIO)
+  pm_set_prio (prio);
   const int lane = threadIdx.x;
   const int q = lane / PM_LPA;
   const unsigned n_tasks = *n_tasks_p;
