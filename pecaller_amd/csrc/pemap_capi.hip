@@ -810,7 +810,11 @@ static void launch_vote (pemap_dev * d, const RunCtx & c, bool split, int slot, 
       int vgrid = vw * d->n_cus;
       if (vgrid > n_ends)
         vgrid = n_ends;
-#define PM_VT(SM) do { if (vw > 0) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_vote_wave_kernel < SM >), dim3 (vgrid), dim3 (64), 0, st, c.ix, c.b, c.prm, H, L, vprio); \
+      // PEMAP_VOTE_PERSIST=0 selects the lean one-end-per-wave form (120 VGPRs instead of 161).  A/B on one box, three runs each:
+      // 77.6 ms per step against 74.3 -- more resident vote waves take slots from the look-up waves -- so the fat form stays
+      static const int vpersist = getenv ("PEMAP_VOTE_PERSIST") ? atoi (getenv ("PEMAP_VOTE_PERSIST")) : 1;
+#define PM_VT(SM) do { if (vw > 0 && vgrid == n_ends && !vpersist) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_vote_wave_kernel < SM, false >), dim3 (vgrid), dim3 (64), 0, st, c.ix, c.b, c.prm, H, L, vprio); \
+    else if (vw > 0) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_vote_wave_kernel < SM, true >), dim3 (vgrid), dim3 (64), 0, st, c.ix, c.b, c.prm, H, L, vprio); \
     else hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_vote_kernel < SM >), dim3 (n_ends), dim3 (PM_SEED_THREADS), 0, st, c.ix, c.b, c.prm, \
                                       H, tasks_s, tasks_m, ctr, L, vote_probe); } while (0)
 #define PM_SEEDL(SM) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_seed_kernel < SM >), dim3 (d->big_grid), dim3 (PM_SEED_THREADS), 0, st, c.ix, c.b, \

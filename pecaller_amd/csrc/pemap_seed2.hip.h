@@ -577,7 +577,9 @@ __device__ __forceinline__ void pm_vote_prefetch (PmVotePre & r, const PmLists &
       }
 }
 
-template < int SMAX > __global__ __launch_bounds__ (64) void pm_vote_wave_kernel (PmIndex ix, PmBatch b, PmParams prm, PmHits h, PmLists in, int prio)
+// PERSIST: the wave strides over the ends and loads the next end's lists while it votes; otherwise one end per wave (the
+// grid covers the ends) and no second register set
+template < int SMAX, bool PERSIST > __global__ __launch_bounds__ (64) void pm_vote_wave_kernel (PmIndex ix, PmBatch b, PmParams prm, PmHits h, PmLists in, int prio)
 {
   pm_set_prio (prio);
   __shared__ PmVoteWaveShared sh;
@@ -587,10 +589,11 @@ template < int SMAX > __global__ __launch_bounds__ (64) void pm_vote_wave_kernel
   const uint32_t span = (uint32_t) (2 * (max_off - 1));
   PmVotePre nxt;
   pm_vote_prefetch (nxt, in, blockIdx.x, b.n_ends, lane);
-  for (int e = blockIdx.x; e < b.n_ends; e += gridDim.x)
+  for (int e = blockIdx.x; e < b.n_ends; e += PERSIST ? (int) gridDim.x : b.n_ends)
     {
       const PmVotePre cur = nxt;
-      pm_vote_prefetch (nxt, in, e + gridDim.x, b.n_ends, lane);
+      if (PERSIST)
+        pm_vote_prefetch (nxt, in, e + gridDim.x, b.n_ends, lane);
       const int kind = (int) (__shfl (cur.hw, 21) & 0xFFu);
       if (kind == PM_KIND_BIG)
         continue;               // left to pm_seed_kernel in list mode
