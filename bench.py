@@ -201,7 +201,7 @@ def main():
         alg_bytes = per_end[dom] * (ends / a.steps) / launches
         achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
         kname = "pm_%s_kernel" % dom
-        if dom == "lookup" and os.environ.get("PEMAP_LOOKUP_WAVES", "7") != "0":
+        if dom == "lookup" and os.environ.get("PEMAP_LOOKUP_WAVES", "6") != "0":
             kname = "pm_lookup_wave_kernel"     # the persistent wave-per-end form of the look-up kernel (default)
         traffic, tsrc = pmc_traffic(kname, gs, B, L)
         total_b = algorithmic_bytes_per_end(L, P_e, H_e)

@@ -735,7 +735,7 @@ struct PmChunkCtr
   PmCounters c;
   unsigned long long positions;
   unsigned n_big;
-  unsigned pad;
+  unsigned next_end;            // work counter of the persistent look-up waves
 };
 
 #define PM_MAX_CHUNKS 256
@@ -753,15 +753,16 @@ static void launch_lookup (pemap_dev * d, const RunCtx & c, int slot, PmChunkCtr
   PmLists L = d->lists[slot];
   L.n_big = &cc->n_big;
   L.positions = &cc->positions;
+  L.next_end = &cc->next_end;
   hipStream_t st = d->serial_split ? d->stream : d->stream2;
   hipEventRecord (ev[0], st);
   // occupancy knob of the look-up kernel (diagnostic): dynamic LDS padding in KB limits its workgroups per CU, so that
   // the latency-bound vote kernel running beside it keeps its wave slots
   const char *padenv = getenv ("PEMAP_LOOKUP_LDS_PAD_KB");
   const unsigned pad = (padenv ? (unsigned) atoi (padenv) : 20u) * 1024u;    // 5 look-up workgroups per CU (swept: 8..44 KB)
-  // PEMAP_LOOKUP_WAVES=n (default 7, swept 2..24): n persistent one-wave workgroups per CU; 0 = the workgroup-per-end kernel
+  // PEMAP_LOOKUP_WAVES=n (default 6, swept 2..24): n persistent one-wave workgroups per CU; 0 = the workgroup-per-end kernel
   const char *lwenv = getenv ("PEMAP_LOOKUP_WAVES");
-  const int lw = lwenv ? atoi (lwenv) : 7;
+  const int lw = lwenv ? atoi (lwenv) : 6;
   int lgrid = lw * d->n_cus;
   if (lgrid > c.b.n_ends)
     lgrid = c.b.n_ends;

@@ -27,6 +27,7 @@ struct PmLists
   uint32_t *big_list;                  // ends left to the monolithic kernel
   unsigned *n_big;
   unsigned long long *positions;       // P counter
+  unsigned *next_end;                  // work counter of the persistent look-up waves (ends beyond the first grid-ful)
 };
 
 template < int SMAX > struct __align__ (8) PmLookupShared
@@ -227,6 +228,176 @@ template < int SMAX > struct __align__ (8) PmLookupWaveShared
   uint8_t seq[2][320];
 };
 
+// one read-end of the wave-per-end look-up kernel
+template < int SMAX, int PM_LW_BATCH, class SH >
+__device__ __forceinline__ void pm_lookup_one_end (SH & sh, const PmIndex & ix, const PmBatch & b, const PmParams & prm, const PmLists & out, const int e,
+                                                   const int lane, const int idepth, const uint32_t pos_index_0, unsigned long long &n_pos)
+{
+  int len;
+  const uint8_t *src = pm_read_ptr (b, e, &len);
+  // ---- read + reverse complement; N filter (pemapper.c:1552-1559: upper-case 'N' only)
+  int isn = 0;
+  for (int i = lane; i < len; i += 64)
+    {
+      const uint8_t c = src[i];
+      sh.seq[0][i] = c;
+      sh.seq[1][len - 1 - i] = pm_rc (c);
+      isn += (c == 'N');
+    }
+  for (int o = 32; o; o >>= 1)
+    isn += __shfl_xor (isn, o);
+  int total_cuts = len / idepth;    // pemapper.c:1573-1587
+  if (len % idepth == 0)
+    total_cuts--;
+  if (total_cuts > SMAX - 1)
+    total_cuts = SMAX - 1;
+  const int S = total_cuts + 1;
+  PmEndHeader *hd = &out.hdr[e];
+  if (isn >= 1 + len / 10)
+    {
+      if (lane == 0)
+        hd->kind = PM_KIND_SKIP;
+      return;
+    }
+  if (lane <= total_cuts)
+    sh.offsets[lane] = (lane < total_cuts || total_cuts == 0) ? lane * idepth : len - idepth;
+  pm_wave_sync ();
+  if (lane < 2 * S)
+    {
+      const int strand = lane / S, seg = lane - strand * S;
+      const uint8_t *p = &sh.seq[strand][sh.offsets[seg]];
+      uint32_t k = 0;
+#pragma unroll 4
+      for (int i = 0; i < 16; i++)
+        k = (k << 2) + pm_code (p[i], prm.bisulfite);
+      sh.kmer[lane] = k;
+    }
+  pm_wave_sync ();
+  // ---- 2 x S x 49 bucket look-ups (get_mers, pemapper.c:2158-2165): 8-byte gathers, PM_LW_BATCH rounds (x 64 lanes) in
+  //      flight at a time -- a few such waves per CU already hold more lines in flight than DRAM turns around, and the
+  //      small register footprint is what lets the fp64 SW waves stay resident beside them
+#pragma unroll 1
+  for (int r0 = 0; r0 * 64 < 2 * S * 49; r0 += PM_LW_BATCH)
+    {
+      uint32_t v0[PM_LW_BATCH], v1[PM_LW_BATCH];
+#pragma unroll
+      for (int r = 0; r < PM_LW_BATCH; r++)
+        {
+          const int x = lane + (r0 + r) * 64;
+          v0[r] = v1[r] = 0;
+          if (x < 2 * S * 49)
+            {
+              const int sg = x / 49, j = x - sg * 49;
+              const pm_u32x2 pr = *(const pm_u32x2 *) (ix.pos_index + pm_neighbour (sh.kmer[sg], j));
+              v0[r] = pr.x;
+              v1[r] = pr.y;
+            }
+        }
+#pragma unroll
+      for (int r = 0; r < PM_LW_BATCH; r++)
+        {
+          const int x = lane + (r0 + r) * 64;
+          if (x < 2 * S * 49)
+            {
+              // the all-T k-mer's successor is entry 0: `which + 1` is evaluated in 32 bits (pemapper.c:2163)
+              const int sg = x / 49, j = x - sg * 49;
+              const uint32_t nb = pm_neighbour (sh.kmer[sg], j);
+              const uint32_t ln = ((nb == 0xFFFFFFFFu) ? pos_index_0 : v1[r]) - v0[r];
+              sh.it_start[x] = v0[r];
+              sh.it_off[x] = (ln >= PM_TOO_MANY) ? 0xFFFF : (uint16_t) ln;
+            }
+        }
+    }
+  pm_wave_sync ();
+  // ---- a segment with any bucket >= too_many_spots is emptied (pemapper.c:1602-1606); one lane per segment
+  int cnt = 0;
+  if (lane < 2 * S)
+    {
+      int sum = 0;
+      bool bad = false;
+#pragma unroll 7
+      for (int j = 0; j < 49; j++)
+        {
+          const uint16_t ln = sh.it_off[lane * 49 + j];
+          sh.it_off[lane * 49 + j] = (uint16_t) sum;
+          if (ln == 0xFFFF)
+            bad = true;
+          else
+            sum += ln;
+        }
+      cnt = bad ? 0 : sum;
+    }
+  // exclusive prefix of the segment counts inside each strand (lanes 0..S-1 and S..2S-1)
+  int inc = cnt;
+  for (int o = 1; o < 64; o <<= 1)
+    {
+      const int t = __shfl_up (inc, o);
+      if (lane >= o)
+        inc += t;
+    }
+  const int T0 = __shfl (inc, S - 1), TT = __shfl (inc, 2 * S - 1);
+  const int T1 = TT - T0;
+  if (lane < 2 * S)
+    {
+      const int strand = lane / S, seg = lane - strand * S;
+      sh.seg_base[strand][seg] = inc - cnt - (strand ? T0 : 0);
+    }
+  if (lane == 0)
+    {
+      sh.seg_base[0][S] = T0;
+      sh.seg_base[1][S] = T1;
+    }
+  pm_wave_sync ();
+  if (T0 > PM_SEED_CAP || T1 > PM_SEED_CAP)
+    {
+      if (lane == 0)
+        {
+          hd->kind = PM_KIND_BIG;
+          out.big_list[atomicAdd (out.n_big, 1u)] = (uint32_t) e;
+        }
+      return;
+    }
+  if (lane == 0)
+    {
+      hd->kind = PM_KIND_NORMAL;
+      hd->T[0] = (uint16_t) T0;
+      hd->T[1] = (uint16_t) T1;
+    }
+  n_pos += (unsigned long long) TT;
+  if (lane < 2 * (S + 1))
+    {
+      const int st = lane / (S + 1), k = lane - st * (S + 1);
+      hd->seg_base[st][k] = (uint16_t) sh.seg_base[st][k];
+    }
+  // ---- bucket slices -> (diagonal key, segment) lists, one position per lane and round
+  uint32_t *okey = out.key + (size_t) e * 2 * PM_SEED_CAP;
+  uint8_t *oseg = out.seg + (size_t) e * 2 * PM_SEED_CAP;
+#pragma unroll 2
+  for (int pp = lane; pp < TT; pp += 64)
+    {
+      const int strand = pp < T0 ? 0 : 1;
+      const int p = strand ? pp - T0 : pp;
+      int seg = 0;
+      while (p >= sh.seg_base[strand][seg + 1])
+        seg++;
+      const int q = p - sh.seg_base[strand][seg];
+      const int x0 = (strand * S + seg) * 49;
+      int lo = 0, hi = 48;  // largest j with it_off[j] <= q: that slice holds position q
+      while (lo < hi)
+        {
+          const int mid = (lo + hi + 1) >> 1;
+          if ((int) sh.it_off[x0 + mid] <= q)
+            lo = mid;
+          else
+            hi = mid - 1;
+        }
+      const uint32_t m = ix.mers[sh.it_start[x0 + lo] + (uint32_t) (q - (int) sh.it_off[x0 + lo])];
+      okey[strand * PM_SEED_CAP + p] = m + (uint32_t) (PM_DIAG_BIAS - sh.offsets[seg]);
+      oseg[strand * PM_SEED_CAP + p] = (uint8_t) seg;
+    }
+  pm_wave_sync ();
+}
+
 template < int SMAX, int PM_LW_BATCH > __global__ __launch_bounds__ (64) void pm_lookup_wave_kernel (PmIndex ix, PmBatch b, PmParams prm, PmLists out, int prio)
 {
   pm_set_prio (prio);
@@ -236,171 +407,16 @@ template < int SMAX, int PM_LW_BATCH > __global__ __launch_bounds__ (64) void pm
   const int idepth = ix.idepth;
   const uint32_t pos_index_0 = ix.pos_index[0];
   unsigned long long n_pos = 0;
-  for (int e = blockIdx.x; e < b.n_ends; e += gridDim.x)
+  // Ends are handed out through a counter, fetched one end ahead: persistent waves start whenever the other stream's kernels
+  // leave them a slot, and a static stride would make the latest starter the whole kernel's tail.
+  int e_next = (int) gridDim.x + (int) __builtin_amdgcn_readfirstlane ((int) (lane == 0 ? atomicAdd (out.next_end, 1u) : 0u));
+  for (int e = blockIdx.x; e < b.n_ends;)
     {
-      int len;
-      const uint8_t *src = pm_read_ptr (b, e, &len);
-      // ---- read + reverse complement; N filter (pemapper.c:1552-1559: upper-case 'N' only)
-      int isn = 0;
-      for (int i = lane; i < len; i += 64)
-        {
-          const uint8_t c = src[i];
-          sh.seq[0][i] = c;
-          sh.seq[1][len - 1 - i] = pm_rc (c);
-          isn += (c == 'N');
-        }
-      for (int o = 32; o; o >>= 1)
-        isn += __shfl_xor (isn, o);
-      int total_cuts = len / idepth;    // pemapper.c:1573-1587
-      if (len % idepth == 0)
-        total_cuts--;
-      if (total_cuts > SMAX - 1)
-        total_cuts = SMAX - 1;
-      const int S = total_cuts + 1;
-      PmEndHeader *hd = &out.hdr[e];
-      if (isn >= 1 + len / 10)
-        {
-          if (lane == 0)
-            hd->kind = PM_KIND_SKIP;
-          continue;
-        }
-      if (lane <= total_cuts)
-        sh.offsets[lane] = (lane < total_cuts || total_cuts == 0) ? lane * idepth : len - idepth;
-      pm_wave_sync ();
-      if (lane < 2 * S)
-        {
-          const int strand = lane / S, seg = lane - strand * S;
-          const uint8_t *p = &sh.seq[strand][sh.offsets[seg]];
-          uint32_t k = 0;
-#pragma unroll 4
-          for (int i = 0; i < 16; i++)
-            k = (k << 2) + pm_code (p[i], prm.bisulfite);
-          sh.kmer[lane] = k;
-        }
-      pm_wave_sync ();
-      // ---- 2 x S x 49 bucket look-ups (get_mers, pemapper.c:2158-2165): 8-byte gathers, PM_LW_BATCH rounds (x 64 lanes) in
-      //      flight at a time -- a few such waves per CU already hold more lines in flight than DRAM turns around, and the
-      //      small register footprint is what lets the fp64 SW waves stay resident beside them
-#pragma unroll 1
-      for (int r0 = 0; r0 * 64 < 2 * S * 49; r0 += PM_LW_BATCH)
-        {
-          uint32_t v0[PM_LW_BATCH], v1[PM_LW_BATCH];
-#pragma unroll
-          for (int r = 0; r < PM_LW_BATCH; r++)
-            {
-              const int x = lane + (r0 + r) * 64;
-              v0[r] = v1[r] = 0;
-              if (x < 2 * S * 49)
-                {
-                  const int sg = x / 49, j = x - sg * 49;
-                  const pm_u32x2 pr = *(const pm_u32x2 *) (ix.pos_index + pm_neighbour (sh.kmer[sg], j));
-                  v0[r] = pr.x;
-                  v1[r] = pr.y;
-                }
-            }
-#pragma unroll
-          for (int r = 0; r < PM_LW_BATCH; r++)
-            {
-              const int x = lane + (r0 + r) * 64;
-              if (x < 2 * S * 49)
-                {
-                  // the all-T k-mer's successor is entry 0: `which + 1` is evaluated in 32 bits (pemapper.c:2163)
-                  const int sg = x / 49, j = x - sg * 49;
-                  const uint32_t nb = pm_neighbour (sh.kmer[sg], j);
-                  const uint32_t ln = ((nb == 0xFFFFFFFFu) ? pos_index_0 : v1[r]) - v0[r];
-                  sh.it_start[x] = v0[r];
-                  sh.it_off[x] = (ln >= PM_TOO_MANY) ? 0xFFFF : (uint16_t) ln;
-                }
-            }
-        }
-      pm_wave_sync ();
-      // ---- a segment with any bucket >= too_many_spots is emptied (pemapper.c:1602-1606); one lane per segment
-      int cnt = 0;
-      if (lane < 2 * S)
-        {
-          int sum = 0;
-          bool bad = false;
-#pragma unroll 7
-          for (int j = 0; j < 49; j++)
-            {
-              const uint16_t ln = sh.it_off[lane * 49 + j];
-              sh.it_off[lane * 49 + j] = (uint16_t) sum;
-              if (ln == 0xFFFF)
-                bad = true;
-              else
-                sum += ln;
-            }
-          cnt = bad ? 0 : sum;
-        }
-      // exclusive prefix of the segment counts inside each strand (lanes 0..S-1 and S..2S-1)
-      int inc = cnt;
-      for (int o = 1; o < 64; o <<= 1)
-        {
-          const int t = __shfl_up (inc, o);
-          if (lane >= o)
-            inc += t;
-        }
-      const int T0 = __shfl (inc, S - 1), TT = __shfl (inc, 2 * S - 1);
-      const int T1 = TT - T0;
-      if (lane < 2 * S)
-        {
-          const int strand = lane / S, seg = lane - strand * S;
-          sh.seg_base[strand][seg] = inc - cnt - (strand ? T0 : 0);
-        }
-      if (lane == 0)
-        {
-          sh.seg_base[0][S] = T0;
-          sh.seg_base[1][S] = T1;
-        }
-      pm_wave_sync ();
-      if (T0 > PM_SEED_CAP || T1 > PM_SEED_CAP)
-        {
-          if (lane == 0)
-            {
-              hd->kind = PM_KIND_BIG;
-              out.big_list[atomicAdd (out.n_big, 1u)] = (uint32_t) e;
-            }
-          continue;
-        }
-      if (lane == 0)
-        {
-          hd->kind = PM_KIND_NORMAL;
-          hd->T[0] = (uint16_t) T0;
-          hd->T[1] = (uint16_t) T1;
-        }
-      n_pos += (unsigned long long) TT;
-      if (lane < 2 * (S + 1))
-        {
-          const int st = lane / (S + 1), k = lane - st * (S + 1);
-          hd->seg_base[st][k] = (uint16_t) sh.seg_base[st][k];
-        }
-      // ---- bucket slices -> (diagonal key, segment) lists, one position per lane and round
-      uint32_t *okey = out.key + (size_t) e * 2 * PM_SEED_CAP;
-      uint8_t *oseg = out.seg + (size_t) e * 2 * PM_SEED_CAP;
-#pragma unroll 2
-      for (int pp = lane; pp < TT; pp += 64)
-        {
-          const int strand = pp < T0 ? 0 : 1;
-          const int p = strand ? pp - T0 : pp;
-          int seg = 0;
-          while (p >= sh.seg_base[strand][seg + 1])
-            seg++;
-          const int q = p - sh.seg_base[strand][seg];
-          const int x0 = (strand * S + seg) * 49;
-          int lo = 0, hi = 48;  // largest j with it_off[j] <= q: that slice holds position q
-          while (lo < hi)
-            {
-              const int mid = (lo + hi + 1) >> 1;
-              if ((int) sh.it_off[x0 + mid] <= q)
-                lo = mid;
-              else
-                hi = mid - 1;
-            }
-          const uint32_t m = ix.mers[sh.it_start[x0 + lo] + (uint32_t) (q - (int) sh.it_off[x0 + lo])];
-          okey[strand * PM_SEED_CAP + p] = m + (uint32_t) (PM_DIAG_BIAS - sh.offsets[seg]);
-          oseg[strand * PM_SEED_CAP + p] = (uint8_t) seg;
-        }
-      pm_wave_sync ();
+      const int e_cur = e;
+      e = e_next;
+      if (e < b.n_ends)
+        e_next = (int) gridDim.x + (int) __builtin_amdgcn_readfirstlane ((int) (lane == 0 ? atomicAdd (out.next_end, 1u) : 0u));
+      pm_lookup_one_end < SMAX, PM_LW_BATCH > (sh, ix, b, prm, out, e_cur, lane, idepth, pos_index_0, n_pos);
     }
   if (lane == 0 && n_pos)
     atomicAdd (out.positions, n_pos);
