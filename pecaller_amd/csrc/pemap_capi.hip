@@ -869,16 +869,16 @@ template < int W, int LPA > static void launch_chunk (pemap_dev * d, const RunCt
   if (!(split && d->vote_on_mem))
     launch_vote (d, c, split, slot, cc, ev, d->stream);
   hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, LPA, true >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, H,
-                      tasks_s, &ctr->n_tasks_s, ctr, dirbuf, dump_slab, c.tstride, c.L, swprio);
+                      tasks_s, &ctr->n_tasks_s, ctr, dirbuf, dump_slab, c.tstride, c.L, swprio, &ctr->sw_next[0]);
   hipEventRecord (ev[4], d->stream);
   hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, LPA, false >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, H,
-                      tasks_m, &ctr->n_tasks_m, ctr, dirbuf, dump_slab, c.tstride, c.L, swprio);
+                      tasks_m, &ctr->n_tasks_m, ctr, dirbuf, dump_slab, c.tstride, c.L, swprio, &ctr->sw_next[1]);
   hipEventRecord (ev[5], d->stream);
   hipLaunchKernelGGL (pm_select_kernel, dim3 ((c.b.n + 255) / 256), dim3 (256), 0, d->stream, c.b, c.prm, H, d->d_redo, wins, ctr,
                       m1, m2, mt);
   hipEventRecord (ev[6], d->stream);
   hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, LPA, true >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, H,
-                      d->d_redo, &ctr->n_redo, ctr, dirbuf, dump_slab, c.tstride, c.L, swprio);
+                      d->d_redo, &ctr->n_redo, ctr, dirbuf, dump_slab, c.tstride, c.L, swprio, &ctr->sw_next[2]);
   hipEventRecord (ev[7], d->stream);
   hipEventRecord (ev[9], d->stream);
   // PEMAP_WALK_BLOCKS_PER_CU (default 4, swept 1..16): resident 256-lane blocks of the walk per CU; few enough walkers that

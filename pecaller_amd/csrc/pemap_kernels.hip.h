@@ -46,6 +46,7 @@ struct PmCounters
   unsigned long long cells_dirs;
   unsigned long long pile_incs;
   unsigned long long n_ins;
+  unsigned int sw_next[4];         // work counters of the three SW launches of a chunk (single-hit, multi-hit, redo)
 };
 
 // insertion log cursor: survives runs until the host drains the log

@@ -390,7 +390,7 @@ template < int W, int PM_LPA, bool DIRS > __global__ __launch_bounds__ (64, PM_W
                                                                                               const uint32_t * tasks,
                                                                                               const unsigned *n_tasks_p, PmCounters * ctr,
                                                                                               uint32_t * dirbuf, uint32_t * dump_slab, int tstride,
-                                                                                              int mm_fill, int prio)
+                                                                                              int mm_fill, int prio, unsigned *next_task)
 {
   constexpr int TPW = 64 / PM_LPA;        // tasks per wave
   __shared__ uint32_t stage[DIRS ? 64 * PM_STAGE_OF (PmSwGeom < W >::DW) * PmSwGeom < W >::DW : 4];
@@ -401,12 +401,19 @@ template < int W, int PM_LPA, bool DIRS > __global__ __launch_bounds__ (64, PM_W
   const int q = lane / PM_LPA;
   const unsigned n_tasks = *n_tasks_p;
   const size_t slab_dwords = (size_t) PM_LPA * tstride * PmSwGeom < W >::DW;
-  for (unsigned base = blockIdx.x * (unsigned) TPW; base < n_tasks; base += gridDim.x * (unsigned) TPW)
+  // task groups are handed out through a counter, fetched one group ahead (persistent waves start at different times)
+  unsigned base_next = gridDim.x * (unsigned) TPW
+    + (unsigned) __builtin_amdgcn_readfirstlane ((int) (threadIdx.x == 0 ? atomicAdd (next_task, (unsigned) TPW) : 0u));
+  for (unsigned base = blockIdx.x * (unsigned) TPW; base < n_tasks;)
     {
+      const unsigned base_cur = base;
+      base = base_next;
+      if (base < n_tasks)
+        base_next = gridDim.x * (unsigned) TPW + (unsigned) __builtin_amdgcn_readfirstlane ((int) (threadIdx.x == 0 ? atomicAdd (next_task, (unsigned) TPW) : 0u));
       __builtin_amdgcn_fence (__ATOMIC_SEQ_CST, "wavefront");
       __builtin_amdgcn_wave_barrier ();
       PmSwTask tk;
-      tk.valid = q < TPW && (base + q) < n_tasks;
+      tk.valid = q < TPW && (base_cur + q) < n_tasks;
       size_t o = 0;
       tk.mm = mm_fill;
       tk.nn = 0;
@@ -416,7 +423,7 @@ template < int W, int PM_LPA, bool DIRS > __global__ __launch_bounds__ (64, PM_W
       uint32_t *slab = nullptr;
       if (tk.valid)
         {
-          o = tasks[base + q];
+          o = tasks[base_cur + q];
           int end = (int) (o / PM_MAX_HITS);
           tk.read = pm_read_ptr (b, end, &tk.mm);
           tk.nn = h.nn[o];
