@@ -397,11 +397,22 @@ __device__ int pcs_expand (const PcsPool & cur, PcsPool & nw, const PcsPool & bi
         templ -= 1e10;
       if ((j == 13 || j == 5) && r5 < 3)
         templ -= 1e10;
+      // allele counts with the sample's old genotype taken out and the candidate put in (allele_counts[ref][g][.]: one count
+      // for each allele of the genotype, the second only when diploid)
       int ac[PCS_NA], nall = 0;
+      int oa = -1, ob = -1, na, nb;
+      if (g_old < PCS_NG)
+        pcs_het (g_old, oa, ob, ref);
+      pcs_het (j, na, nb, ref);
+      if (P.haploid)
+        {
+          ob = -1;
+          nb = -1;
+        }
 #pragma unroll
       for (int k = 0; k < PCS_NA; k++)
         {
-          ac[k] = cur.acount[s * PCS_NA + k] - (g_old < PCS_NG ? pcs_ac (ref, g_old, k, P.haploid) : 0) + pcs_ac (ref, j, k, P.haploid);
+          ac[k] = cur.acount[s * PCS_NA + k] - (k == oa) - (k == ob) + (k == na) + (k == nb);
           nall += ac[k] > 0;
         }
       const int hets = cur.hets[s] - ((g_old < PCS_NG && g_old >= PCS_NA) ? 1 : 0) + (j >= PCS_NA ? 1 : 0);
@@ -450,7 +461,9 @@ __device__ int pcs_expand (const PcsPool & cur, PcsPool & nw, const PcsPool & bi
         }
       const double post = prior + templ;
       // ---- the reference's acceptance rule, in candidate order (pecaller.c:2628, 2738-2758)
-      unsigned long long m = __ballot (valid);
+      // best_like / best_post only grow, so a candidate that fails the first test against their values at the start of the
+      // chunk fails it later too: only the others take part in the ordered replay
+      unsigned long long m = __ballot (valid && ((templ + thres > best_post) || (templ + 0.01 > best_like)));
       while (m)
         {
           const int k = __ffsll ((long long) m) - 1;
