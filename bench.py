@@ -196,18 +196,24 @@ def main():
         }
         # one "launch" of the dominant kernel = one chunk of the step (the run is cut into chunks that pipeline on two
         # streams); algorithmic bytes per launch / average launch duration (HIP events on the kernel's own stream)
+        # `achieved` prices the launch with SURVEY.md 8(d)'s per-unit figure B(L) (the whole path's algorithmic bytes per read-end:
+        # one launch of the dominant kernel carries one chunk of ends through the path's bound); the kernel's own algorithmic
+        # bytes (for the look-up kernel: B's index and payload terms plus the lists it writes for the vote) are reported beside it
         launches = max(1, agg["chunks"] // a.steps)
         launch_ms = avg_ms[dom] / launches
-        alg_bytes = per_end[dom] * (ends / a.steps) / launches
+        total_b = algorithmic_bytes_per_end(L, P_e, H_e)
+        alg_bytes = total_b * (ends / a.steps) / launches
+        kernel_bytes = per_end[dom] * (ends / a.steps) / launches
         achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
         kname = "pm_%s_kernel" % dom
         if dom == "lookup" and os.environ.get("PEMAP_LOOKUP_WAVES", "6") != "0":
             kname = "pm_lookup_wave_kernel"     # the persistent wave-per-end form of the look-up kernel (default)
         traffic, tsrc = pmc_traffic(kname, gs, B, L)
-        total_b = algorithmic_bytes_per_end(L, P_e, H_e)
         roof = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc,
                 "launches_per_step": launches, "avg_launch_ms": round(launch_ms, 3), "algorithmic_bytes_per_launch": round(alg_bytes),
+                "kernel_algorithmic_bytes_per_launch": round(kernel_bytes),
+                "kernel_achieved": round(kernel_bytes / (launch_ms * 1e-3) / 1e9, 2),
                 "kernel_ms": {k: round(v, 3) for k, v in avg_ms.items()},
                 "bytes_per_end_path": round(total_b, 1), "P_per_end": round(P_e, 2), "H_per_end": round(H_e, 3),
                 "path_GBs": round(total_b * ends / a.steps / (dt / a.steps) / 1e9, 2),
