@@ -78,9 +78,24 @@ def test_length_limits_are_errors():
     dev = PemapDev(0)
     dev.build_index(ix["genome"], ix["contig_len"])
     dev.set_params(paired=False, min_dist=0, max_dist=500, min_align=0.85)
+    with pytest.raises(PemapError):                 # an empty batch is an error, not a silent no-op
+        dev.map_batch(np.zeros((0, 304), np.uint8), np.zeros(0, np.int32), None, None)
     for ln in (15, 279):
         buf = np.full((4, 304), ord("A"), np.uint8)
         lens = np.array([100, 100, ln, 100], np.int32)
         with pytest.raises(PemapError):
             dev.map_batch(buf, lens, None, None)
+    dev.close()
+
+
+def test_caller_argument_errors():
+    from pecaller_amd.pecall import PecallDev
+    from pecaller_amd import PemapError
+    dev = PecallDev(0)
+    with pytest.raises(PemapError):
+        dev.call_sites(np.zeros((0, 8, 6), np.uint16), np.zeros(0, np.uint8))
+    with pytest.raises(PemapError):
+        dev.call_sites(np.zeros((4, 65, 6), np.uint16), np.zeros(4, np.uint8))        # more than 64 samples
+    with pytest.raises(PemapError):
+        dev.call_sites(np.zeros((4, 8, 6), np.uint16), np.zeros(4, np.uint8), theta=0.9)   # pecaller.c:305-309
     dev.close()
