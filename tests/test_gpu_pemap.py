@@ -134,3 +134,39 @@ def test_rerun_is_additive_and_slices_compose(dev):
     assert np.array_equal(c3, c1) and i3 == i1
     assert np.array_equal(np.concatenate([b1[0], b2[0]]), a1[0])
     assert np.array_equal(np.concatenate([b1[1], b2[1]]), a1[1])
+
+
+def test_torch_tensors_alias_the_library_buffers():
+    """what the multi-GPU start-up relies on: torch views of pemap_dev_buffer pointers share memory with the library, so an RCCL
+    broadcast into them lands in the index the kernels read (pecaller_amd/dist.py: device_tensor).  In a process of its own,
+    torch initialised first as bench.py does (torch brings its own HIP runtime)."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np, torch
+torch.cuda.set_device(0)
+import fixtures
+from pecaller_amd import PemapDev, dist as pd
+ix = fixtures.index()
+dev = PemapDev(0)
+dev.build_index(ix["genome"], ix["contig_len"])
+for which in (0, 1, 2, 3):
+    t = pd.device_tensor(torch, dev, which)
+    host = dev.read_buffer(which, np.uint8 if which == 2 else np.uint32, n_bytes=min(4096, t.numel() * t.element_size()))
+    got = t[:len(host)].cpu().numpy()
+    assert np.array_equal(got if which == 2 else got.view(np.uint32), host), which
+t = pd.device_tensor(torch, dev, 3)
+old = t.clone()
+t[0] = 12345
+torch.cuda.synchronize()
+assert dev.read_buffer(3, np.uint32)[0] == 12345
+t.copy_(old)
+torch.cuda.synchronize()
+assert np.array_equal(dev.read_buffer(3, np.uint32), ix["contig_starts"])
+dev.close()
+print("alias ok")
+'''
+    import os
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))]))
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0 and b"alias ok" in r.stdout, r.stdout[-2000:]
