@@ -76,8 +76,21 @@ int pemap_dev_build_index_resident (pemap_dev * dev, const void *d_genome, uint6
 int pemap_dev_index_alloc (pemap_dev * dev, uint64_t n_mers, uint64_t genome_size, int n_contigs, int idepth);
 int pemap_dev_index_commit (pemap_dev * dev);
 
+/* Look-up replicas -- an MI355X-side layout with no counterpart in the reference.  The look-ups of a read-end
+ * (2 x segments x 49 buckets, fill_mers / get_mers, pemapper.c:1969-2003, 2158-2165) cost one 64-byte HBM request each
+ * in the reference's table; index_commit therefore also builds 8 re-ordered copies of the table (128 GiB + the records
+ * of the multi-position buckets) in which a k-mer and its 48 neighbours share 8 lines.  Results are identical either
+ * way.  n = -1: build them when the device has the memory (default; PEMAP_REPLICAS=0/1 in the environment overrides),
+ * 0: never, 8: fail if they cannot be built.  May be called before or after the index is in place. */
+int pemap_dev_set_lookup_replicas (pemap_dev * dev, int n);
+/* how many replicas serve the look-ups now (0 or 8), and the bytes of the multi-position records */
+int pemap_dev_lookup_replicas (pemap_dev * dev, int *n_replicas, uint64_t * record_bytes);
+
 /* Device pointers and sizes of the resident arrays: which = 0 pos_index (u32[2^32+1]), 1 mers (u32[n_mers]),
- * 2 genome (u8[genome_size]), 3 contig_starts (u32[n_contigs+1]), 4 pileup counters (u32[genome_size][6]).
+ * 2 genome (u8[genome_size]), 3 contig_starts (u32[n_contigs+1]), 4 pileup counters (u32[genome_size][6]),
+ * 5 the look-up replicas (u32[8][2^32]; replica p holds the entry of k-mer k at k with its 4-bit fields 0 and p
+ * swapped), 6 the records of the multi-position buckets (16-byte units {count, positions...}); 5 and 6 are empty
+ * (n_bytes = 0) when no replicas are in use.
  * For collectives (broadcast of 0..3 at start-up, sum of 4 at the end) and for copying the index back to the host. */
 int pemap_dev_buffer (pemap_dev * dev, int which, void **d_ptr, uint64_t * n_bytes);
 int pemap_dev_index_info (pemap_dev * dev, uint64_t * n_mers, uint64_t * genome_size, int *n_contigs, int *idepth);

@@ -272,6 +272,184 @@ __global__ __launch_bounds__ (SC_BLOCK) void ix_maxscan_apply_kernel (uint32_t *
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Look-up replicas.  The reference's table costs one 64-byte fabric request per 8-byte look-up, and a read-end makes
+// 2 x S x 49 of them: MI355X serves ~48 G random requests per second whatever their size up to 128 bytes
+// (tools/micro/line_gather.hip), so the look-up phase is bound by the NUMBER of lines it touches.  288 GB of HBM buy
+// that number down: the 2^32-entry table is kept 8 times, replica p ordered by the k-mer with its 4-bit fields 0 and p
+// swapped, so that the 16 k-mers that differ only in bases 2p, 2p+1 (counted from the read's last base) share one
+// 64-byte line of replica p.  A k-mer and its 48 single-substitution neighbours (fill_mers, pemapper.c:1969-2003) then
+// sit in 8 lines, one per replica, instead of 43.  An entry is self-contained:
+//     0xFFFFFFFF          empty bucket
+//     0xFFFFFFFE          bucket of too_many_spots (100) or more positions: the segment is dropped (pemapper.c:1602-1606)
+//     v < multi_base      the bucket's only position
+//     otherwise           2..99 positions: record {count, positions...} at multi + 4 * (v - multi_base) words (16-byte units)
+// so the common buckets (empty, one position) need no second request.  Bucket sizes follow get_mers (pemapper.c:2158-2165)
+// including its 32-bit `which + 1` for the all-T k-mer.  Built from pos_index / mers, which stay resident (big read-ends,
+// the export entry points and the broadcast use them).
+// ------------------------------------------------------------------------------------------------------------
+#define IX_REP_EMPTY 0xFFFFFFFFu
+#define IX_REP_TOOMANY 0xFFFFFFFEu
+#define IX_REP_TOO_MANY_SPOTS 100u
+
+__device__ __forceinline__ uint32_t ix_bucket_len (const uint32_t * pos_index, uint64_t k, uint32_t pos_index_0)
+{
+  const uint32_t nxt = (k == 0xFFFFFFFFull) ? pos_index_0 : pos_index[k + 1];
+  return nxt - pos_index[k];
+}
+
+// 16-byte units of the bucket's record (0 unless it holds 2..99 positions)
+__global__ void ix_rep_units_kernel (const uint32_t * pos_index, uint32_t * units)
+{
+  const uint32_t p0 = pos_index[0];
+  for (uint64_t k = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; k < (1ull << 32); k += (uint64_t) gridDim.x * blockDim.x)
+    {
+      const uint32_t ln = ix_bucket_len (pos_index, k, p0);
+      units[k] = (ln >= 2 && ln < IX_REP_TOO_MANY_SPOTS) ? (ln + 4u) / 4u : 0u;
+    }
+}
+
+// exclusive prefix sums over 2^32 u32 values, in place: tile sums, a one-block scan of them, the tiles themselves
+__global__ __launch_bounds__ (SC_BLOCK) void ix_sumscan_reduce_kernel (const uint32_t * a, uint64_t n, uint32_t * tile_sum)
+{
+  __shared__ uint32_t s[SC_BLOCK];
+  uint64_t base = (uint64_t) blockIdx.x * SC_TILE;
+  uint32_t m = 0;
+  for (int r = 0; r < SC_ITEMS; r++)
+    {
+      uint64_t i = base + (uint64_t) r * SC_BLOCK + threadIdx.x;
+      if (i < n)
+        m += a[i];
+    }
+  s[threadIdx.x] = m;
+  __syncthreads ();
+  for (int o = SC_BLOCK / 2; o > 0; o >>= 1)
+    {
+      if (threadIdx.x < o)
+        s[threadIdx.x] += s[threadIdx.x + o];
+      __syncthreads ();
+    }
+  if (threadIdx.x == 0)
+    tile_sum[blockIdx.x] = s[0];
+}
+
+__global__ __launch_bounds__ (1024) void ix_sumscan_tiles_kernel (uint32_t * tile_sum, uint64_t n, unsigned long long *total)
+{
+  __shared__ unsigned long long s_part[1024];
+  const uint64_t per = (n + 1023) / 1024;
+  const uint64_t lo = threadIdx.x * per, hi = (lo + per < n) ? lo + per : n;
+  unsigned long long m = 0;
+  for (uint64_t i = lo; i < hi; i++)
+    m += tile_sum[i];
+  s_part[threadIdx.x] = m;
+  __syncthreads ();
+  if (threadIdx.x == 0)
+    {
+      unsigned long long acc = 0;
+      for (int i = 0; i < 1024; i++)
+        {
+          unsigned long long t = s_part[i];
+          s_part[i] = acc;
+          acc += t;
+        }
+      *total = acc;
+    }
+  __syncthreads ();
+  unsigned long long acc = s_part[threadIdx.x];
+  for (uint64_t i = lo; i < hi; i++)
+    {
+      uint32_t t = tile_sum[i];
+      tile_sum[i] = (uint32_t) acc;        // meaningful only while the total fits 32 bits (checked by the caller)
+      acc += t;
+    }
+}
+
+__global__ __launch_bounds__ (SC_BLOCK) void ix_sumscan_apply_kernel (uint32_t * a, uint64_t n, const uint32_t * tile_carry)
+{
+  __shared__ uint32_t s[SC_BLOCK];
+  uint64_t base = (uint64_t) blockIdx.x * SC_TILE + (uint64_t) threadIdx.x * SC_ITEMS;
+  uint32_t v[SC_ITEMS];
+  uint32_t m = 0;
+#pragma unroll
+  for (int r = 0; r < SC_ITEMS; r++)
+    {
+      uint64_t i = base + r;
+      const uint32_t t = (i < n) ? a[i] : 0u;
+      v[r] = m;                 // exclusive inside the thread
+      m += t;
+    }
+  s[threadIdx.x] = m;
+  __syncthreads ();
+  uint32_t mine = m;
+  for (int o = 1; o < SC_BLOCK; o <<= 1)
+    {
+      uint32_t t = (threadIdx.x >= (unsigned) o) ? s[threadIdx.x - o] : 0u;
+      __syncthreads ();
+      mine += t;
+      s[threadIdx.x] = mine;
+      __syncthreads ();
+    }
+  uint32_t carry = tile_carry[blockIdx.x];
+  if (threadIdx.x > 0)
+    carry += s[threadIdx.x - 1];
+#pragma unroll
+  for (int r = 0; r < SC_ITEMS; r++)
+    {
+      uint64_t i = base + r;
+      if (i < n)
+        a[i] = v[r] + carry;
+    }
+}
+
+// replica 0 (the reference's k-mer order): the entry of every bucket, and the records of the buckets of 2..99 positions
+__global__ void ix_rep_encode_kernel (const uint32_t * pos_index, const uint32_t * mers, const uint32_t * unit_off, uint32_t multi_base,
+                                      uint32_t * rep0, uint32_t * multi)
+{
+  const uint32_t p0 = pos_index[0];
+  for (uint64_t k = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; k < (1ull << 32); k += (uint64_t) gridDim.x * blockDim.x)
+    {
+      const uint32_t st = pos_index[k];
+      const uint32_t ln = ix_bucket_len (pos_index, k, p0);
+      uint32_t e;
+      if (ln == 0)
+        e = IX_REP_EMPTY;
+      else if (ln >= IX_REP_TOO_MANY_SPOTS)
+        e = IX_REP_TOOMANY;
+      else if (ln == 1)
+        e = mers[st];
+      else
+        {
+          const uint32_t off = unit_off[k];
+          e = multi_base + off;
+          uint32_t *rec = multi + (size_t) off * 4;
+          rec[0] = ln;
+          const uint32_t words = ((ln + 4u) / 4u) * 4u;
+          for (uint32_t i = 1; i < words; i++)
+            rec[i] = (i <= ln) ? mers[st + i - 1] : 0u;
+        }
+      rep0[k] = e;
+    }
+}
+
+// replica p from replica 0: dst[k with 4-bit fields 0 and p swapped] = src[k].  One 256-thread block moves the 16 x 16
+// entries that share all other fields: 16 whole lines in, 16 whole lines out.
+__global__ __launch_bounds__ (256) void ix_rep_permute_kernel (const uint32_t * src, uint32_t * dst, int p)
+{
+  __shared__ uint32_t tile[16][17];
+  const unsigned sh = 4u * (unsigned) p;
+  const int a = threadIdx.x >> 4, b = threadIdx.x & 15;
+  for (uint64_t t = blockIdx.x; t < (1ull << 24); t += gridDim.x)
+    {
+      // t = the 24 bits of the other six fields: fields 1..p-1 below field p, fields p+1..7 above it
+      const uint64_t low = t & ((1ull << (sh - 4)) - 1ull), high = t >> (sh - 4);
+      const uint64_t base = (high << (sh + 4)) | (low << 4);
+      tile[a][b] = src[base | ((uint64_t) a << sh) | (uint64_t) b];     // field p = a, field 0 = b
+      __syncthreads ();
+      dst[base | ((uint64_t) a << sh) | (uint64_t) b] = tile[b][a];     // entry whose field p = b, field 0 = a, stored at (a, b)
+      __syncthreads ();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Pileup export (the final genome walk, pemapper.c:828-843): u32 device counters -> the reference's u16 columns.
 // ------------------------------------------------------------------------------------------------------------
 __global__ void pile_to_u16_kernel (const uint32_t * counts, uint64_t n_words, uint16_t * out)

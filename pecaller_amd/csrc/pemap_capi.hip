@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdarg.h>
+#include <unistd.h>
 #include <cstring>
 #include <vector>
 #include "../../include/pemap_hip.h"
@@ -23,6 +24,10 @@ struct pemap_dev
   char err[512];
   // index
   uint32_t *d_pos_index, *d_mers;
+  uint32_t *d_rep, *d_multi;    // look-up replicas (pemap_aux.hip.h), built by index_commit
+  uint32_t multi_base;
+  int n_rep, rep_want;          // rep_want: -1 = when the memory is there (default), 0 = never, 8 = required
+  uint64_t multi_units;
   uint8_t *d_genome;
   uint32_t *d_contig_starts;
   uint64_t n_mers, gsize;
@@ -127,6 +132,11 @@ extern "C" int pemap_dev_create (pemap_dev ** out, int device_id)
   memset (d->err, 0, sizeof (d->err));
   d->device = device_id;
   d->d_pos_index = d->d_mers = nullptr;
+  d->d_rep = d->d_multi = nullptr;
+  d->multi_base = 0;
+  d->n_rep = 0;
+  d->rep_want = -1;
+  d->multi_units = 0;
   d->d_genome = nullptr;
   d->d_contig_starts = nullptr;
   d->d_counts = nullptr;
@@ -221,6 +231,9 @@ static void free_index (pemap_dev * d)
 {
   hipFree (d->d_pos_index);
   hipFree (d->d_mers);
+  hipFree (d->d_multi);         // d_rep is kept for the next index (pemap_dev_destroy frees it)
+  d->d_multi = nullptr;
+  d->n_rep = 0;
   hipFree (d->d_genome);
   hipFree (d->d_contig_starts);
   hipFree (d->d_counts);
@@ -275,6 +288,8 @@ extern "C" void pemap_dev_destroy (pemap_dev * d)
   hipSetDevice (d->device);
   hipStreamSynchronize (d->stream);
   free_index (d);
+  hipFree (d->d_rep);
+  d->d_rep = nullptr;
   free_work (d);
   hipFree (d->d_reads1);
   hipFree (d->d_reads2);
@@ -349,12 +364,137 @@ extern "C" int pemap_dev_index_alloc (pemap_dev * d, uint64_t n_mers, uint64_t g
   return 0;
 }
 
+// The 8 look-up replicas and the records of the multi-position buckets (pemap_aux.hip.h), from pos_index / mers.
+static int build_replicas (pemap_dev * d)
+{
+  hipFree (d->d_multi);
+  d->d_multi = nullptr;
+  d->n_rep = 0;
+  int want = d->rep_want;
+  { const char *e = getenv ("PEMAP_REPLICAS"); if (e && want < 0) want = atoi (e) ? 8 : 0; }
+  if (want == 0)
+    {
+      hipFree (d->d_rep);
+      d->d_rep = nullptr;
+      return 0;
+    }
+  const size_t rep_bytes = 8ull * (1ull << 32) * sizeof (uint32_t);
+  if (!d->d_rep)
+    {
+      // The replicas' 128 GiB are allocated once per object and kept across indexes.  What must stay free beside them for
+      // the work arrays of a run (direction slabs, hit records, lists) and the records is probed by allocating it.  The
+      // driver hands freed memory back lazily (an allocation of this size right after a hipFree of the same size fails,
+      // and hipMemGetInfo lags too), hence the retries.
+      const size_t reserve = (size_t) 48 << 30;
+      bool ok = false;
+      for (int attempt = 0; attempt < 10 && !ok; attempt++)
+        {
+          void *probe = nullptr;
+          if (attempt)
+            {
+              (void) hipDeviceSynchronize ();
+              usleep (300000);
+            }
+          if (hipMalloc ((void **) &d->d_rep, rep_bytes) == hipSuccess)
+            {
+              if (hipMalloc (&probe, reserve) == hipSuccess)
+                ok = true;
+              else
+                {
+                  hipFree (d->d_rep);
+                  d->d_rep = nullptr;
+                }
+              hipFree (probe);
+            }
+          if (!ok)
+            {
+              (void) hipGetLastError ();
+              d->d_rep = nullptr;
+            }
+        }
+      if (!ok)
+        {
+          if (want == 8)
+            return fail (d, "look-up replicas: the device cannot hold %.1f GB beside the index and %.1f GB of work arrays", rep_bytes / 1e9, reserve / 1e9);
+          return 0;             // the reference's layout serves the look-ups (pm_lookup_wave_kernel)
+        }
+    }
+  uint32_t *units = d->d_rep + (1ull << 32);    // replica 1's place holds the record offsets until replica 0 is encoded
+  const uint64_t n = 1ull << 32;
+  const unsigned grid = (unsigned) d->n_cus * 64u;
+  hipLaunchKernelGGL (ix_rep_units_kernel, dim3 (grid), dim3 (256), 0, d->stream, d->d_pos_index, units);
+  const uint64_t sc_tiles = (n + SC_TILE - 1) / SC_TILE;
+  uint32_t *d_tsum = nullptr;
+  unsigned long long *d_total = nullptr;
+  TRY (dev_alloc (d, &d_tsum, sc_tiles));
+  TRY (dev_alloc (d, &d_total, 1));
+  hipLaunchKernelGGL (ix_sumscan_reduce_kernel, dim3 ((unsigned) sc_tiles), dim3 (SC_BLOCK), 0, d->stream, units, n, d_tsum);
+  hipLaunchKernelGGL (ix_sumscan_tiles_kernel, dim3 (1), dim3 (1024), 0, d->stream, d_tsum, sc_tiles, d_total);
+  unsigned long long total = 0;
+  HIPCHK (d, hipMemcpyAsync (&total, d_total, sizeof (total), hipMemcpyDeviceToHost, d->stream));
+  HIPCHK (d, hipStreamSynchronize (d->stream));
+  // entries below multi_base are positions (compressed coordinates < genome size); codes up to 0xFFFFFFFD address the records
+  d->multi_base = (uint32_t) d->gsize;
+  const bool fits = total < (unsigned long long) (0xFFFFFFFEu - d->multi_base);
+  if (fits)
+    {
+      hipLaunchKernelGGL (ix_sumscan_apply_kernel, dim3 ((unsigned) sc_tiles), dim3 (SC_BLOCK), 0, d->stream, units, n, d_tsum);
+      if (dev_alloc (d, &d->d_multi, (size_t) total * 4 + 64))
+        {
+          hipFree (d_tsum);
+          hipFree (d_total);
+          return 1;
+        }
+      hipLaunchKernelGGL (ix_rep_encode_kernel, dim3 (grid), dim3 (256), 0, d->stream, d->d_pos_index, d->d_mers, units, d->multi_base, d->d_rep,
+                          d->d_multi);
+      for (int p = 1; p < 8; p++)
+        hipLaunchKernelGGL (ix_rep_permute_kernel, dim3 ((unsigned) d->n_cus * 32u), dim3 (256), 0, d->stream, d->d_rep,
+                            d->d_rep + ((size_t) p << 32), p);
+    }
+  HIPCHK (d, hipStreamSynchronize (d->stream));
+  HIPCHK (d, hipGetLastError ());
+  hipFree (d_tsum);
+  hipFree (d_total);
+  if (!fits)
+    {
+      if (want == 8)
+        return fail (d, "look-up replicas: %llu record units do not fit the codes above genome size %llu", total, (unsigned long long) d->gsize);
+      return 0;
+    }
+  d->multi_units = total;
+  d->n_rep = 8;
+  return 0;
+}
+
+extern "C" int pemap_dev_set_lookup_replicas (pemap_dev * d, int n)
+{
+  if (n != -1 && n != 0 && n != 8)
+    return fail (d, "set_lookup_replicas: %d (-1 = when the memory is there, 0 = never, 8 = required)", n);
+  d->rep_want = n;
+  if (d->index_ready)
+    {
+      HIPCHK (d, hipSetDevice (d->device));
+      HIPCHK (d, hipDeviceSynchronize ());
+      return build_replicas (d);
+    }
+  return 0;
+}
+
+extern "C" int pemap_dev_lookup_replicas (pemap_dev * d, int *n_replicas, uint64_t * record_bytes)
+{
+  *n_replicas = d->n_rep;
+  if (record_bytes)
+    *record_bytes = d->n_rep ? d->multi_units * 16ull : 0ull;
+  return 0;
+}
+
 extern "C" int pemap_dev_index_commit (pemap_dev * d)
 {
   if (!d->d_pos_index)
     return fail (d, "index_commit: no index arrays allocated");
   HIPCHK (d, hipSetDevice (d->device));
   HIPCHK (d, hipDeviceSynchronize ());
+  TRY (build_replicas (d));
   d->index_ready = true;
   return 0;
 }
@@ -473,6 +613,8 @@ extern "C" int pemap_dev_buffer (pemap_dev * d, int which, void **d_ptr, uint64_
     case 2: *d_ptr = d->d_genome; *n_bytes = d->gsize; break;
     case 3: *d_ptr = d->d_contig_starts; *n_bytes = ((uint64_t) d->n_contigs + 1) * 4; break;
     case 4: *d_ptr = d->d_counts; *n_bytes = d->gsize * 6 * 4; break;
+    case 5: *d_ptr = d->d_rep; *n_bytes = d->n_rep ? 8ull * (1ull << 32) * 4ull : 0ull; break;
+    case 6: *d_ptr = d->d_multi; *n_bytes = d->n_rep ? d->multi_units * 16ull : 0ull; break;
     default: return fail (d, "buffer: which = %d", which);
     }
   return 0;
@@ -770,7 +912,9 @@ static void launch_lookup (pemap_dev * d, const RunCtx & c, int slot, PmChunkCtr
   const int lb = lbenv ? atoi (lbenv) : 4;
   static const int lprio = getenv ("PEMAP_LOOKUP_PRIO") ? atoi (getenv ("PEMAP_LOOKUP_PRIO")) : 0;
 #define PM_LKW(SM, B) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_lookup_wave_kernel < SM, B >), dim3 (lgrid), dim3 (64), 0, st, c.ix, c.b, c.prm, L, lprio)
-#define PM_LK(SM) do { if (lw > 0 && lb >= 16) PM_LKW (SM, 16); else if (lw > 0 && lb >= 8) PM_LKW (SM, 8); else if (lw > 0) PM_LKW (SM, 4); \
+#define PM_LKR(SM, B) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_lookup_rep_kernel < SM, B >), dim3 (lgrid), dim3 (64), 0, st, c.ix, c.b, c.prm, L, lprio)
+#define PM_LK(SM) do { if (lw > 0 && c.ix.n_rep == 8 && lb >= 8) PM_LKR (SM, 10); else if (lw > 0 && c.ix.n_rep == 8) PM_LKR (SM, 5); \
+    else if (lw > 0 && lb >= 16) PM_LKW (SM, 16); else if (lw > 0 && lb >= 8) PM_LKW (SM, 8); else if (lw > 0) PM_LKW (SM, 4); \
     else hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_lookup_kernel < SM >), dim3 (c.b.n_ends), dim3 (PM_SEED_THREADS), pad, st, c.ix, c.b, c.prm, L); } while (0)
   switch (seg_template (c.L))
     {
@@ -782,6 +926,7 @@ static void launch_lookup (pemap_dev * d, const RunCtx & c, int slot, PmChunkCtr
     }
 #undef PM_LK
 #undef PM_LKW
+#undef PM_LKR
   hipEventRecord (ev[1], st);
 }
 
@@ -1090,6 +1235,10 @@ static int run_slice (pemap_dev * d, int first, int n, int sync)
   c.ix.gsize = d->gsize;
   c.ix.n_contigs = d->n_contigs;
   c.ix.idepth = d->idepth;
+  c.ix.rep = d->d_rep;
+  c.ix.multi = d->d_multi;
+  c.ix.multi_base = d->multi_base;
+  c.ix.n_rep = d->n_rep;
   c.prm.min_dist = d->min_dist;
   c.prm.max_dist = d->max_dist;
   c.prm.min_align = d->min_align;

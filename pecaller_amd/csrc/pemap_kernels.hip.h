@@ -30,6 +30,11 @@ struct PmIndex
   uint64_t gsize;
   int n_contigs;
   int idepth;
+  // look-up replicas (pemap_aux.hip.h): n_rep = 8 tables of 2^32 self-contained entries, replica p at rep + p * 2^32, or 0
+  const uint32_t *rep;
+  const uint32_t *multi;           // records {count, positions...} of the buckets of 2..99 positions, 16-byte units
+  uint32_t multi_base;             // entries >= multi_base (and < 0xFFFFFFFE) point into multi
+  int n_rep;
 };
 
 // counters shared by the kernels of one run (zeroed at the start of every run)

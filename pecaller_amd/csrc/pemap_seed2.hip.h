@@ -422,6 +422,262 @@ template < int SMAX, int PM_LW_BATCH > __global__ __launch_bounds__ (64) void pm
     atomicAdd (out.positions, n_pos);
 }
 
+// ---- the look-ups against the 8 replicas of the table (pemap_aux.hip.h): ONE WAVE per read-end, persistent, same output
+// as pm_lookup_wave_kernel.  A (strand, segment)'s k-mer and its 48 neighbours lie in 8 lines, one per replica: the
+// wave reads each line whole -- 4 adjacent lanes x 16 bytes, 16 lines per wave instruction, every line of the read-end
+// in flight at once -- into LDS, decodes the 2 x S x 49 entries from there, then fetches the record headers of the
+// buckets of 2..99 positions (the only second-level requests) and copies the positions out.  2 x S x 8 + (multi
+// buckets) fabric requests per read-end against 2 x S x 43 + (non-empty buckets) for the reference's layout.
+template < int SMAX > struct __align__ (16) PmLookupRepShared
+{
+  static constexpr int NITEMS = 2 * SMAX * 49;
+  static constexpr int NLINES = 2 * SMAX * 8;
+  uint32_t lines[NLINES * 16];
+  uint32_t it_start[NITEMS];          // the entry: a position, or the code of a record
+  uint16_t it_off[NITEMS];            // bucket sizes (0xFFFF = too many), then their exclusive prefix inside the segment
+  uint16_t mlist[NITEMS];             // items whose entry points to a record
+  uint32_t kmer[2 * SMAX];
+  int seg_base[2][SMAX + 1];
+  int offsets[SMAX + 1];
+  uint8_t seq[2][320];
+};
+
+__device__ __forceinline__ uint32_t pm_swap_fields (uint32_t k, int p)
+{
+  const unsigned sh = 4u * (unsigned) p;
+  const uint32_t f0 = k & 15u, fp = (k >> sh) & 15u;
+  return (k & ~(15u | (15u << sh))) | (f0 << sh) | fp;        // p = 0: k itself
+}
+
+template < int SMAX, int PM_LR_BATCH, class SH >
+__device__ __forceinline__ void pm_lookup_rep_one_end (SH & sh, const PmIndex & ix, const PmBatch & b, const PmParams & prm, const PmLists & out, const int e,
+                                                       const int lane, const int idepth, unsigned long long &n_pos)
+{
+  int len;
+  const uint8_t *src = pm_read_ptr (b, e, &len);
+  // ---- read + reverse complement; N filter (pemapper.c:1552-1559: upper-case 'N' only)
+  int isn = 0;
+  for (int i = lane; i < len; i += 64)
+    {
+      const uint8_t c = src[i];
+      sh.seq[0][i] = c;
+      sh.seq[1][len - 1 - i] = pm_rc (c);
+      isn += (c == 'N');
+    }
+  for (int o = 32; o; o >>= 1)
+    isn += __shfl_xor (isn, o);
+  int total_cuts = len / idepth;    // pemapper.c:1573-1587
+  if (len % idepth == 0)
+    total_cuts--;
+  if (total_cuts > SMAX - 1)
+    total_cuts = SMAX - 1;
+  const int S = total_cuts + 1;
+  PmEndHeader *hd = &out.hdr[e];
+  if (isn >= 1 + len / 10)
+    {
+      if (lane == 0)
+        hd->kind = PM_KIND_SKIP;
+      return;
+    }
+  if (lane <= total_cuts)
+    sh.offsets[lane] = (lane < total_cuts || total_cuts == 0) ? lane * idepth : len - idepth;
+  pm_wave_sync ();
+  if (lane < 2 * S)
+    {
+      const int strand = lane / S, seg = lane - strand * S;
+      const uint8_t *p = &sh.seq[strand][sh.offsets[seg]];
+      uint32_t k = 0;
+#pragma unroll 4
+      for (int i = 0; i < 16; i++)
+        k = (k << 2) + pm_code (p[i], prm.bisulfite);
+      sh.kmer[lane] = k;
+    }
+  pm_wave_sync ();
+  // ---- the 2 x S x 8 lines, 16 per wave instruction, PM_LR_BATCH instructions (x 16 lines) in flight at a time
+  {
+    const int n_lines = 2 * S * 8;
+    const int quarter = lane & 3;
+#pragma unroll 1
+    for (int r0 = 0; r0 * 16 < n_lines; r0 += PM_LR_BATCH)
+      {
+        uint4 v[PM_LR_BATCH];
+#pragma unroll
+        for (int r = 0; r < PM_LR_BATCH; r++)
+          {
+            const int li = (r0 + r) * 16 + (lane >> 2);
+            v[r] = make_uint4 (0u, 0u, 0u, 0u);
+            if (li < n_lines)
+              {
+                const int sg = li >> 3, p = li & 7;
+                const uint32_t idx = pm_swap_fields (sh.kmer[sg], p);
+                v[r] = *(const uint4 *) (ix.rep + ((size_t) p << 32) + (size_t) (idx & ~15u) + (size_t) (quarter * 4));
+              }
+          }
+#pragma unroll
+        for (int r = 0; r < PM_LR_BATCH; r++)
+          {
+            const int li = (r0 + r) * 16 + (lane >> 2);
+            if (li < n_lines)
+              *(uint4 *) (&sh.lines[li * 16 + quarter * 4]) = v[r];
+          }
+      }
+  }
+  pm_wave_sync ();
+  // ---- the 2 x S x 49 entries (get_mers, pemapper.c:2158-2165, in fill_mers' order)
+  int n_multi = 0;
+  const uint32_t multi_base = ix.multi_base;
+  for (int x0 = 0; x0 < 2 * S * 49; x0 += 64)
+    {
+      const int x = x0 + lane;
+      bool is_multi = false;
+      if (x < 2 * S * 49)
+        {
+          const int sg = x / 49, j = x - sg * 49;
+          const int p = (j == 0) ? 0 : (j - 1) / 6;
+          const uint32_t nb = pm_neighbour (sh.kmer[sg], j);
+          const uint32_t ent = sh.lines[(sg * 8 + p) * 16 + ((nb >> (4 * p)) & 15u)];
+          sh.it_start[x] = ent;
+          is_multi = ent >= multi_base && ent < 0xFFFFFFFEu;
+          sh.it_off[x] = (ent == 0xFFFFFFFFu) ? (uint16_t) 0 : (ent == 0xFFFFFFFEu) ? (uint16_t) 0xFFFF : (uint16_t) 1;
+        }
+      const unsigned long long bal = __ballot (is_multi);
+      if (is_multi)
+        sh.mlist[n_multi + __popcll (bal & ((1ull << lane) - 1ull))] = (uint16_t) x;
+      n_multi += __popcll (bal);
+    }
+  pm_wave_sync ();
+  // ---- sizes of the buckets that have a record: its first 16 bytes, 4 rounds in flight
+#pragma unroll 1
+  for (int i0 = 0; i0 < n_multi; i0 += 256)
+    {
+      uint32_t cnt[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+        {
+          const int i = i0 + r * 64 + lane;
+          cnt[r] = 0;
+          if (i < n_multi)
+            cnt[r] = ix.multi[(size_t) (sh.it_start[sh.mlist[i]] - multi_base) * 4];
+        }
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+        {
+          const int i = i0 + r * 64 + lane;
+          if (i < n_multi)
+            sh.it_off[sh.mlist[i]] = (uint16_t) cnt[r];
+        }
+    }
+  pm_wave_sync ();
+  // ---- a segment with any bucket >= too_many_spots is emptied (pemapper.c:1602-1606); one lane per segment
+  int cnt = 0;
+  if (lane < 2 * S)
+    {
+      int sum = 0;
+      bool bad = false;
+#pragma unroll 7
+      for (int j = 0; j < 49; j++)
+        {
+          const uint16_t ln = sh.it_off[lane * 49 + j];
+          sh.it_off[lane * 49 + j] = (uint16_t) sum;
+          if (ln == 0xFFFF)
+            bad = true;
+          else
+            sum += ln;
+        }
+      cnt = bad ? 0 : sum;
+    }
+  int inc = cnt;
+  for (int o = 1; o < 64; o <<= 1)
+    {
+      const int t = __shfl_up (inc, o);
+      if (lane >= o)
+        inc += t;
+    }
+  const int T0 = __shfl (inc, S - 1), TT = __shfl (inc, 2 * S - 1);
+  const int T1 = TT - T0;
+  if (lane < 2 * S)
+    {
+      const int strand = lane / S, seg = lane - strand * S;
+      sh.seg_base[strand][seg] = inc - cnt - (strand ? T0 : 0);
+    }
+  if (lane == 0)
+    {
+      sh.seg_base[0][S] = T0;
+      sh.seg_base[1][S] = T1;
+    }
+  pm_wave_sync ();
+  if (T0 > PM_SEED_CAP || T1 > PM_SEED_CAP)
+    {
+      if (lane == 0)
+        {
+          hd->kind = PM_KIND_BIG;
+          out.big_list[atomicAdd (out.n_big, 1u)] = (uint32_t) e;
+        }
+      return;
+    }
+  if (lane == 0)
+    {
+      hd->kind = PM_KIND_NORMAL;
+      hd->T[0] = (uint16_t) T0;
+      hd->T[1] = (uint16_t) T1;
+    }
+  n_pos += (unsigned long long) TT;
+  if (lane < 2 * (S + 1))
+    {
+      const int st = lane / (S + 1), k = lane - st * (S + 1);
+      hd->seg_base[st][k] = (uint16_t) sh.seg_base[st][k];
+    }
+  // ---- positions -> (diagonal key, segment) lists, one position per lane and round
+  uint32_t *okey = out.key + (size_t) e * 2 * PM_SEED_CAP;
+  uint8_t *oseg = out.seg + (size_t) e * 2 * PM_SEED_CAP;
+#pragma unroll 2
+  for (int pp = lane; pp < TT; pp += 64)
+    {
+      const int strand = pp < T0 ? 0 : 1;
+      const int p = strand ? pp - T0 : pp;
+      int seg = 0;
+      while (p >= sh.seg_base[strand][seg + 1])
+        seg++;
+      const int q = p - sh.seg_base[strand][seg];
+      const int x0 = (strand * S + seg) * 49;
+      int lo = 0, hi = 48;  // largest j with it_off[j] <= q: that bucket holds position q
+      while (lo < hi)
+        {
+          const int mid = (lo + hi + 1) >> 1;
+          if ((int) sh.it_off[x0 + mid] <= q)
+            lo = mid;
+          else
+            hi = mid - 1;
+        }
+      const uint32_t ent = sh.it_start[x0 + lo];
+      const uint32_t m = (ent < multi_base) ? ent : ix.multi[(size_t) (ent - multi_base) * 4 + 1u + (uint32_t) (q - (int) sh.it_off[x0 + lo])];
+      okey[strand * PM_SEED_CAP + p] = m + (uint32_t) (PM_DIAG_BIAS - sh.offsets[seg]);
+      oseg[strand * PM_SEED_CAP + p] = (uint8_t) seg;
+    }
+  pm_wave_sync ();
+}
+
+template < int SMAX, int PM_LR_BATCH > __global__ __launch_bounds__ (64) void pm_lookup_rep_kernel (PmIndex ix, PmBatch b, PmParams prm, PmLists out, int prio)
+{
+  pm_set_prio (prio);
+  typedef PmLookupRepShared < SMAX > SH;
+  __shared__ SH sh;
+  const int lane = threadIdx.x;
+  const int idepth = ix.idepth;
+  unsigned long long n_pos = 0;
+  int e_next = (int) gridDim.x + (int) __builtin_amdgcn_readfirstlane ((int) (lane == 0 ? atomicAdd (out.next_end, 1u) : 0u));
+  for (int e = blockIdx.x; e < b.n_ends;)
+    {
+      const int e_cur = e;
+      e = e_next;
+      if (e < b.n_ends)
+        e_next = (int) gridDim.x + (int) __builtin_amdgcn_readfirstlane ((int) (lane == 0 ? atomicAdd (out.next_end, 1u) : 0u));
+      pm_lookup_rep_one_end < SMAX, PM_LR_BATCH > (sh, ix, b, prm, out, e_cur, lane, idepth, n_pos);
+    }
+  if (lane == 0 && n_pos)
+    atomicAdd (out.positions, n_pos);
+}
+
 // LDS of the vote kernel: one strand at a time (the lists come from HBM), no look-up items
 template < int SMAX > struct __align__ (8) PmVoteShared
 {

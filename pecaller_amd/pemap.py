@@ -14,7 +14,8 @@ CLASS_NAMES = ["UNIQUE_MATE", "UNIQUE_SLIP", "UNIQUE_SINGLE", "UNIQUE_MIS", "NON
 # every symbol include/pemap_hip.h declares (tests check that the library exports all of them)
 SYMBOLS = [
     "pemap_dev_last_error", "pemap_dev_create", "pemap_dev_destroy", "pemap_dev_load_index", "pemap_dev_build_index",
-    "pemap_dev_build_index_resident", "pemap_dev_index_alloc", "pemap_dev_index_commit", "pemap_dev_buffer",
+    "pemap_dev_build_index_resident", "pemap_dev_index_alloc", "pemap_dev_index_commit", "pemap_dev_set_lookup_replicas",
+    "pemap_dev_lookup_replicas", "pemap_dev_buffer",
     "pemap_dev_index_info", "pemap_dev_read_buffer", "pemap_dev_set_params", "pemap_dev_map_batch",
     "pemap_dev_stage_reads", "pemap_dev_run", "pemap_dev_run_slice", "pemap_dev_collect", "pemap_dev_sync",
     "pemap_dev_synth_genome", "pemap_dev_synth_reads", "pemap_dev_staged_reads", "pemap_dev_staged_info",
@@ -52,6 +53,8 @@ def load_library():
         L.pemap_dev_build_index_resident.argtypes = [vp, vp, u64, vp, i, i]
         L.pemap_dev_index_alloc.argtypes = [vp, u64, u64, i, i]
         L.pemap_dev_index_commit.argtypes = [vp]
+        L.pemap_dev_set_lookup_replicas.argtypes = [vp, i]
+        L.pemap_dev_lookup_replicas.argtypes = [vp, C.POINTER(i), C.POINTER(u64)]
         L.pemap_dev_buffer.argtypes = [vp, i, C.POINTER(vp), C.POINTER(u64)]
         L.pemap_dev_index_info.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(i), C.POINTER(i)]
         L.pemap_dev_read_buffer.argtypes = [vp, i, u64, vp, u64]
@@ -132,6 +135,16 @@ class PemapDev:
 
     def index_commit(self):
         self._ck(self.L.pemap_dev_index_commit(self.h))
+
+    def set_lookup_replicas(self, n):
+        """-1 = when the memory is there (default), 0 = the reference's table only, 8 = required."""
+        self._ck(self.L.pemap_dev_set_lookup_replicas(self.h, int(n)))
+
+    def lookup_replicas(self):
+        n = C.c_int(0)
+        b = C.c_uint64(0)
+        self._ck(self.L.pemap_dev_lookup_replicas(self.h, C.byref(n), C.byref(b)))
+        return n.value, b.value
 
     def index_info(self):
         a, b, c, d = C.c_uint64(), C.c_uint64(), C.c_int(), C.c_int()

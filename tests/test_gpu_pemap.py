@@ -46,10 +46,76 @@ def test_device_index_equals_reference_index(dev):
         assert two[0] == us[i] and two[1] == us[i + 1]
 
 
+def _swap_fields(k, p):
+    k = np.asarray(k, dtype=np.uint64)
+    sh = np.uint64(4 * p)
+    f0, fp = k & np.uint64(15), (k >> sh) & np.uint64(15)
+    return (k & ~(np.uint64(15) | (np.uint64(15) << sh))) | (f0 << sh) | fp
+
+
+def test_lookup_replicas_encode_the_reference_table(dev):
+    """The 8 re-ordered copies of the table that serve the look-ups on the device: every sampled entry must say what
+    pos_index / mers say about its bucket (get_mers, pemapper.c:2158-2165): empty, the only position, the record of 2..99
+    positions in .mdx order, or the too_many_spots marker."""
+    ix = fixtures.index()
+    n_rep, rec_bytes = dev.lookup_replicas()
+    assert n_rep == 8, "an MI355X has the memory for the replicas: they must be in use"
+    n_mers, gsize, _, _ = dev.index_info()
+    uk, us = ix["ukmer"].astype(np.int64), ix["ustart"].astype(np.int64)
+    mers = dev.read_buffer(1, np.uint32)
+    multi = dev.read_buffer(6, np.uint32)
+    assert multi.nbytes == rec_bytes
+    ln_of = dict(zip(uk.tolist(), (us[1:] - us[:-1]).tolist()))
+    st_of = dict(zip(uk.tolist(), us[:-1].tolist()))
+    rng = np.random.default_rng(5)
+    ks = set(uk[rng.integers(0, len(uk), size=600)].tolist())
+    big = uk[np.nonzero((us[1:] - us[:-1]) >= 2)[0]]
+    ks |= set(big[rng.integers(0, len(big), size=300)].tolist()) if len(big) else set()
+    ks |= set(rng.integers(0, 1 << 32, size=100).tolist()) | {0, (1 << 32) - 1}
+    # neighbours of a few of them: the entries the kernel reads from the same lines
+    for k in list(ks)[:50]:
+        for f in range(16):
+            ks.add(k ^ (1 << (2 * f)))
+    seen = {0: 0, 1: 0, 2: 0, 100: 0}
+    for k in sorted(ks):
+        ln = ln_of.get(k, 0)
+        if k == (1 << 32) - 1:      # `which + 1` wraps to entry 0 (pemapper.c:2163): pos_index[0] - pos_index[k] in 32 bits
+            ln = (0 - st_of.get(k, n_mers)) & 0xFFFFFFFF
+        for p in range(8):
+            d = int(_swap_fields(k, p))
+            e = int(dev.read_buffer(5, np.uint32, offset_bytes=((p << 32) + d) * 4, n_bytes=4)[0])
+            if ln == 0:
+                assert e == 0xFFFFFFFF, (k, p)
+            elif ln >= 100:
+                assert e == 0xFFFFFFFE, (k, p)
+            elif ln == 1:
+                assert e == mers[st_of[k]], (k, p)
+            else:
+                assert gsize <= e < 0xFFFFFFFE, (k, p)
+                o = (e - gsize) * 4
+                assert multi[o] == ln and np.array_equal(multi[o + 1:o + 1 + ln], mers[st_of[k]:st_of[k] + ln]), (k, p)
+        seen[0 if ln == 0 else 1 if ln == 1 else 2 if ln < 100 else 100] += 1
+    assert seen[1] > 100 and seen[2] > 100 and seen[0] > 100
+    # one whole window of replica 0 (the reference's order): emptiness agrees with the prefix table everywhere
+    W = 1 << 24
+    start = int(uk[len(uk) // 2]) & ~(W - 1)
+    win = dev.read_buffer(5, np.uint32, offset_bytes=start * 4, n_bytes=W * 4)
+    pi = dev.read_buffer(0, np.uint32, offset_bytes=start * 4, n_bytes=(W + 1) * 4).astype(np.int64)
+    lens = pi[1:] - pi[:-1]
+    assert np.array_equal(win == 0xFFFFFFFF, lens == 0)
+    assert np.array_equal(win == 0xFFFFFFFE, lens >= 100)
+    one = lens == 1
+    assert np.array_equal(win[one], mers[pi[:-1][one]])
+
+
+@pytest.mark.parametrize("replicas", [8, 0])
 @pytest.mark.parametrize("name", ["r150", "r100", "r250"])
-def test_map_matches_reference_golden(dev, name):
+def test_map_matches_reference_golden(dev, name, replicas):
     s = fixtures.SETS[name]
     r1, l1, r2, l2 = fixtures.reads(name)
+    # 8: the look-ups read the replicas (the default on an MI355X); 0: the reference's table (pm_lookup_wave_kernel)
+    dev.set_lookup_replicas(replicas)
+    assert dev.lookup_replicas()[0] == replicas
     dev.set_params(paired=s["paired"], min_dist=0, max_dist=500, min_align=0.85)
     dev.reset_pileup()
     m1, m2, mt = dev.map_batch(r1, l1, r2, l2)
@@ -81,6 +147,7 @@ def test_hits_and_scores_match_oracle(dev):
     ix = fixtures.index()
     r1, l1, r2, l2 = fixtures.reads("r150")
     n = 4000
+    dev.set_lookup_replicas(8)
     dev.set_params(paired=True, min_dist=0, max_dist=500, min_align=0.85)
     dev.reset_pileup()
     m1, m2, mt = dev.map_batch(r1[:n], l1[:n], r2[:n], l2[:n])
