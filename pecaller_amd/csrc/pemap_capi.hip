@@ -904,7 +904,11 @@ static void launch_lookup (pemap_dev * d, const RunCtx & c, int slot, PmChunkCtr
   const unsigned pad = (padenv ? (unsigned) atoi (padenv) : 20u) * 1024u;    // 5 look-up workgroups per CU (swept: 8..44 KB)
   // PEMAP_LOOKUP_WAVES=n (default 6, swept 2..24): n persistent one-wave workgroups per CU; 0 = the workgroup-per-end kernel
   const char *lwenv = getenv ("PEMAP_LOOKUP_WAVES");
-  const int lw = lwenv ? atoi (lwenv) : 6;
+  // PEMAP_LOOKUP_V (with replicas): 1 = pm_lookup_rep_kernel (default), 2 = the pipelined pm_lookup_rep2_kernel (measured
+  // slower: 68 ms per step at its best point, 3 waves per CU, against 65 -- see DESIGN.md)
+  static const int lv = getenv ("PEMAP_LOOKUP_V") ? atoi (getenv ("PEMAP_LOOKUP_V")) : 1;
+  // waves per CU: with the replicas 4 (one per SIMD: a fifth takes a third SW wave's registers somewhere), otherwise 6
+  const int lw = lwenv ? atoi (lwenv) : (c.ix.n_rep == 8) ? (lv == 2 ? 3 : 4) : 6;
   int lgrid = lw * d->n_cus;
   if (lgrid > c.b.n_ends)
     lgrid = c.b.n_ends;
@@ -913,7 +917,8 @@ static void launch_lookup (pemap_dev * d, const RunCtx & c, int slot, PmChunkCtr
   static const int lprio = getenv ("PEMAP_LOOKUP_PRIO") ? atoi (getenv ("PEMAP_LOOKUP_PRIO")) : 0;
 #define PM_LKW(SM, B) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_lookup_wave_kernel < SM, B >), dim3 (lgrid), dim3 (64), 0, st, c.ix, c.b, c.prm, L, lprio)
 #define PM_LKR(SM, B) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_lookup_rep_kernel < SM, B >), dim3 (lgrid), dim3 (64), 0, st, c.ix, c.b, c.prm, L, lprio)
-#define PM_LK(SM) do { if (lw > 0 && c.ix.n_rep == 8 && lb >= 8) PM_LKR (SM, 10); else if (lw > 0 && c.ix.n_rep == 8) PM_LKR (SM, 5); \
+#define PM_LK(SM) do { if (lw > 0 && c.ix.n_rep == 8 && lv == 2) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_lookup_rep2_kernel < SM >), dim3 (lgrid), dim3 (64), sizeof (PmLookupRep2Shared < SM >), st, c.ix, c.b, c.prm, L, lprio); \
+    else if (lw > 0 && c.ix.n_rep == 8 && lb >= 8) PM_LKR (SM, 10); else if (lw > 0 && c.ix.n_rep == 8) PM_LKR (SM, 5); \
     else if (lw > 0 && lb >= 16) PM_LKW (SM, 16); else if (lw > 0 && lb >= 8) PM_LKW (SM, 8); else if (lw > 0) PM_LKW (SM, 4); \
     else hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_lookup_kernel < SM >), dim3 (c.b.n_ends), dim3 (PM_SEED_THREADS), pad, st, c.ix, c.b, c.prm, L); } while (0)
   switch (seg_template (c.L))

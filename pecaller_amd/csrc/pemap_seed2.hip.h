@@ -678,6 +678,408 @@ template < int SMAX, int PM_LR_BATCH > __global__ __launch_bounds__ (64) void pm
     atomicAdd (out.positions, n_pos);
 }
 
+// ---- the same look-ups as a three-stage pipeline inside the wave.  pm_lookup_rep_kernel spends its time waiting: per
+// read-end the read, the lines, the record headers and the record positions are four dependent trips to HBM, and its
+// rate is the number of resident waves over the sum of those latencies.  Here a wave works on three read-ends at once:
+//   R (end k+2)  the read's bytes requested into registers
+//   P (end k+1)  read -> LDS, N filter, k-mers, the 2 x S x 8 line requests issued as LDS-DMA (global_load_lds_dwordx4:
+//                16 bytes per lane straight into LDS, no registers held while in flight)
+//   Q (end k)    entries decoded from the lines that landed during the previous Q, record headers, prefix, positions out
+// so that a read-end costs one exposed HBM latency (the record headers) instead of four, and two or three waves per CU
+// do what six did -- which leaves the CU to the fp64 SW kernel of the other stream.  Lane j handles neighbour j of every
+// (strand, segment), one segment per round, and keeps the entries in registers from decode to output.  The order of the
+// positions inside a segment's list is immaterial (the reference sorts them, the vote kernel hashes them), so a segment's
+// list is laid out as [buckets of one position, in neighbour order][records of 2..99 positions]: the offsets of the first
+// kind are ballots and population counts, only the records need a prefix sum.
+template < int SMAX > struct __align__ (16) PmLookupRep2Shared
+{
+  static constexpr int NITEMS = 2 * SMAX * 49;
+  static constexpr int NROUNDS = SMAX;                          // 2 x SMAX x 8 lines, 16 per wave instruction
+  uint32_t lines[2][NROUNDS * 256];
+  uint32_t ment[NITEMS];              // the entries that point to a record, in (segment, neighbour) order
+  uint32_t mp[NITEMS + 1];            // exclusive prefix of their counts
+  uint16_t mlist[NITEMS];             // segment * 64 + neighbour of each
+  uint32_t kmer[2][2 * SMAX];
+  int offsets[2][SMAX + 1];
+  int seg_ms[2 * SMAX + 2];           // where the positions of a segment's records start in the end's lists, minus mp[] of its first record
+  int seg_base[2][SMAX + 1];
+  uint8_t seq[2][320];
+};
+
+typedef __attribute__ ((address_space (3))) void *pm_lptr_t;
+#define PM_SEG_DEAD ((int) 0x80000000)
+
+// pm_rc without branches (five copies of the switch's decision tree per stage were most of the kernel's code): the
+// complements of 'A'..'Z' as bytes of four 64-bit constants, everything else 'N'
+__device__ __forceinline__ uint8_t pm_rc_flat (uint8_t c)
+{
+  const unsigned idx = (unsigned) c - (unsigned) 'A';
+  const unsigned w = idx >> 3;
+  const unsigned long long t = (w == 0) ? 0x4e434e4e4e474e54ull : (w == 1) ? 0x4e4e4e4b4e4d4e4eull : (w == 2) ? 0x4e574e4e4153594eull : 0x4e4e4e4e4e4e4e52ull;
+  const uint8_t r = (uint8_t) (t >> (8u * (idx & 7u)));
+  return idx < 26u ? r : (uint8_t) 'N';
+}
+
+// pm_code without branches
+__device__ __forceinline__ unsigned pm_code_flat (uint8_t c, int bis)
+{
+  const unsigned lc = (unsigned) c | 0x20u;
+  unsigned code = (lc == 'c') ? 1u : (lc == 'g') ? 2u : (lc == 't') ? 3u : 0u;
+  code = (bis && c == 'C') ? 3u : code;
+  return code;
+}
+
+// LDS-DMA as an asm statement (cdna_hip_programming.md, inline-asm notes): 16 bytes per lane from each lane's own address to
+// lds_byte_addr + 16 * lane.  hipcc does not count it, which is the point: issued through the builtin, every later LDS
+// read of the kernel waits for vmcnt(0), i.e. for the NEXT read-end's lines as well.  The kernel waits for it itself.
+__device__ __forceinline__ void pm_glds16 (const void *gsrc, uint32_t lds_byte_addr)
+{
+  unsigned keep;
+  asm volatile ("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0":"=&s" (keep):"v" (gsrc), "s" (lds_byte_addr):"memory");
+}
+
+// LDS is passed as dynamic shared memory (sizeof (PmLookupRep2Shared < SMAX >)): with a static 34 KB the compiler concludes
+// that one wave per SIMD is all the kernel will ever get and spends 256 VGPRs on it, whatever the launch bounds say.
+extern __shared__ __align__ (16) uint8_t pm_lookup_rep2_lds[];
+
+template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? 3 : 2) void pm_lookup_rep2_kernel (PmIndex ix, PmBatch b, PmParams prm, PmLists out, int prio)
+{
+  pm_set_prio (prio);
+  typedef PmLookupRep2Shared < SMAX > SH;
+  SH & sh = *reinterpret_cast < SH * >(pm_lookup_rep2_lds);
+  const int lane = threadIdx.x;
+  const int idepth = ix.idepth;
+  const uint32_t multi_base = ix.multi_base;
+  const int n_ends = b.n_ends;
+  const int nb = b.stride < 320 ? b.stride : 320;
+  unsigned long long n_pos = 0;
+  // ends are handed out through a counter; two values are always in flight ahead of their use
+  int eQ = n_ends, eP = blockIdx.x, eR;
+  int eF = (int) gridDim.x + (int) __builtin_amdgcn_readfirstlane ((int) (lane == 0 ? atomicAdd (out.next_end, 1u) : 0u));
+  eR = eF;
+  eF = (int) gridDim.x + (int) __builtin_amdgcn_readfirstlane ((int) (lane == 0 ? atomicAdd (out.next_end, 1u) : 0u));
+  // stage registers: the bytes of eP
+  uint8_t rb[5];
+  int rlen = 0;
+  int SQ = 0;
+  bool skipQ = true;
+  uint32_t kQ = 0;
+  int buf = 0;
+  // lane j looks at neighbour j of every segment (fill_mers' order, pm_neighbour): the 2-bit field it replaces, the
+  // alternative's rank, the replica (= 4-bit field) whose line holds it
+  const int nb_f = lane > 0 ? (lane - 1) / 3 : 0;
+  const uint32_t nb_a = lane > 0 ? (uint32_t) ((lane - 1) % 3) : 0u;
+  const uint32_t nb_sh = 2u * (uint32_t) (nb_f & 15);
+  const uint32_t nb_keep = lane > 0 ? ~(3u << nb_sh) : 0xFFFFFFFFu;      // lane 0: the k-mer itself
+  const uint32_t nb_alt_on = lane > 0 ? 0xFFFFFFFFu : 0u;
+  const int nb_p = (nb_f >> 1) & 7;
+  const uint32_t nb_p4 = 4u * (uint32_t) nb_p, nb_pw = 16u * (uint32_t) nb_p;
+  {
+    const uint8_t *src = pm_read_ptr (b, eP, &rlen);
+#pragma unroll
+    for (int t = 0; t < 5; t++)
+      {
+        const int i = lane + 64 * t;
+        rb[t] = (i < nb) ? src[i] : (uint8_t) 0;
+      }
+  }
+  while (eQ < n_ends || eP < n_ends)
+    {
+      // the lines of eQ (requested during the previous iteration) and the bytes of eP have landed after this
+      asm volatile ("s_waitcnt vmcnt(0)":::"memory");
+      int SP = 0;
+      bool skipP = true;
+      uint32_t kP = 0;          // lane sg: the k-mer of (strand, segment) sg of eP
+      if (eP < n_ends)
+        {
+          // ---- P: the read in registers -> LDS, N filter (pemapper.c:1552-1559), k-mers, line requests into lines[buf ^ 1]
+          const int bf = buf ^ 1;
+          const int len = rlen;
+          int isn = 0;
+#pragma unroll
+          for (int t = 0; t < 5; t++)
+            {
+              const int i = lane + 64 * t;
+              if (i < len)
+                {
+                  // the 2-bit codes of both strands (fill_cv_mat / convert_ct, pemapper.c:2375-2383, 2292-2300), not the letters
+                  const uint8_t c = rb[t];
+                  sh.seq[0][i] = (uint8_t) pm_code_flat (c, prm.bisulfite);
+                  sh.seq[1][len - 1 - i] = (uint8_t) pm_code_flat (pm_rc_flat (c), prm.bisulfite);
+                  isn += (c == 'N');
+                }
+            }
+          for (int o = 32; o; o >>= 1)
+            isn += __shfl_xor (isn, o);
+          int cuts = len / idepth;      // pemapper.c:1573-1587
+          if (len % idepth == 0)
+            cuts--;
+          if (cuts > SMAX - 1)
+            cuts = SMAX - 1;
+          SP = cuts + 1;
+          skipP = isn >= 1 + len / 10;
+          if (!skipP)
+            {
+              if (lane <= cuts)
+                sh.offsets[bf][lane] = (lane < cuts || cuts == 0) ? lane * idepth : len - idepth;
+              pm_wave_sync ();
+              if (lane < 2 * SP)
+                {
+                  const int strand = lane / SP, seg = lane - strand * SP;
+                  const uint8_t *p = &sh.seq[strand][sh.offsets[bf][seg]];
+                  uint32_t k = 0;
+#pragma unroll
+                  for (int i = 0; i < 16; i++)
+                    k = (k << 2) + p[i];
+                  sh.kmer[bf][lane] = k;
+                  kP = k;
+                }
+              pm_wave_sync ();
+              const int n_lines = 2 * SP * 8;
+              const uint32_t lds0 = (uint32_t) __builtin_amdgcn_readfirstlane ((int) (uint32_t) (size_t) (pm_lptr_t) & sh.lines[bf][0]);
+#pragma unroll
+              for (int r = 0; r < SMAX; r++)
+                {
+                  const int li = r * 16 + (lane >> 2);
+                  if (li < n_lines)
+                    {
+                      const int p = li & 7;
+                      const uint32_t idx = pm_swap_fields (sh.kmer[bf][li >> 3], p);
+                      const uint32_t *g = ix.rep + ((size_t) p << 32) + (size_t) (idx & ~15u) + (size_t) ((lane & 3) * 4);
+                      pm_glds16 (g, lds0 + (uint32_t) (r * 1024));
+                    }
+                }
+            }
+        }
+      // ---- R: request the bytes of the end after (whole row up to the stride: no dependence on its length)
+      const int eN = eR;
+      if (eN < n_ends)
+        {
+          eR = eF;
+          eF = (int) gridDim.x + (int) __builtin_amdgcn_readfirstlane ((int) (lane == 0 ? atomicAdd (out.next_end, 1u) : 0u));
+          const uint8_t *src = pm_read_ptr (b, eN, &rlen);
+#pragma unroll
+          for (int t = 0; t < 5; t++)
+            {
+              const int i = lane + 64 * t;
+              rb[t] = (i < nb) ? src[i] : (uint8_t) 0;
+            }
+        }
+      // ---- Q
+      if (eQ < n_ends)
+        {
+          const int e = eQ, S = SQ;
+          PmEndHeader *hd = &out.hdr[e];
+          if (skipQ)
+            {
+              if (lane == 0)
+                hd->kind = PM_KIND_SKIP;
+            }
+          else
+            {
+              const uint32_t *lines = &sh.lines[buf][0];
+              // ---- C: one (strand, segment) per round, lane j = neighbour j (get_mers, pemapper.c:2158-2165, fill_mers' order).
+              //      First every read of the landed lines (nothing between them that could order them), then the bookkeeping.
+              uint32_t ent[2 * SMAX];
+#pragma unroll
+              for (int sg = 0; sg < 2 * SMAX; sg++)
+                {
+                  const uint32_t k = (uint32_t) __builtin_amdgcn_readlane ((int) kQ, sg);
+                  const uint32_t cur = (k >> nb_sh) & 3u;
+                  const uint32_t alt = nb_a + (nb_a >= cur ? 1u : 0u);
+                  const uint32_t nbk = (k & nb_keep) | ((alt << nb_sh) & nb_alt_on);
+                  ent[sg] = lines[sg * 128 + nb_pw + ((nbk >> nb_p4) & 15u)];
+                }
+              int n_multi = 0;
+              int my_ns = 0, my_mfirst = 0;     // lane sg: segment sg's buckets of one position; its first record in mlist
+              int my_badi = 0;                  // lane sg: a bucket of the segment reaches too_many_spots (pemapper.c:1602-1606)
+#pragma unroll
+              for (int sg = 0; sg < 2 * SMAX; sg++)
+                {
+                  const uint32_t en = (lane < 49 && sg < 2 * S) ? ent[sg] : 0xFFFFFFFFu;
+                  ent[sg] = en;
+                  const bool is_multi = en >= multi_base && en < 0xFFFFFFFEu;
+                  const unsigned long long bs = __ballot (en < multi_base), bm = __ballot (is_multi), bt = __ballot (en == 0xFFFFFFFEu);
+                  if (is_multi)
+                    {
+                      const int slot = n_multi + (int) __builtin_amdgcn_mbcnt_hi ((unsigned) (bm >> 32), __builtin_amdgcn_mbcnt_lo ((unsigned) bm, 0u));
+                      sh.mlist[slot] = (uint16_t) (sg * 64 + lane);
+                      sh.ment[slot] = en;
+                    }
+                  my_ns = (lane == sg) ? (int) __popcll (bs) : my_ns;
+                  my_mfirst = (lane == sg) ? n_multi : my_mfirst;
+                  my_badi = (lane == sg) ? (bt != 0ull ? 1 : 0) : my_badi;
+                  n_multi += __popcll (bm);
+                }
+              const bool my_bad = my_badi != 0;
+              pm_wave_sync ();
+              // ---- D: the counts of the records (their first word), 4 rounds in flight, and the exclusive prefix of the counts
+              {
+                uint32_t carry = 0;
+#pragma unroll 1
+                for (int i0 = 0; i0 < n_multi; i0 += 256)
+                  {
+                    uint32_t cnt[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                      {
+                        const int i = i0 + r * 64 + lane;
+                        cnt[r] = 0;
+                        if (i < n_multi)
+                          cnt[r] = ix.multi[(size_t) (sh.ment[i] - multi_base) * 4];
+                      }
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                      {
+                        const int i = i0 + r * 64 + lane;
+                        if (i0 + r * 64 < n_multi)
+                          {
+                            uint32_t incl = cnt[r];
+                            for (int o = 1; o < 64; o <<= 1)
+                              {
+                                const uint32_t t = __shfl_up (incl, o);
+                                if (lane >= o)
+                                  incl += t;
+                              }
+                            if (i < n_multi)
+                              sh.mp[i] = carry + incl - cnt[r];
+                            carry += __shfl (incl, 63);
+                          }
+                      }
+                  }
+                if (lane == 0)
+                  sh.mp[n_multi] = carry;
+              }
+              pm_wave_sync ();
+              // ---- E: segment sizes, their prefix inside each strand, where each segment's two kinds of positions start
+              int mf_next = __shfl_down (my_mfirst, 1);
+              if (lane == 2 * S - 1)
+                mf_next = n_multi;
+              int cnt = 0;
+              uint32_t mp_first = 0;
+              if (lane < 2 * S)
+                {
+                  mp_first = sh.mp[my_mfirst];
+                  cnt = my_bad ? 0 : my_ns + (int) (sh.mp[mf_next] - mp_first);
+                }
+              int inc = cnt;
+              for (int o = 1; o < 64; o <<= 1)
+                {
+                  const int t = __shfl_up (inc, o);
+                  if (lane >= o)
+                    inc += t;
+                }
+              const int T0 = __shfl (inc, S - 1), TT = __shfl (inc, 2 * S - 1);
+              const int T1 = TT - T0;
+              int my_dst = PM_SEG_DEAD;         // lane sg: list index of the segment's first position
+              uint32_t my_bias = 0;
+              if (lane < 2 * S)
+                {
+                  const int strand = lane / S, seg = lane - strand * S;
+                  const int sb = inc - cnt - (strand ? T0 : 0);
+                  sh.seg_base[strand][seg] = sb;
+                  my_bias = (uint32_t) (PM_DIAG_BIAS - sh.offsets[buf][seg]);
+                  if (!my_bad)
+                    my_dst = strand * PM_SEED_CAP + sb;
+                  sh.seg_ms[lane] = my_bad ? PM_SEG_DEAD : my_dst + my_ns - (int) mp_first;
+                }
+              if (lane == 0)
+                {
+                  sh.seg_base[0][S] = T0;
+                  sh.seg_base[1][S] = T1;
+                }
+              pm_wave_sync ();
+              if (T0 > PM_SEED_CAP || T1 > PM_SEED_CAP)
+                {
+                  if (lane == 0)
+                    {
+                      hd->kind = PM_KIND_BIG;
+                      out.big_list[atomicAdd (out.n_big, 1u)] = (uint32_t) e;
+                    }
+                }
+              else
+                {
+                  if (lane == 0)
+                    {
+                      hd->kind = PM_KIND_NORMAL;
+                      hd->T[0] = (uint16_t) T0;
+                      hd->T[1] = (uint16_t) T1;
+                    }
+                  n_pos += (unsigned long long) TT;
+                  if (lane < 2 * (S + 1))
+                    {
+                      const int st = lane / (S + 1), k = lane - st * (S + 1);
+                      hd->seg_base[st][k] = (uint16_t) sh.seg_base[st][k];
+                    }
+                  uint32_t *okey = out.key + (size_t) e * 2 * PM_SEED_CAP;
+                  uint8_t *oseg = out.seg + (size_t) e * 2 * PM_SEED_CAP;
+                  // ---- F: the buckets of one position, from registers
+#pragma unroll
+                  for (int sg = 0; sg < 2 * SMAX; sg++)
+                    if (sg < 2 * S)
+                      {
+                        const int dd = __builtin_amdgcn_readlane (my_dst, sg);
+                        const uint32_t bias = (uint32_t) __builtin_amdgcn_readlane ((int) my_bias, sg);
+                        const uint32_t en = ent[sg];
+                        const bool single = en < multi_base;
+                        const unsigned long long bs = __ballot (single);
+                        if (single && dd != PM_SEG_DEAD)
+                          {
+                            const uint32_t at = (uint32_t) dd + __builtin_amdgcn_mbcnt_hi ((unsigned) (bs >> 32), __builtin_amdgcn_mbcnt_lo ((unsigned) bs, 0u));
+                            *(uint32_t *) ((uint8_t *) okey + (at << 2)) = en + bias;        // (32-bit byte offset: at < 2 * PM_SEED_CAP)
+                            oseg[at] = (uint8_t) (sg >= S ? sg - S : sg);
+                          }
+                      }
+                  // ---- G: the records' positions (the first three come with the count)
+#pragma unroll 1
+                  for (int i0 = 0; i0 < n_multi; i0 += 64)
+                    {
+                      const int i = i0 + lane;
+                      if (i < n_multi)
+                        {
+                          const int sg = sh.mlist[i] >> 6;
+                          const int ms = sh.seg_ms[sg];
+                          if (ms != PM_SEG_DEAD)
+                            {
+                              const uint32_t dst = (uint32_t) ms + sh.mp[i];
+                              const uint32_t *rec = ix.multi + (size_t) (sh.ment[i] - multi_base) * 4;
+                              const uint4 h = *(const uint4 *) rec;
+                              const int seg = sg >= S ? sg - S : sg;
+                              const uint32_t bias = (uint32_t) (PM_DIAG_BIAS - sh.offsets[buf][seg]);
+                              const uint32_t c = h.x;
+                              okey[dst] = h.y + bias;
+                              oseg[dst] = (uint8_t) seg;
+                              okey[dst + 1] = h.z + bias;
+                              oseg[dst + 1] = (uint8_t) seg;
+                              if (c > 2)
+                                {
+                                  okey[dst + 2] = h.w + bias;
+                                  oseg[dst + 2] = (uint8_t) seg;
+                                }
+#pragma unroll 1
+                              for (uint32_t t = 3; t < c; t++)
+                                {
+                                  okey[dst + t] = rec[t + 1] + bias;
+                                  oseg[dst + t] = (uint8_t) seg;
+                                }
+                            }
+                        }
+                    }
+                }
+              pm_wave_sync ();
+            }
+        }
+      eQ = eP;
+      eP = eN;
+      kQ = kP;
+      SQ = SP;
+      skipQ = skipP;
+      buf ^= 1;
+    }
+  if (lane == 0 && n_pos)
+    atomicAdd (out.positions, n_pos);
+}
+
 // LDS of the vote kernel: one strand at a time (the lists come from HBM), no look-up items
 template < int SMAX > struct __align__ (8) PmVoteShared
 {
