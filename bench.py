@@ -175,6 +175,7 @@ def main():
         cand = {k: v for k, v in avg_ms.items() if k != ("seed" if split else "lookup") and (split or k != "vote")}
         dom = max(cand, key=cand.get)
         ends = agg["ends"]
+        n_rep, rec_bytes = dev.lookup_replicas()
         P_e = agg["positions"] / ends
         H_e = agg["sw_score"] / ends
         L = a.read_len
@@ -186,7 +187,8 @@ def main():
         slab = lanes * ((L + 21 + lanes + 15) // 16 * 16) * ((W * 4 + 31) // 32) * 4
         per_end = {
             "seed": S * 49 * 2 * 8 + 4.0 * P_e + L,                     # pos_index pairs + bucket payload + the read
-            "lookup": S * 49 * 2 * 8 + 4.0 * P_e + L + 5.0 * P_e,       # ... + the (key, segment) lists written for the vote
+            # ... + the (key, segment) lists written for the vote; with the look-up replicas an entry is 4 bytes, not a pair
+            "lookup": S * 49 * 2 * (4 if n_rep else 8) + 4.0 * P_e + L + 5.0 * P_e,
             "vote": 5.0 * P_e + H_e * 16,
             "sw_single": n_single * (L + 21 + L + slab),                # window + read in, direction nibbles out
             "sw_multi": n_multi * (L + 21 + L),
@@ -207,7 +209,12 @@ def main():
         achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
         kname = "pm_%s_kernel" % dom
         if dom == "lookup" and os.environ.get("PEMAP_LOOKUP_WAVES", "6") != "0":
-            kname = "pm_lookup_wave_kernel"     # the persistent wave-per-end form of the look-up kernel (default)
+            # the persistent wave-per-end forms of the look-up kernel: against the 8 replicas of the table (default on an
+            # MI355X), or against the reference's table
+            kname = ("pm_lookup_rep2_kernel" if os.environ.get("PEMAP_LOOKUP_V", "1") == "2" else "pm_lookup_rep_kernel") if n_rep \
+                else "pm_lookup_wave_kernel"
+        elif dom.startswith("sw_"):
+            kname = "pm_sw_kernel"
         traffic, tsrc = pmc_traffic(kname, gs, B, L)
         roof = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc,
@@ -229,7 +236,8 @@ def main():
             "config": {"workload": "hg38-sized synthetic index resident in HBM (%.2f Gbp, %d contigs, %d%% repeat tiles), "
                                    "2x%dbp paired-end reads, %d pairs per step per GPU" % (gs / 1e9, n_contigs, int(a.repeat_frac * 100), L, B),
                        "genome_size": gs, "n_mers": n_mers, "batch_pairs": B, "read_len": L, "sub_rate": a.sub_rate,
-                       "indel_rate": a.indel_rate, "sharding": "reads split by rank, index replica per GPU"},
+                       "indel_rate": a.indel_rate, "sharding": "reads split by rank, index replica per GPU",
+                       "lookup_replicas": n_rep, "lookup_record_bytes": rec_bytes},
             "roofline": roof, "cpu_baseline": cpu, "timings": {k: round(v, 2) for k, v in timings.items()},
             "counters_per_step": {k: int(v / a.steps) for k, v in agg.items()},
         }
@@ -242,19 +250,22 @@ def main():
 
 def pmc_traffic(kernel, gsize, B, L):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs
-    of this same command, profiles/r01_bench_pmc_final.json), valid for the default workload only.  FETCH_SIZE is taken
-    at face value: on this kernel's 8-byte random gathers it equals TCC_EA0_RDREQ x 64 B, one 64-byte request per gather
-    (calibrated with tools/micro/gather_calib.hip; the 1/2 factor of MI355X_MICROARCH.md applies to coalesced streams)."""
-    path = os.path.join(ROOT, "profiles", "r01_bench_pmc_final.json")
-    if not (os.path.exists(path) and gsize == 3100000000 and B == 1000000 and L == 150):
+    of this same command, profiles/r01_bench_pmc_*.json, newest pipeline first), valid for the default workload only.
+    FETCH_SIZE is taken at face value: on this path's random 8- to 64-byte reads it equals TCC_EA0_RDREQ x 64 B, one 64-byte
+    request each (calibrated with tools/micro/gather_calib.hip; the 1/2 factor of MI355X_MICROARCH.md applies to coalesced
+    streams)."""
+    if not (gsize == 3100000000 and B == 1000000 and L == 150):
         return None, None
-    try:
-        pm = json.load(open(path))
-        f = [v for k, v in pm["FETCH_SIZE"].items() if k.startswith(kernel)][0]["mean_KB_per_launch"]
-        w = [v for k, v in pm["WRITE_SIZE"].items() if k.startswith(kernel)][0]["mean_KB_per_launch"]
-        return round((f + w) * 1024.0), "profiles/r01_bench_pmc_final.json"
-    except Exception:
-        return None, None
+    for name in ("r01_bench_pmc_replicas.json", "r01_bench_pmc_final.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            pm = json.load(open(path))
+            f = [v for k, v in pm["FETCH_SIZE"].items() if k.startswith(kernel)][0]["mean_KB_per_launch"]
+            w = [v for k, v in pm["WRITE_SIZE"].items() if k.startswith(kernel)][0]["mean_KB_per_launch"]
+            return round((f + w) * 1024.0), "profiles/" + name
+        except Exception:
+            continue
+    return None, None
 
 
 def cpu_baseline(dev, a, B):
