@@ -180,8 +180,8 @@ def main():
         H_e = agg["sw_score"] / ends
         L = a.read_len
         S = L // 16 + (0 if L % 16 == 0 else 1)
-        n_single = (agg["sw_dirs"] - agg["redo"]) / ends      # problems scored once, with nibbles
-        n_multi = (agg["sw_score"] - (agg["sw_dirs"] - agg["redo"])) / ends
+        n_single = (agg["sw_dirs"] - agg["redo"]) / ends      # single-hit problems the DP scored, with nibbles (the rest: gapless rule)
+        n_multi = (agg["sw_score"] - (agg["sw_dirs"] - agg["redo"]) - agg.get("gapless", 0)) / ends
         # SW geometry as pick_geom (pemap_capi.hip): lanes per alignment, columns per lane
         lanes, W = (8, 13) if L <= 104 else (8, 19) if L <= 152 else (8, 26) if L <= 208 else (8, 32) if L <= 256 else (8, 38)
         slab = lanes * ((L + 21 + lanes + 15) // 16 * 16) * ((W * 4 + 31) // 32) * 4

@@ -147,11 +147,13 @@ int pemap_dev_summary (pemap_dev * dev, long *out13);
  * scored with direction nibbles (single-hit ends + re-scored winners), [4] = DP cells without nibbles, [5] = DP cells
  * with nibbles, [6] = pileup increments, [7] = insertions logged, [8] = alignments walked back, [9] = winners re-scored,
  * [10] = read-ends with a strand of more than 1024 positions (handled by the monolithic seed kernel),
- * [11] = chunks the run was cut into (= launches of every kernel).
+ * [11] = chunks the run was cut into (= launches of every kernel),
+ * [12] = single-hit problems decided without the DP (a diagonal with at most one mismatch; with PEMAP_GAPLESS=0 none):
+ *        [3], [5] count the DP's share only.
  * times_ms[0..7] = seed stage (look-up + vote), SW single-hit (with nibbles), SW multi-hit, select, SW re-score,
  * walk+pileup, look-up kernel alone, vote kernels alone: kernel durations from HIP events on the object's streams,
  * summed over the run's chunks (with the two-stream pipeline they overlap in time, so their sum exceeds the wall time). */
-int pemap_dev_run_stats (pemap_dev * dev, uint64_t * stats12, float *times_ms8);
+int pemap_dev_run_stats (pemap_dev * dev, uint64_t * stats13, float *times_ms8);
 
 /* Debug/parity taps: per read-end hit lists and per-hit SW results of the last run.
  * n_hits[n_ends]; the other arrays are [n_ends][PEMAP_MAX_HITS]. Any pointer may be NULL. end = 2*pair + mate in paired mode. */

@@ -757,10 +757,10 @@ static int ensure_work (pemap_dev * d, int n_ends, bool two_sets)
         {
           TRY (alloc_hits (d, d->hits2, n_ends));
           TRY (dev_alloc (d, &d->d_wins2, (size_t) n_ends));
-          TRY (dev_alloc (d, &d->d_tasks_s2, (size_t) n_ends));
+          TRY (dev_alloc (d, &d->d_tasks_s2, (size_t) n_ends * 2));       // second half: the problems left to the DP
           TRY (dev_alloc (d, &d->d_tasks_m2, nh));
         }
-      TRY (dev_alloc (d, &d->d_tasks_s, (size_t) n_ends));
+      TRY (dev_alloc (d, &d->d_tasks_s, (size_t) n_ends * 2));
       TRY (dev_alloc (d, &d->d_tasks_m, nh));
       TRY (dev_alloc (d, &d->d_redo, (size_t) n_ends));
       d->cap_ends = n_ends;
@@ -1002,6 +1002,13 @@ static void launch_vote (pemap_dev * d, const RunCtx & c, bool split, int slot, 
   hipEventRecord (ev[3], st);
 }
 
+// PEMAP_GAPLESS=0: every single-hit problem goes through the DP (the rule of pm_gapless_kernel off)
+static bool pm_gapless_on ()
+{
+  static const int g = getenv ("PEMAP_GAPLESS") ? atoi (getenv ("PEMAP_GAPLESS")) : 1;
+  return g != 0;
+}
+
 // ---- the ALU stream's work for one chunk: (the seed stage unless it ran on the memory stream,) SW, selection, traceback.
 template < int W, int LPA > static void launch_chunk (pemap_dev * d, const RunCtx & c, uint32_t * m1, uint32_t * m2, int *mt, bool split, int slot,
                                              PmChunkCtr * cc, hipEvent_t * ev)
@@ -1018,8 +1025,19 @@ template < int W, int LPA > static void launch_chunk (pemap_dev * d, const RunCt
   PmCounters *ctr = &cc->c;
   if (!(split && d->vote_on_mem))
     launch_vote (d, c, split, slot, cc, ev, d->stream);
-  hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, LPA, true >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, H,
-                      tasks_s, &ctr->n_tasks_s, ctr, dirbuf, dump_slab, c.tstride, c.L, swprio, &ctr->sw_next[0]);
+  if (pm_gapless_on ())
+    {
+      uint32_t *tasks_dp = tasks_s + d->cap_ends;
+      int ggrid = (n_ends + 7) / 8;
+      if (ggrid > d->n_cus * 16)
+        ggrid = d->n_cus * 16;
+      hipLaunchKernelGGL (pm_gapless_kernel, dim3 (ggrid), dim3 (256), 0, d->stream, c.ix, c.b, c.prm, H, tasks_s, &ctr->n_tasks_s, tasks_dp, ctr);
+      hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, LPA, true >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, H,
+                          tasks_dp, &ctr->n_tasks_dp, ctr, dirbuf, dump_slab, c.tstride, c.L, swprio, &ctr->sw_next[0]);
+    }
+  else
+    hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, LPA, true >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, H,
+                        tasks_s, &ctr->n_tasks_s, ctr, dirbuf, dump_slab, c.tstride, c.L, swprio, &ctr->sw_next[0]);
   hipEventRecord (ev[4], d->stream);
   hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, LPA, false >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, H,
                       tasks_m, &ctr->n_tasks_m, ctr, dirbuf, dump_slab, c.tstride, c.L, swprio, &ctr->sw_next[1]);
@@ -1080,6 +1098,7 @@ static int absorb_run (pemap_dev * d)
       const PmCounters & c = hc[k].c;
       t.n_tasks_s += c.n_tasks_s;
       t.n_tasks_m += c.n_tasks_m;
+      t.n_tasks_dp += pm_gapless_on () ? c.n_tasks_dp : c.n_tasks_s;
       t.n_slots += c.n_slots;
       t.n_redo += c.n_redo;
       t.n_wins += c.n_wins;
@@ -1516,7 +1535,7 @@ extern "C" int pemap_dev_run_stats (pemap_dev * d, uint64_t * s, float *t)
       s[0] = d->run_ends;
       s[1] = c.positions;
       s[2] = (uint64_t) c.n_tasks_s + c.n_tasks_m;
-      s[3] = (uint64_t) c.n_tasks_s + c.n_redo;
+      s[3] = (uint64_t) c.n_tasks_dp + c.n_redo;
       s[4] = c.cells_score;
       s[5] = c.cells_dirs;
       s[6] = c.pile_incs;
@@ -1525,6 +1544,7 @@ extern "C" int pemap_dev_run_stats (pemap_dev * d, uint64_t * s, float *t)
       s[9] = c.n_redo;
       s[10] = d->last_big;
       s[11] = (uint64_t) d->run_chunks;
+      s[12] = (uint64_t) c.n_tasks_s - c.n_tasks_dp;
     }
   if (t)
     memcpy (t, d->last_ms, sizeof (d->last_ms));
@@ -1569,7 +1589,7 @@ extern "C" int pemap_dev_debug_hits (pemap_dev * d, int *n_hits, uint32_t * spot
       std::vector < uint8_t > t (nh);
       HIPCHK (d, hipMemcpy (t.data (), d->hits.stk, nh, hipMemcpyDeviceToHost));
       for (size_t i = 0; i < nh; i++)
-        start_k[i] = t[i];
+        start_k[i] = t[i] & 3;  // (bit 2 = decided by the gapless rule)
     }
   return 0;
 }

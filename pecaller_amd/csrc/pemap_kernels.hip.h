@@ -45,7 +45,7 @@ struct PmCounters
   unsigned int n_slots;            // direction slabs handed out
   unsigned int n_redo;             // winners of multi-hit ends: scored again with direction nibbles
   unsigned int n_wins;             // alignments to walk back
-  unsigned int pad0;
+  unsigned int n_tasks_dp;         // single-hit problems the gapless rule (pm_gapless_kernel) leaves to the DP
   unsigned long long positions;    // P: entries copied out of .mdx
   unsigned long long cells_score;  // DP cells computed without / with direction nibbles
   unsigned long long cells_dirs;

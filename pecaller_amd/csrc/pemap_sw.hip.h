@@ -377,6 +377,132 @@ __device__ __forceinline__ void pm_sw_forward (const PmSwTask & tk, int bis, int
   bi = __shfl (i_b, srcl);
 }
 
+// ============================================================================================================
+// K3a: the gapless rule.  For most reads the affine-gap DP only confirms what a comparison along the window's
+// nn - mm + 1 diagonals already shows, and that case can be decided exactly without it.  Scores (pemapper.c:2006-2095):
+// match +1, mismatch -1/3, gap open 2, gap extend 1/36; the read is aligned globally, so a gapless alignment on diagonal d
+// with x mismatches scores (mm - x) - x/3 and ANY alignment with a gap scores at most mm - 2 (at most mm matches, at least
+// one gap open).  Hence, if some diagonal has x <= 1 (score >= mm - 4/3 > mm - 2):
+//   * every cell of the last read column that can hold the best score (pemapper.c:1717-1742) is the end of a diagonal
+//     with x <= 1, in plane 0; the DP's value there is the left fold  S0 = S0 + bonus  from S0[.][0] = 0 (2062-2081)
+//     along that diagonal, because every other path into a cell of such a diagonal carries a gap and is smaller by more
+//     than 2/3 -- the fold is reproduced here addition by addition, so the double is the DP's to the last bit;
+//   * the winner is the first of them in ascending row order under strict '>' (1724-1741);
+//   * the traceback (1799-1831) never leaves plane 0: at every cell of the winning diagonal S0 >= j - 4/3 while S1 and
+//     S2 are <= j - 2, so `S1 > S0` and `S2 > max(S0, S1)` are false all the way to column 0: mm diagonal steps.
+// Such a problem gets its score, start cell (plane 0, row d + mm) and the PM_GAPLESS flag; the walk kernel then emits
+// mm diagonal steps without a direction slab.  Everything else is appended to tasks_dp for pm_sw_kernel.  With 1 %
+// substitutions 56 % of the 150-base reads have at most one.  One half-wave per problem, lane = diagonal; wrong diagonals
+// drop out after a few bases.
+// ============================================================================================================
+#define PM_GAPLESS 4            // flag in PmHits::stk beside the plane number
+
+__global__ __launch_bounds__ (256) void pm_gapless_kernel (PmIndex ix, PmBatch b, PmParams prm, PmHits h, const uint32_t * tasks,
+                                                          const unsigned *n_tasks_p, uint32_t * tasks_dp, PmCounters * ctr)
+{
+  __shared__ __align__ (8) uint8_t rd[8][320];
+  const int lane = threadIdx.x & 63, l = lane & 31;
+  const int slot = threadIdx.x >> 5;            // half-wave of the block
+  const unsigned n_tasks = *n_tasks_p;
+  const int bis = prm.bisulfite;
+  const double miss = __hiloint2double ((int) 0xBFD55555u, (int) 0x55555555u);     // -1/3 as the reference's double (pemapper.c:2011-2019)
+  for (unsigned t0 = blockIdx.x * 8u; t0 < n_tasks; t0 += gridDim.x * 8u)
+    {
+      const unsigned t = t0 + (unsigned) slot;
+      const bool valid = t < n_tasks;
+      size_t o = 0;
+      int mm = 0, nn = 0, orient = 0;
+      const uint8_t *read = b.reads1, *ref = ix.genome;
+      if (valid)
+        {
+          o = tasks[t];
+          read = pm_read_ptr (b, (int) (o / PM_MAX_HITS), &mm);
+          nn = h.nn[o];
+          orient = h.orient[o];
+          ref = ix.genome + h.gpos[o];
+        }
+      // the oriented read, padded with zeros to a multiple of 8
+      for (int jz = l; jz < ((mm + 7) & ~7); jz += 32)
+        rd[slot][jz] = (jz < mm) ? pm_oriented (read, mm, orient, jz) : (uint8_t) 0;
+      __builtin_amdgcn_fence (__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier ();
+      const int ndiag = valid ? nn - mm + 1 : 0;         // diagonals on which the whole read lies inside the window
+      int mism = 2, mpos = 0;
+      if (l < ndiag)
+        {
+          mism = 0;
+          const uint8_t *rp = ref + l;
+          for (int j = 0; j < mm && mism < 2; j += 8)
+            {
+              const uint64_t q = *(const uint64_t *) &rd[slot][j];
+              const uint64_t r = *(const pm_u64_unaligned *) (rp + j);      // (the genome buffer is padded: reading past the window is safe)
+              const int nb = mm - j < 8 ? mm - j : 8;
+              uint64_t x = q ^ r;
+              if (nb < 8)
+                x &= (1ull << (8 * nb)) - 1ull;
+              if (x != 0ull)
+                for (int k = 0; k < nb; k++)
+                  if (((x >> (8 * k)) & 0xFFull) && !pm_match ((uint8_t) (r >> (8 * k)), (uint8_t) (q >> (8 * k)), bis))
+                    {
+                      mism++;
+                      mpos = j + k;
+                    }
+            }
+        }
+      const bool cand = mism <= 1;
+      // the DP's value at the end of a candidate diagonal: the left fold of the bonuses
+      double sc = 0.0;
+      if (cand)
+        {
+          if (mism == 0)
+            sc = (double) mm;
+          else
+            {
+              // (only the last mismatch position was kept, and there is exactly one)
+              sc = (double) mpos + miss;
+              for (int k = mpos + 1; k < mm; k++)
+                sc = sc + 1.0;
+            }
+        }
+      const unsigned long long bal = __ballot (cand);
+      const unsigned cmask = (unsigned) (bal >> (lane & 32));     // this half-wave's candidates
+      if (valid)
+        {
+          if (cmask == 0u)
+            {
+              if (l == 0)
+                tasks_dp[atomicAdd (&ctr->n_tasks_dp, 1u)] = (uint32_t) o;
+            }
+          else
+            {
+              // ascending rows, strict '>' (pemapper.c:1724-1741)
+              double best = 0.0;
+              int bd = -1;
+              unsigned m = cmask;
+              while (m)
+                {
+                  const int dl = __ffs ((int) m) - 1;
+                  m &= m - 1u;
+                  const double s = __shfl (sc, (lane & 32) + dl);
+                  if (bd < 0 || s > best)
+                    {
+                      best = s;
+                      bd = dl;
+                    }
+                }
+              if (l == 0)
+                {
+                  h.score[o] = best;
+                  h.stk[o] = (uint8_t) PM_GAPLESS;
+                  h.sti[o] = (int16_t) (bd + mm);
+                }
+            }
+        }
+      __builtin_amdgcn_fence (__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier ();
+    }
+}
+
 __device__ __forceinline__ int pm_wave_max (int v)
 {
   for (int o = 32; o > 0; o >>= 1)
@@ -695,6 +821,14 @@ template < int W, int PM_LPA > __global__ __launch_bounds__ (256) void pm_walk_k
       int k = h.stk[o], i = h.sti[o], j = mm;
       int i1 = 0, ins_len = 0;
       unsigned long long *pw = path + (size_t) w * path_words;
+      if (k & PM_GAPLESS)
+        {
+          // decided by pm_gapless_kernel: mm diagonal steps (code 0) from (plane 0, row i, column mm), no direction slab
+          for (int q = 0; q < (mm + 31) / 32; q++)
+            pw[q] = 0ull;
+          n_steps[w] = (uint16_t) mm;
+          continue;
+        }
       unsigned long long acc = 0;
       int ns = 0;
       while (i > 0 && j > 0)
