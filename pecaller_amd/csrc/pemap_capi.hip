@@ -907,8 +907,8 @@ static void launch_lookup (pemap_dev * d, const RunCtx & c, int slot, PmChunkCtr
   // PEMAP_LOOKUP_V (with replicas): 1 = pm_lookup_rep_kernel (default), 2 = the pipelined pm_lookup_rep2_kernel (measured
   // slower: 68 ms per step at its best point, 3 waves per CU, against 65 -- see DESIGN.md)
   static const int lv = getenv ("PEMAP_LOOKUP_V") ? atoi (getenv ("PEMAP_LOOKUP_V")) : 1;
-  // waves per CU: with the replicas 4 (one per SIMD: a fifth takes a third SW wave's registers somewhere), otherwise 6
-  const int lw = lwenv ? atoi (lwenv) : (c.ix.n_rep == 8) ? (lv == 2 ? 3 : 4) : 6;
+  // waves per CU: with the replicas 5 (4 before the gapless rule halved the SW kernel's share: one per SIMD), otherwise 6
+  const int lw = lwenv ? atoi (lwenv) : (c.ix.n_rep == 8) ? (lv == 2 ? 3 : 5) : 6;
   int lgrid = lw * d->n_cus;
   if (lgrid > c.b.n_ends)
     lgrid = c.b.n_ends;
@@ -963,7 +963,9 @@ static void launch_vote (pemap_dev * d, const RunCtx & c, bool split, int slot, 
         vgrid = n_ends;
       // PEMAP_VOTE_PERSIST=0 selects the lean one-end-per-wave form (120 VGPRs instead of 161).  A/B on one box, three runs each:
       // 77.6 ms per step against 74.3 -- more resident vote waves take slots from the look-up waves -- so the fat form stays
-      static const int vpersist = getenv ("PEMAP_VOTE_PERSIST") ? atoi (getenv ("PEMAP_VOTE_PERSIST")) : 1;
+      // (with the look-up replicas the look-ups are off the critical path and the lean form wins: 55.3 ms against 56.2)
+      static const int vpersist_env = getenv ("PEMAP_VOTE_PERSIST") ? atoi (getenv ("PEMAP_VOTE_PERSIST")) : -1;
+      const int vpersist = vpersist_env >= 0 ? vpersist_env : (c.ix.n_rep == 8 ? 0 : 1);
 #define PM_VT(SM) do { if (vw > 0 && vgrid == n_ends && !vpersist) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_vote_wave_kernel < SM, false >), dim3 (vgrid), dim3 (64), 0, st, c.ix, c.b, c.prm, H, L, vprio); \
     else if (vw > 0) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_vote_wave_kernel < SM, true >), dim3 (vgrid), dim3 (64), 0, st, c.ix, c.b, c.prm, H, L, vprio); \
     else hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_vote_kernel < SM >), dim3 (n_ends), dim3 (PM_SEED_THREADS), 0, st, c.ix, c.b, c.prm, \
