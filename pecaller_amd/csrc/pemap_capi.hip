@@ -1011,6 +1011,13 @@ static bool pm_gapless_on ()
   return g != 0;
 }
 
+// PEMAP_GAPLESS=1 restricts the rule to its first case (diagonals with at most one mismatch)
+static int pm_gapless_max_x ()
+{
+  static const int g = getenv ("PEMAP_GAPLESS") ? atoi (getenv ("PEMAP_GAPLESS")) : 2;
+  return g;
+}
+
 // ---- the ALU stream's work for one chunk: (the seed stage unless it ran on the memory stream,) SW, selection, traceback.
 template < int W, int LPA > static void launch_chunk (pemap_dev * d, const RunCtx & c, uint32_t * m1, uint32_t * m2, int *mt, bool split, int slot,
                                              PmChunkCtr * cc, hipEvent_t * ev)
@@ -1033,7 +1040,8 @@ template < int W, int LPA > static void launch_chunk (pemap_dev * d, const RunCt
       int ggrid = (n_ends + 7) / 8;
       if (ggrid > d->n_cus * 16)
         ggrid = d->n_cus * 16;
-      hipLaunchKernelGGL (pm_gapless_kernel, dim3 (ggrid), dim3 (256), 0, d->stream, c.ix, c.b, c.prm, H, tasks_s, &ctr->n_tasks_s, tasks_dp, ctr);
+      hipLaunchKernelGGL (pm_gapless_kernel, dim3 (ggrid), dim3 (256), 0, d->stream, c.ix, c.b, c.prm, H, tasks_s, &ctr->n_tasks_s, tasks_dp, ctr,
+                          pm_gapless_max_x ());
       hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, LPA, true >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, H,
                           tasks_dp, &ctr->n_tasks_dp, ctr, dirbuf, dump_slab, c.tstride, c.L, swprio, &ctr->sw_next[0]);
     }

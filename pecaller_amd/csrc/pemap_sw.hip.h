@@ -379,29 +379,36 @@ __device__ __forceinline__ void pm_sw_forward (const PmSwTask & tk, int bis, int
 
 // ============================================================================================================
 // K3a: the gapless rule.  For most reads the affine-gap DP only confirms what a comparison along the window's
-// nn - mm + 1 diagonals already shows, and that case can be decided exactly without it.  Scores (pemapper.c:2006-2095):
-// match +1, mismatch -1/3, gap open 2, gap extend 1/36; the read is aligned globally, so a gapless alignment on diagonal d
-// with x mismatches scores (mm - x) - x/3 and ANY alignment with a gap scores at most mm - 2 (at most mm matches, at least
-// one gap open).  Hence, if some diagonal has x <= 1 (score >= mm - 4/3 > mm - 2):
-//   * every cell of the last read column that can hold the best score (pemapper.c:1717-1742) is the end of a diagonal
-//     with x <= 1, in plane 0; the DP's value there is the left fold  S0 = S0 + bonus  from S0[.][0] = 0 (2062-2081)
-//     along that diagonal, because every other path into a cell of such a diagonal carries a gap and is smaller by more
-//     than 2/3 -- the fold is reproduced here addition by addition, so the double is the DP's to the last bit;
-//   * the winner is the first of them in ascending row order under strict '>' (1724-1741);
-//   * the traceback (1799-1831) never leaves plane 0: at every cell of the winning diagonal S0 >= j - 4/3 while S1 and
-//     S2 are <= j - 2, so `S1 > S0` and `S2 > max(S0, S1)` are false all the way to column 0: mm diagonal steps.
-// Such a problem gets its score, start cell (plane 0, row d + mm) and the PM_GAPLESS flag; the walk kernel then emits
-// mm diagonal steps without a direction slab.  Everything else is appended to tasks_dp for pm_sw_kernel.  With 1 %
-// substitutions 56 % of the 150-base reads have at most one.  One half-wave per problem, lane = diagonal; wrong diagonals
-// drop out after a few bases.
+// nn - mm + 1 diagonals already shows, and those cases can be decided exactly without it.  Scores (pemapper.c:2006-2095):
+// match +1, mismatch -1/3, gap open 2, gap extend 1/36; the read is aligned globally.  A gapless alignment on diagonal d
+// with x mismatches scores mm - 4x/3.  An alignment with gaps scores at most: mm - 4 with two or more gaps; mm - 3 with one
+// insertion (a read base is lost as well); mm - 2 - (b-1)/36 - 4y/3 with one deletion of b reference bases and y mismatches.
+// Let xmin be the smallest x over the diagonals.
+//   (1) xmin <= 1.  mm - 4/3 > mm - 2: only diagonals with x <= 1 can hold the best cell of the last read column
+//       (pemapper.c:1717-1742), in plane 0, and the DP's value there is the left fold  S0 = S0 + bonus  from S0[.][0] = 0
+//       (2062-2081) along the diagonal: any other path into a cell of such a diagonal carries a gap (<= c - 2 at column c)
+//       against the fold's >= c - 4/3.  The traceback (1799-1831) stays in plane 0: on the diagonal S0 >= c - 4/3 while
+//       S1 <= c - 2 and S2 <= c - 3, so `S1 > S0` and `S2 > max (S0, S1)` are false down to column 0: mm diagonal steps.
+//   (2) xmin = 2.  mm - 8/3 is beaten exactly by the alignments with ONE deletion and NO mismatch (mm - 2 ... mm - 2.56):
+//       a prefix [0, p) perfect on a diagonal d1 and the suffix [p, mm) perfect on a later one d2.  With pre[d] the
+//       length of d's perfect prefix and suf[d] of its perfect suffix, one exists iff pre[d1] + suf[d2] >= mm for some
+//       d1 < d2.  If none does, (1)'s statements hold for the diagonals with x = 2: a path with a gap reaches a cell of
+//       such a diagonal with more than the fold's c - 8/3 only as (perfect prefix elsewhere, deletion, perfect stretch
+//       here past both mismatches), which continued to the end IS such an alignment; the same for S1 on the diagonal.
+// In both cases the winner is the first maximum in ascending row order under strict '>' (1724-1741) among the folds,
+// which are reproduced addition by addition, so the score is the DP's double to the last bit.  Such a problem gets its
+// score, start cell (plane 0, row d + mm) and the PM_GAPLESS flag; the walk kernel then emits mm diagonal steps without
+// a direction slab.  Everything else is appended to tasks_dp for pm_sw_kernel.  With 1 % substitutions 81 % of the
+// 150-base reads have at most two.  One half-wave per problem, lane = diagonal; wrong diagonals drop out after a few
+// bases.
 // ============================================================================================================
 #define PM_GAPLESS 4            // flag in PmHits::stk beside the plane number
 
 __global__ __launch_bounds__ (256) void pm_gapless_kernel (PmIndex ix, PmBatch b, PmParams prm, PmHits h, const uint32_t * tasks,
-                                                          const unsigned *n_tasks_p, uint32_t * tasks_dp, PmCounters * ctr)
+                                                          const unsigned *n_tasks_p, uint32_t * tasks_dp, PmCounters * ctr, int max_x)
 {
   __shared__ __align__ (8) uint8_t rd[8][320];
-  const int lane = threadIdx.x & 63, l = lane & 31;
+  const int lane = threadIdx.x & 63, l = lane & 31, half = lane & 32;
   const int slot = threadIdx.x >> 5;            // half-wave of the block
   const unsigned n_tasks = *n_tasks_p;
   const int bis = prm.bisulfite;
@@ -427,12 +434,14 @@ __global__ __launch_bounds__ (256) void pm_gapless_kernel (PmIndex ix, PmBatch b
       __builtin_amdgcn_fence (__ATOMIC_SEQ_CST, "wavefront");
       __builtin_amdgcn_wave_barrier ();
       const int ndiag = valid ? nn - mm + 1 : 0;         // diagonals on which the whole read lies inside the window
-      int mism = 2, mpos = 0;
-      if (l < ndiag)
+      const bool mine = l < ndiag;
+      const uint8_t *rp = ref + l;
+      // forward: mismatches up to the third, the positions of the first two
+      int mism = 3, m1 = mm, m2 = mm;
+      if (mine)
         {
           mism = 0;
-          const uint8_t *rp = ref + l;
-          for (int j = 0; j < mm && mism < 2; j += 8)
+          for (int j = 0; j < mm && mism < 3; j += 8)
             {
               const uint64_t q = *(const uint64_t *) &rd[slot][j];
               const uint64_t r = *(const pm_u64_unaligned *) (rp + j);      // (the genome buffer is padded: reading past the window is safe)
@@ -444,28 +453,78 @@ __global__ __launch_bounds__ (256) void pm_gapless_kernel (PmIndex ix, PmBatch b
                 for (int k = 0; k < nb; k++)
                   if (((x >> (8 * k)) & 0xFFull) && !pm_match ((uint8_t) (r >> (8 * k)), (uint8_t) (q >> (8 * k)), bis))
                     {
+                      if (mism == 0)
+                        m1 = j + k;
+                      else if (mism == 1)
+                        m2 = j + k;
                       mism++;
-                      mpos = j + k;
                     }
             }
         }
-      const bool cand = mism <= 1;
-      // the DP's value at the end of a candidate diagonal: the left fold of the bonuses
-      double sc = 0.0;
-      if (cand)
+      const unsigned c1 = (unsigned) (__ballot (mism <= 1) >> half);      // this half-wave's diagonals with x <= 1
+      unsigned cmask = c1;
+      if (c1 == 0u && max_x >= 2)
         {
-          if (mism == 0)
-            sc = (double) mm;
-          else
+          const unsigned c2 = (unsigned) (__ballot (mism == 2) >> half);
+          if (c2 != 0u)
             {
-              // (only the last mismatch position was kept, and there is exactly one)
-              sc = (double) mpos + miss;
-              for (int k = mpos + 1; k < mm; k++)
-                sc = sc + 1.0;
+              // case (2): is there a one-deletion alignment without mismatch?  suf[d] by a scan from the read's end
+              int suf = 0;
+              if (mine)
+                {
+                  suf = mm;
+                  for (int j = (mm - 1) & ~7; j >= 0 && suf == mm; j -= 8)
+                    {
+                      const uint64_t q = *(const uint64_t *) &rd[slot][j];
+                      const uint64_t r = *(const pm_u64_unaligned *) (rp + j);
+                      const int nb = mm - j < 8 ? mm - j : 8;
+                      uint64_t x = q ^ r;
+                      if (nb < 8)
+                        x &= (1ull << (8 * nb)) - 1ull;
+                      if (x != 0ull)
+                        for (int k = nb - 1; k >= 0 && suf == mm; k--)
+                          if (((x >> (8 * k)) & 0xFFull) && !pm_match ((uint8_t) (r >> (8 * k)), (uint8_t) (q >> (8 * k)), bis))
+                            suf = mm - 1 - (j + k);
+                    }
+                }
+              // pmax = the longest perfect prefix among the earlier diagonals
+              const int pre = mine ? m1 : 0;
+              int pmax = pre;
+              for (int s = 1; s < 32; s <<= 1)
+                {
+                  const int v = __shfl_up (pmax, s);
+                  if (l >= s)
+                    pmax = max (pmax, v);
+                }
+              int pbefore = __shfl_up (pmax, 1);
+              if (l == 0)
+                pbefore = 0;
+              const unsigned del = (unsigned) (__ballot (mine && pbefore + suf >= mm) >> half);
+              cmask = del ? 0u : c2;
             }
         }
-      const unsigned long long bal = __ballot (cand);
-      const unsigned cmask = (unsigned) (bal >> (lane & 32));     // this half-wave's candidates
+      // the DP's value at the end of a candidate diagonal: the left fold of the bonuses
+      double sc = 0.0;
+      if ((cmask >> l) & 1u)
+        {
+          int k = 0;
+          if (mism >= 1)
+            {
+              sc = (double) m1 + miss;
+              k = m1 + 1;
+              if (mism == 2)
+                {
+                  for (; k < m2; k++)
+                    sc = sc + 1.0;
+                  sc = sc + miss;
+                  k = m2 + 1;
+                }
+              for (; k < mm; k++)
+                sc = sc + 1.0;
+            }
+          else
+            sc = (double) mm;
+        }
       if (valid)
         {
           if (cmask == 0u)
@@ -483,7 +542,7 @@ __global__ __launch_bounds__ (256) void pm_gapless_kernel (PmIndex ix, PmBatch b
                 {
                   const int dl = __ffs ((int) m) - 1;
                   m &= m - 1u;
-                  const double s = __shfl (sc, (lane & 32) + dl);
+                  const double s = __shfl (sc, half + dl);
                   if (bd < 0 || s > best)
                     {
                       best = s;
