@@ -907,13 +907,14 @@ static void launch_lookup (pemap_dev * d, const RunCtx & c, int slot, PmChunkCtr
   // PEMAP_LOOKUP_V (with replicas): 1 = pm_lookup_rep_kernel (default), 2 = the pipelined pm_lookup_rep2_kernel (measured
   // slower: 68 ms per step at its best point, 3 waves per CU, against 65 -- see DESIGN.md)
   static const int lv = getenv ("PEMAP_LOOKUP_V") ? atoi (getenv ("PEMAP_LOOKUP_V")) : 1;
-  // waves per CU: with the replicas 5 (4 before the gapless rule halved the SW kernel's share: one per SIMD), otherwise 6
-  const int lw = lwenv ? atoi (lwenv) : (c.ix.n_rep == 8) ? (lv == 2 ? 3 : 5) : 6;
+  // waves per CU: 6 (with the replicas 4 was the optimum while the SW kernel scored every problem: one per SIMD; since the
+  // gapless rule took 78 % of its problems away the two streams balance at 6)
+  const int lw = lwenv ? atoi (lwenv) : (c.ix.n_rep == 8) ? (lv == 2 ? 3 : 6) : 6;
   int lgrid = lw * d->n_cus;
   if (lgrid > c.b.n_ends)
     lgrid = c.b.n_ends;
   const char *lbenv = getenv ("PEMAP_LOOKUP_BATCH");     // look-up rounds (x 64 lanes) a wave keeps in flight: 4, 8 or 16
-  const int lb = lbenv ? atoi (lbenv) : 4;
+  const int lb = lbenv ? atoi (lbenv) : (c.ix.n_rep == 8 ? 8 : 4);
   static const int lprio = getenv ("PEMAP_LOOKUP_PRIO") ? atoi (getenv ("PEMAP_LOOKUP_PRIO")) : 0;
 #define PM_LKW(SM, B) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_lookup_wave_kernel < SM, B >), dim3 (lgrid), dim3 (64), 0, st, c.ix, c.b, c.prm, L, lprio)
 #define PM_LKR(SM, B) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_lookup_rep_kernel < SM, B >), dim3 (lgrid), dim3 (64), 0, st, c.ix, c.b, c.prm, L, lprio)
