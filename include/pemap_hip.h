@@ -148,7 +148,7 @@ int pemap_dev_summary (pemap_dev * dev, long *out13);
  * with nibbles, [6] = pileup increments, [7] = insertions logged, [8] = alignments walked back, [9] = winners re-scored,
  * [10] = read-ends with a strand of more than 1024 positions (handled by the monolithic seed kernel),
  * [11] = chunks the run was cut into (= launches of every kernel),
- * [12] = single-hit problems decided without the DP (a diagonal with at most one mismatch; with PEMAP_GAPLESS=0 none):
+ * [12] = problems decided without the DP (a diagonal with at most one mismatch; with PEMAP_GAPLESS=0 none):
  *        [3], [5] count the DP's share only.
  * times_ms[0..7] = seed stage (look-up + vote), SW single-hit (with nibbles), SW multi-hit, select, SW re-score,
  * walk+pileup, look-up kernel alone, vote kernels alone: kernel durations from HIP events on the object's streams,

@@ -758,10 +758,10 @@ static int ensure_work (pemap_dev * d, int n_ends, bool two_sets)
           TRY (alloc_hits (d, d->hits2, n_ends));
           TRY (dev_alloc (d, &d->d_wins2, (size_t) n_ends));
           TRY (dev_alloc (d, &d->d_tasks_s2, (size_t) n_ends * 2));       // second half: the problems left to the DP
-          TRY (dev_alloc (d, &d->d_tasks_m2, nh));
+          TRY (dev_alloc (d, &d->d_tasks_m2, nh * 2));    // second half: the problems left to the DP
         }
       TRY (dev_alloc (d, &d->d_tasks_s, (size_t) n_ends * 2));
-      TRY (dev_alloc (d, &d->d_tasks_m, nh));
+      TRY (dev_alloc (d, &d->d_tasks_m, nh * 2));
       TRY (dev_alloc (d, &d->d_redo, (size_t) n_ends));
       d->cap_ends = n_ends;
     }
@@ -1041,8 +1041,8 @@ template < int W, int LPA > static void launch_chunk (pemap_dev * d, const RunCt
       int ggrid = (n_ends + 7) / 8;
       if (ggrid > d->n_cus * 16)
         ggrid = d->n_cus * 16;
-      hipLaunchKernelGGL (pm_gapless_kernel, dim3 (ggrid), dim3 (256), 0, d->stream, c.ix, c.b, c.prm, H, tasks_s, &ctr->n_tasks_s, tasks_dp, ctr,
-                          pm_gapless_max_x ());
+      hipLaunchKernelGGL (pm_gapless_kernel, dim3 (ggrid), dim3 (256), 0, d->stream, c.ix, c.b, c.prm, H, tasks_s, &ctr->n_tasks_s, tasks_dp,
+                          &ctr->n_tasks_dp, pm_gapless_max_x ());
       hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, LPA, true >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, H,
                           tasks_dp, &ctr->n_tasks_dp, ctr, dirbuf, dump_slab, c.tstride, c.L, swprio, &ctr->sw_next[0]);
     }
@@ -1050,8 +1050,19 @@ template < int W, int LPA > static void launch_chunk (pemap_dev * d, const RunCt
     hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, LPA, true >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, H,
                         tasks_s, &ctr->n_tasks_s, ctr, dirbuf, dump_slab, c.tstride, c.L, swprio, &ctr->sw_next[0]);
   hipEventRecord (ev[4], d->stream);
-  hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, LPA, false >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, H,
-                      tasks_m, &ctr->n_tasks_m, ctr, dirbuf, dump_slab, c.tstride, c.L, swprio, &ctr->sw_next[1]);
+  if (pm_gapless_on ())
+    {
+      // the same rule on the problems of the multi-hit ends (scores only; a winner it decided is not scored again);
+      // sw_next[3] counts what is left to the DP
+      uint32_t *tasks_mdp = tasks_m + (size_t) d->cap_ends * PM_MAX_HITS;
+      hipLaunchKernelGGL (pm_gapless_kernel, dim3 (d->n_cus * 16), dim3 (256), 0, d->stream, c.ix, c.b, c.prm, H, tasks_m, &ctr->n_tasks_m, tasks_mdp,
+                          &ctr->sw_next[3], pm_gapless_max_x ());
+      hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, LPA, false >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, H,
+                          tasks_mdp, &ctr->sw_next[3], ctr, dirbuf, dump_slab, c.tstride, c.L, swprio, &ctr->sw_next[1]);
+    }
+  else
+    hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, LPA, false >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, H,
+                        tasks_m, &ctr->n_tasks_m, ctr, dirbuf, dump_slab, c.tstride, c.L, swprio, &ctr->sw_next[1]);
   hipEventRecord (ev[5], d->stream);
   hipLaunchKernelGGL (pm_select_kernel, dim3 ((c.b.n + 255) / 256), dim3 (256), 0, d->stream, c.b, c.prm, H, d->d_redo, wins, ctr,
                       m1, m2, mt);
@@ -1110,6 +1121,7 @@ static int absorb_run (pemap_dev * d)
       t.n_tasks_s += c.n_tasks_s;
       t.n_tasks_m += c.n_tasks_m;
       t.n_tasks_dp += pm_gapless_on () ? c.n_tasks_dp : c.n_tasks_s;
+      t.sw_next[3] += pm_gapless_on () ? c.sw_next[3] : c.n_tasks_m;
       t.n_slots += c.n_slots;
       t.n_redo += c.n_redo;
       t.n_wins += c.n_wins;
@@ -1555,7 +1567,7 @@ extern "C" int pemap_dev_run_stats (pemap_dev * d, uint64_t * s, float *t)
       s[9] = c.n_redo;
       s[10] = d->last_big;
       s[11] = (uint64_t) d->run_chunks;
-      s[12] = (uint64_t) c.n_tasks_s - c.n_tasks_dp;
+      s[12] = ((uint64_t) c.n_tasks_s - c.n_tasks_dp) + ((uint64_t) c.n_tasks_m - c.sw_next[3]);
     }
   if (t)
     memcpy (t, d->last_ms, sizeof (d->last_ms));

@@ -405,7 +405,7 @@ __device__ __forceinline__ void pm_sw_forward (const PmSwTask & tk, int bis, int
 #define PM_GAPLESS 4            // flag in PmHits::stk beside the plane number
 
 __global__ __launch_bounds__ (256) void pm_gapless_kernel (PmIndex ix, PmBatch b, PmParams prm, PmHits h, const uint32_t * tasks,
-                                                          const unsigned *n_tasks_p, uint32_t * tasks_dp, PmCounters * ctr, int max_x)
+                                                          const unsigned *n_tasks_p, uint32_t * tasks_dp, unsigned *n_tasks_dp, int max_x)
 {
   __shared__ __align__ (8) uint8_t rd[8][320];
   const int lane = threadIdx.x & 63, l = lane & 31, half = lane & 32;
@@ -530,7 +530,7 @@ __global__ __launch_bounds__ (256) void pm_gapless_kernel (PmIndex ix, PmBatch b
           if (cmask == 0u)
             {
               if (l == 0)
-                tasks_dp[atomicAdd (&ctr->n_tasks_dp, 1u)] = (uint32_t) o;
+                tasks_dp[atomicAdd (n_tasks_dp, 1u)] = (uint32_t) o;
             }
           else
             {
@@ -585,6 +585,10 @@ template < int W, int PM_LPA, bool DIRS > __global__ __launch_bounds__ (64, PM_W
   const int lane = threadIdx.x;
   const int q = lane / PM_LPA;
   const unsigned n_tasks = *n_tasks_p;
+  // (a wave without a first task group leaves before it touches the work counter: the launches for the multi-hit ends and
+  // the re-scored winners are often all but empty, and 4096 waves adding to one counter cost 0.2 ms each time)
+  if (blockIdx.x * (unsigned) TPW >= n_tasks)
+    return;
   const size_t slab_dwords = (size_t) PM_LPA * tstride * PmSwGeom < W >::DW;
   // task groups are handed out through a counter, fetched one group ahead (persistent waves start at different times)
   unsigned base_next = gridDim.x * (unsigned) TPW
@@ -812,9 +816,10 @@ __global__ void pm_select_kernel (PmBatch b, PmParams prm, PmHits h, uint32_t * 
         r2 = r;
       else
         r1 = r;
-      if (h.slot[e] < 0)
+      if (h.slot[e] < 0 && !(h.stk[o] & PM_GAPLESS))
         {
-          // winner of a multi-hit end: give it a slab and have it scored again with direction nibbles
+          // winner of a multi-hit end (not decided by the gapless rule, whose traceback needs no nibbles): give it a slab
+          // and have it scored again with direction nibbles
           h.slot[e] = (int) atomicAdd (&ctr->n_slots, 1u);
           redo[atomicAdd (&ctr->n_redo, 1u)] = (uint32_t) o;
         }
