@@ -256,7 +256,7 @@ def pmc_traffic(kernel, gsize, B, L):
     streams)."""
     if not (gsize == 3100000000 and B == 1000000 and L == 150):
         return None, None
-    for name in ("r01_bench_pmc_replicas.json", "r01_bench_pmc_final.json"):
+    for name in ("r01_bench_pmc_gapless.json", "r01_bench_pmc_replicas.json", "r01_bench_pmc_final.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             pm = json.load(open(path))

@@ -237,3 +237,45 @@ print("alias ok")
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))]))
     r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert r.returncode == 0 and b"alias ok" in r.stdout, r.stdout[-2000:]
+
+
+def test_gapless_rule_counts_and_can_be_switched_off(dev):
+    """the gapless rule (pm_gapless_kernel) decides most alignments of the golden read set without the DP; its results are
+    already pinned by the golden tests above -- here: it is in use, and the full-DP path (PEMAP_GAPLESS=0, a process of
+    its own because the setting is read once) still reproduces the reference's outputs, hit scores included"""
+    import os
+    import subprocess
+    import sys
+    r1, l1, r2, l2 = fixtures.reads("r150")
+    dev.set_lookup_replicas(8)
+    dev.set_params(paired=True, min_dist=0, max_dist=500, min_align=0.85)
+    dev.reset_pileup()
+    dev.map_batch(r1, l1, r2, l2)
+    stats, _ = dev.run_stats()
+    assert stats["gapless"] > stats["sw_score"] // 3, stats
+    assert stats["gapless"] + (stats["sw_dirs"] - stats["redo"]) <= stats["sw_score"]
+    code = r'''
+import numpy as np, fixtures, oracle_py
+from pecaller_amd import PemapDev
+ix = fixtures.index()
+dev = PemapDev(0)
+dev.build_index(ix["genome"], ix["contig_len"])
+for name in ("r150", "r100"):
+    s = fixtures.SETS[name]
+    r1, l1, r2, l2 = fixtures.reads(name)
+    dev.set_params(paired=s["paired"], min_dist=0, max_dist=500, min_align=0.85)
+    dev.reset_pileup()
+    m1, m2, mt = dev.map_batch(r1, l1, r2, l2)
+    assert dev.run_stats()[0]["gapless"] == 0
+    assert np.array_equal(m1, fixtures.golden_m(name, 1))
+    if s["paired"]:
+        assert np.array_equal(m2, fixtures.golden_m(name, 2))
+    counts, ins = dev.fetch_pileup()
+    fixtures.check_pileup_against_golden(name, counts)
+dev.close()
+print("full dp ok")
+'''
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, PEMAP_GAPLESS="0", PYTHONPATH=os.pathsep.join([os.path.dirname(here), here]))
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert r.returncode == 0 and b"full dp ok" in r.stdout, r.stdout[-2000:]
