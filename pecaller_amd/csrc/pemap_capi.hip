@@ -690,13 +690,39 @@ static int ensure_reads (pemap_dev * d, int n, int stride, int paired)
 // lanes * W >= L.  8 lanes by default (13 / 19 / 26 / 32 / 38 columns).  PEMAP_SW_LANES=16 gives reads over 152 bases 16 lanes
 // x 13 / 16 / 19 columns instead (three waves per SIMD instead of two or one, more steps per cell): measured equal on
 // 2 x 250 bases (112 ms of SW per 1 M pairs either way), so it stays an option.
+// PEMAP_GAPLESS=0: every problem goes through the DP (the rule of pm_gapless_kernel off); 1: its first case only (diagonals
+// with at most one mismatch); default 2: both cases
+static int pm_gapless_max_x ()
+{
+  static const int g = getenv ("PEMAP_GAPLESS") ? atoi (getenv ("PEMAP_GAPLESS")) : 2;
+  return g;
+}
+
+static bool pm_gapless_on ()
+{
+  return pm_gapless_max_x () != 0;
+}
+
 static void pick_geom (int L, int *lanes, int *w)
 {
-  static const int want16 = getenv ("PEMAP_SW_LANES") && atoi (getenv ("PEMAP_SW_LANES")) == 16;
+  // PEMAP_SW_LANES unset: 16 lanes for 105..160 bases when the gapless rule leaves the DP few problems per launch (measured
+  // 44.8 ms per step against 46.2), 8 otherwise
+  static const int lanes_env = getenv ("PEMAP_SW_LANES") ? atoi (getenv ("PEMAP_SW_LANES")) : (pm_gapless_on () ? -16 : 0);
+  static const int want16 = lanes_env == 16 || lanes_env == -16;
+  if (lanes_env == -16 && !(L > 8 * 13 && L <= 16 * 10))
+    {
+      // the default only changes the 105..160 range
+      if (L <= 8 * 13) { *lanes = 8; *w = 13; }
+      else { *lanes = 8; *w = L <= 8 * 26 ? 26 : L <= 8 * 32 ? 32 : 38; }
+      return;
+    }
   static const int want12 = getenv ("PEMAP_SW_LANES") && atoi (getenv ("PEMAP_SW_LANES")) == 12;
   // experiment: 12 lanes x 13 columns, 5 alignments per wave, 128 VGPRs -> 4 waves per SIMD; measured 33 ms of SW per step
   // alone against 27.5 for 8 x 19 and much worse beside the look-up waves (27 spilled VGPRs): not the default
   if (want12 && L > 8 * 13 && L <= 12 * 13) { *lanes = 12; *w = 13; return; }
+  // 16 lanes x 10 columns for 105..160 bases: 4 alignments per wave, half the steps' work per wave -- for the few problems per
+  // launch the gapless rule leaves (4.4 K wave-loads of the 8 x 19 form against ~3 K resident waves: two or three rounds)
+  if (want16 && L > 8 * 13 && L <= 16 * 10) { *lanes = 16; *w = 10; return; }
   if (L <= 8 * 13) { *lanes = 8; *w = 13; }
   else if (L <= 8 * 19) { *lanes = 8; *w = 19; }
   else if (!want16) { *lanes = 8; *w = L <= 8 * 26 ? 26 : L <= 8 * 32 ? 32 : 38; }
@@ -1003,20 +1029,6 @@ static void launch_vote (pemap_dev * d, const RunCtx & c, bool split, int slot, 
     }
   hipLaunchKernelGGL (pm_emit_kernel, dim3 ((n_ends + 255) / 256), dim3 (256), 0, st, c.ix, c.b, H, tasks_s, tasks_m, ctr);
   hipEventRecord (ev[3], st);
-}
-
-// PEMAP_GAPLESS=0: every single-hit problem goes through the DP (the rule of pm_gapless_kernel off)
-static bool pm_gapless_on ()
-{
-  static const int g = getenv ("PEMAP_GAPLESS") ? atoi (getenv ("PEMAP_GAPLESS")) : 1;
-  return g != 0;
-}
-
-// PEMAP_GAPLESS=1 restricts the rule to its first case (diagonals with at most one mismatch)
-static int pm_gapless_max_x ()
-{
-  static const int g = getenv ("PEMAP_GAPLESS") ? atoi (getenv ("PEMAP_GAPLESS")) : 2;
-  return g;
 }
 
 // ---- the ALU stream's work for one chunk: (the seed stage unless it ran on the memory stream,) SW, selection, traceback.
@@ -1392,6 +1404,7 @@ static int run_slice (pemap_dev * d, int first, int n, int sync)
         else
           switch (w)
             {
+            case 10: PM_CH (10, 16); break;
             case 13: PM_CH (13, 16); break;
             case 16: PM_CH (16, 16); break;
             default: PM_CH (19, 16); break;
