@@ -825,8 +825,11 @@ static int ensure_work (pemap_dev * d, int n_ends, bool two_sets)
           TRY (dev_alloc (d, &d->d_nsteps2, (size_t) n_ends));
         }
     }
-  // insertion log: 64 bytes per read-end of a chunk is ample for real data; overflow is reported as an error
+  // insertion log: 64 bytes per read-end of a chunk is ample for real data, and at least 512 MB so that runs queued back to
+  // back (the log is drained when a run is absorbed) do not fill it; overflow is reported as an error
   size_t want = (size_t) n_ends * 64 + (1u << 20);
+  if (want < ((size_t) 512 << 20))
+    want = (size_t) 512 << 20;
   if (want > 0xF0000000ull)
     want = 0xF0000000ull;
   if (want > d->ins_cap)

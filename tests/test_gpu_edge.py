@@ -99,3 +99,112 @@ def test_caller_argument_errors():
     with pytest.raises(PemapError):
         dev.call_sites(np.zeros((4, 8, 6), np.uint16), np.zeros(4, np.uint8), theta=0.9)   # pecaller.c:305-309
     dev.close()
+
+
+def _adversarial_genome(seed):
+    """10 contigs of unique sequence with tandem repeats of periods 1..12 and near-duplicated blocks planted in them: the places
+    where several diagonals of an SW window match equally well, or a deletion competes with mismatches"""
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    contigs = []
+    for c in range(10):
+        g = acgt[rng.integers(0, 4, 60000)].copy()
+        pos = 2000
+        for period in range(1, 13):
+            unit = acgt[rng.integers(0, 4, period)]
+            n = int(rng.integers(60, 400))
+            rep = np.tile(unit, n // period + 1)[:n].copy()
+            m = rng.random(n) < 0.02              # slightly impure repeats
+            rep[m] = acgt[rng.integers(0, 4, int(m.sum()))]
+            g[pos:pos + n] = rep
+            pos += n + int(rng.integers(600, 3000))
+        # a block copied 30..40 bases downstream of itself with a few changes (short-range near-duplicate)
+        for _ in range(6):
+            s = int(rng.integers(pos, len(g) - 2000))
+            blk = g[s:s + 120].copy()
+            d = int(rng.integers(1, 22))
+            g[s + 120 + d:s + 240 + d] = blk
+        contigs.append(g)
+    return contigs
+
+
+def _adversarial_reads(contigs, seed, n, L):
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    r1, r2 = [], []
+    for k in range(n):
+        c = contigs[int(rng.integers(0, len(contigs)))]
+        fl = int(rng.integers(L + 20, L + 380))
+        # half of the fragments start inside or next to a planted repeat (the first 40 % of a contig holds them)
+        s = int(rng.integers(1500, int(len(c) * 0.4))) if k % 2 == 0 else int(rng.integers(0, len(c) - fl - 30))
+        ends = []
+        for which in (0, 1):
+            lo = s if which == 0 else s + fl - L
+            kind = int(rng.integers(0, 8))
+            if kind == 5:      # the read skips b reference bases at p: the one-deletion alignment of the rule's second case
+                b = int(rng.integers(1, 22))
+                p = int(rng.integers(20, L - 20))
+                x = np.concatenate([c[lo:lo + p], c[lo + p + b:lo + L + b]]).copy()
+            elif kind == 6:    # an inserted stretch
+                a = int(rng.integers(1, 6))
+                p = int(rng.integers(20, L - 20))
+                x = np.concatenate([c[lo:lo + p], acgt[rng.integers(0, 4, a)], c[lo + p:lo + L - a]]).copy()
+            else:
+                x = c[lo:lo + L].copy()
+            nsub = (0, 1, 2, 2, 3, 1, 0, 4)[kind]      # exact numbers of substitutions: the rule's case boundaries
+            for q in rng.choice(L, size=nsub, replace=False):
+                x[q] = acgt[(int(np.nonzero(acgt == x[q])[0][0]) + int(rng.integers(1, 4))) % 4]
+            if kind == 7 and rng.random() < 0.3:
+                x[int(rng.integers(0, L))] = ord("N")
+            if which == 1:
+                x = COMP[x][::-1].copy()
+            ends.append(x)
+        a, b = ends
+        if rng.random() < 0.5:
+            a, b = b, a
+        r1.append(a.tobytes())
+        r2.append(b.tobytes())
+    return refio.pack_reads(r1) + refio.pack_reads(r2)
+
+
+@pytest.mark.parametrize("L", [150, 100])
+def test_gapless_rule_on_repeats_and_competing_gaps(L):
+    """The gapless rule (pm_gapless_kernel) against the oracle's full DP where it is most exposed: tandem repeats (several
+    diagonals perfect or tied), reads with exactly 0 / 1 / 2 / 3 substitutions, reads that skip 1..21 reference bases (the
+    one-deletion alignment that beats two mismatches), insertions.  Coordinates, classes, pileup, insertions, and per hit
+    the fp64 score bits and the start cell."""
+    from pecaller_amd import PemapDev
+    contigs = _adversarial_genome(77)
+    mers, ukmer, ustart, cs = refio.kmer_index(contigs)
+    ix = dict(mers=mers, ukmer=ukmer, ustart=ustart, genome=np.concatenate(contigs), contig_starts=cs,
+              contig_len=np.array([len(c) for c in contigs], dtype=np.uint32))
+    n = 6000
+    b1, l1, b2, l2 = _adversarial_reads(contigs, 5 + L, n, L)
+    dev = PemapDev(0)
+    dev.build_index(ix["genome"], ix["contig_len"])
+    dev.set_params(paired=True, min_dist=0, max_dist=500, min_align=0.85)
+    m1, m2, mt = dev.map_batch(b1, l1, b2, l2)
+    stats, _ = dev.run_stats()
+    dbg = dev.debug_hits(2 * n)
+    counts, ins = dev.fetch_pileup()
+    o = oracle_py.Oracle(ix, paired=True, min_dist=0, max_dist=500, min_align=0.85)
+    om1, om2, omt, d1, d2 = o.map_batch(b1, l1, b2, l2, debug=True, threads=8)
+    assert np.array_equal(m1, om1), np.nonzero(m1 != om1)[0][:10]
+    assert np.array_equal(m2, om2), np.nonzero(m2 != om2)[0][:10]
+    assert np.array_equal(mt, omt)
+    assert np.array_equal(counts, o.counts())
+    assert sorted(ins) == sorted(o.insertions())
+    multi = 0
+    for which, od in ((0, d1), (1, d2)):
+        nh = dbg["n_hits"][which::2]
+        assert np.array_equal(nh, od["n_hits"])
+        for i in np.nonzero(nh)[0]:
+            k = nh[i]
+            e = 2 * i + which
+            assert np.array_equal(dbg["score"][e, :k].view(np.uint64), od["score"][i, :k].view(np.uint64)), (e, k)
+            assert np.array_equal(dbg["start_k"][e, :k], od["start"][i, :k, 0]), e
+            assert np.array_equal(dbg["start_i"][e, :k], od["start"][i, :k, 1]), e
+            multi += k > 1
+    # the rule decided a good share and left a good share to the DP; multi-hit ends (repeats) occurred
+    assert stats["gapless"] > n // 2 and stats["sw_dirs"] > n // 4 and multi > 50, (stats, multi)
+    dev.close()
