@@ -215,6 +215,8 @@ def main():
             # MI355X), or against the reference's table
             kname = ("pm_lookup_rep2_kernel" if os.environ.get("PEMAP_LOOKUP_V", "1") == "2" else "pm_lookup_rep_kernel") if n_rep \
                 else "pm_lookup_wave_kernel"
+        elif dom == "vote" and os.environ.get("PEMAP_VOTE_WAVES", "1024") != "0":
+            kname = "pm_vote_wave_kernel"
         elif dom.startswith("sw_"):
             kname = "pm_sw_kernel"
         traffic, tsrc = pmc_traffic(kname, gs, B, L)
@@ -227,6 +229,14 @@ def main():
                 "bytes_per_end_path": round(total_b, 1), "P_per_end": round(P_e, 2), "H_per_end": round(H_e, 3),
                 "path_GBs": round(total_b * ends / a.steps / (dt / a.steps) / 1e9, 2),
                 "cells_per_s": round((agg["cells_score"] + agg["cells_dirs"]) / dt, 0)}
+        if dom != "lookup" and split:
+            # the path's HBM-heavy kernel beside the dominant one: same accounting
+            lk_name = ("pm_lookup_rep2_kernel" if os.environ.get("PEMAP_LOOKUP_V", "1") == "2" else "pm_lookup_rep_kernel") if n_rep else "pm_lookup_wave_kernel"
+            lk_ms = avg_ms["lookup"] / launches
+            lk_traffic, lk_src = pmc_traffic(lk_name, gs, B, L)
+            roof["lookup_kernel"] = {"kernel": lk_name, "avg_launch_ms": round(lk_ms, 3), "achieved": round(alg_bytes / (lk_ms * 1e-3) / 1e9, 2),
+                                     "frac": round(alg_bytes / (lk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": lk_traffic, "traffic_source": lk_src,
+                                     "kernel_algorithmic_bytes_per_launch": round(per_end["lookup"] * (ends / a.steps) / launches)}
         cpu = None
         if world == 1 and not a.no_cpu:
             cpu = cpu_baseline(dev, a, B)
@@ -258,7 +268,7 @@ def pmc_traffic(kernel, gsize, B, L):
     streams)."""
     if not (gsize == 3100000000 and B == 1000000 and L == 150):
         return None, None
-    for name in ("r01_bench_pmc_gapless.json", "r01_bench_pmc_replicas.json", "r01_bench_pmc_final.json"):
+    for name in ("r01_bench_pmc_final3.json", "r01_bench_pmc_v12.json", "r01_bench_pmc_replicas.json", "r01_bench_pmc_final.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             pm = json.load(open(path))

@@ -151,8 +151,9 @@ int pemap_dev_summary (pemap_dev * dev, long *out13);
  * [12] = problems decided without the DP (a diagonal with at most one mismatch; with PEMAP_GAPLESS=0 none):
  *        [3], [5] count the DP's share only.
  * times_ms[0..7] = seed stage (look-up + vote), SW single-hit (with nibbles), SW multi-hit, select, SW re-score,
- * walk+pileup, look-up kernel alone, vote kernels alone: kernel durations from HIP events on the object's streams,
- * summed over the run's chunks (with the two-stream pipeline they overlap in time, so their sum exceeds the wall time). */
+ * walk+pileup, look-up kernel alone, vote kernel alone (the list-mode remainder of the big read-ends and the emit kernel count
+ * towards [0] only): kernel durations from HIP events on the object's streams, summed over the run's chunks (the streams of
+ * the pipeline overlap in time, so their sum exceeds the wall time). */
 int pemap_dev_run_stats (pemap_dev * dev, uint64_t * stats13, float *times_ms8);
 
 /* Debug/parity taps: per read-end hit lists and per-hit SW results of the last run.

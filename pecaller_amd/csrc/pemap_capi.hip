@@ -891,6 +891,10 @@ extern "C" int pemap_dev_stage_reads (pemap_dev * d, const char *reads1, const i
   return 0;
 }
 
+__global__ void pm_nop_kernel ()
+{
+}
+
 struct RunCtx
 {
   PmIndex ix;
@@ -910,7 +914,7 @@ struct PmChunkCtr
 };
 
 #define PM_MAX_CHUNKS 256
-#define PM_NEV 10               // events per chunk: lookup start/end, then the ALU stream's kernel boundaries
+#define PM_NEV 12               // events per chunk: lookup start/end, the vote kernel's end, the seed stage's end, then the ALU stream's kernel boundaries
 
 static int seg_template (int L)
 {
@@ -926,6 +930,9 @@ static void launch_lookup (pemap_dev * d, const RunCtx & c, int slot, PmChunkCtr
   L.positions = &cc->positions;
   L.next_end = &cc->next_end;
   hipStream_t st = d->serial_split ? d->stream : d->stream2;
+  // (an event recorded straight after a stream wait is stamped when the wait is queued, not when it is satisfied: the empty
+  // kernel makes the stamp the moment the look-up kernel can start, so that ev[0]..ev[1] is the kernel's own duration)
+  hipLaunchKernelGGL (pm_nop_kernel, dim3 (1), dim3 (1), 0, st);
   hipEventRecord (ev[0], st);
   // occupancy knob of the look-up kernel (diagnostic): dynamic LDS padding in KB limits its workgroups per CU, so that
   // the latency-bound vote kernel running beside it keeps its wave slots
@@ -976,6 +983,7 @@ static void launch_vote (pemap_dev * d, const RunCtx & c, bool split, int slot, 
   PmCounters *ctr = &cc->c;
   const char *pl = getenv ("PEMAP_SEED_PHASE");      // timing probe only: results are meaningless when set
   const int phase_limit = pl ? atoi (pl) : 0;
+  hipLaunchKernelGGL (pm_nop_kernel, dim3 (1), dim3 (1), 0, st);
   hipEventRecord (ev[2], st);
   if (split)
     {
@@ -1004,11 +1012,12 @@ static void launch_vote (pemap_dev * d, const RunCtx & c, bool split, int slot, 
                                          c.prm, H, tasks_s, tasks_m, ctr, d->d_seed_scratch, 0, L.big_list, L.n_big)
       switch (seg_template (c.L))
         {
-        case 7: PM_VT (7); PM_SEEDL (7); break;
-        case 10: PM_VT (10); PM_SEEDL (10); break;
-        case 13: PM_VT (13); PM_SEEDL (13); break;
-        case 16: PM_VT (16); PM_SEEDL (16); break;
-        default: PM_VT (19); PM_SEEDL (19); break;
+        // ev[2]..ev[3] = the vote kernel alone; the list-mode remainder and the emit kernel end at ev[10]
+        case 7: PM_VT (7); hipEventRecord (ev[3], st); PM_SEEDL (7); break;
+        case 10: PM_VT (10); hipEventRecord (ev[3], st); PM_SEEDL (10); break;
+        case 13: PM_VT (13); hipEventRecord (ev[3], st); PM_SEEDL (13); break;
+        case 16: PM_VT (16); hipEventRecord (ev[3], st); PM_SEEDL (16); break;
+        default: PM_VT (19); hipEventRecord (ev[3], st); PM_SEEDL (19); break;
         }
 #undef PM_VT
 #undef PM_SEEDL
@@ -1031,7 +1040,9 @@ static void launch_vote (pemap_dev * d, const RunCtx & c, bool split, int slot, 
 #undef PM_SEED
     }
   hipLaunchKernelGGL (pm_emit_kernel, dim3 ((n_ends + 255) / 256), dim3 (256), 0, st, c.ix, c.b, H, tasks_s, tasks_m, ctr);
-  hipEventRecord (ev[3], st);
+  if (!split)
+    hipEventRecord (ev[3], st);
+  hipEventRecord (ev[10], st);
 }
 
 // ---- the ALU stream's work for one chunk: (the seed stage unless it ran on the memory stream,) SW, selection, traceback.
@@ -1153,13 +1164,12 @@ static int absorb_run (pemap_dev * d)
           d->last_ms[0] += ms;
           d->last_ms[6] += ms;
         }
+      if (hipEventElapsedTime (&ms, ev[2], ev[10]) == hipSuccess)
+        d->last_ms[0] += ms;
       if (hipEventElapsedTime (&ms, ev[2], ev[3]) == hipSuccess)
-        {
-          d->last_ms[0] += ms;
-          d->last_ms[7] += ms;
-        }
+        d->last_ms[7] += ms;
       for (int i = 1; i < 6; i++)
-        if (hipEventElapsedTime (&ms, ev[2 + i], (i == 4) ? ev[9] : ev[3 + i]) == hipSuccess)
+        if (hipEventElapsedTime (&ms, (i == 1) ? ev[10] : ev[2 + i], (i == 4) ? ev[9] : ev[3 + i]) == hipSuccess)
           d->last_ms[i] += ms;
     }
   if (d->last_cur.ins_overflow)
@@ -1255,7 +1265,12 @@ static int run_slice (pemap_dev * d, int first, int n, int sync)
     d->vote_stream = (d->vote_on_mem && vm == 2) ? 3 : 2; }
   if (d->vote_on_mem && d->vote_stream == 3 && !d->stream3)
     {
-      HIPCHK (d, hipStreamCreateWithFlags (&d->stream3, hipStreamNonBlocking));
+      // PEMAP_VOTE_STREAM_PRIO: queue priority of the vote's stream (-1 high, 0 normal, 1 low)
+      const char *vp = getenv ("PEMAP_VOTE_STREAM_PRIO");
+      if (vp)
+        HIPCHK (d, hipStreamCreateWithPriority (&d->stream3, hipStreamNonBlocking, atoi (vp)));
+      else
+        HIPCHK (d, hipStreamCreateWithFlags (&d->stream3, hipStreamNonBlocking));
       for (int i = 0; i < 2; i++)
         HIPCHK (d, hipEventCreateWithFlags (&d->ev_lookup_done[i], hipEventDisableTiming));
     }
