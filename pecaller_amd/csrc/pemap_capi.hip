@@ -387,6 +387,20 @@ static int build_replicas (pemap_dev * d)
       // and hipMemGetInfo lags too), hence the retries.
       const size_t reserve = (size_t) 48 << 30;
       bool ok = false;
+      {
+        // the common case, a fresh process: the free-memory figure is accurate, no probe needed (a 48 GiB allocation costs ~1 s)
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo (&fr, &tot) == hipSuccess && fr >= rep_bytes + reserve)
+          {
+            if (hipMalloc ((void **) &d->d_rep, rep_bytes) == hipSuccess)
+              ok = true;
+            else
+              {
+                (void) hipGetLastError ();
+                d->d_rep = nullptr;
+              }
+          }
+      }
       for (int attempt = 0; attempt < 10 && !ok; attempt++)
         {
           void *probe = nullptr;
