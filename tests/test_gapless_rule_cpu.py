@@ -1,0 +1,109 @@
+"""The gapless rule of pm_gapless_kernel (pecaller_amd/csrc/pemap_sw.hip.h, K3a in DESIGN.md), restated in Python and checked
+against the oracle's full DP (oracle/pemap_oracle.c: smith_waterman_align, pemapper.c:1694-1748) on windows built to stress it:
+short reads over a two-letter alphabet (several diagonals perfect or tied, repeats), exact numbers of substitutions around the
+rule's case boundaries, reads that skip reference bases (the one-deletion alignment that must defer the decision to the DP),
+insertions, N on either side.  Whenever the rule decides, the DP must give the same double, the same start cell, and planes
+in which the traceback never leaves plane 0 along the winning diagonal.  CPU only: this pins the RULE; the kernel that
+implements it is pinned against goldens and the oracle in the GPU tests."""
+import numpy as np
+import oracle_py
+
+MISS = np.frombuffer(np.array([0xBFD5555555555555], dtype=np.uint64).tobytes(), dtype=np.float64)[0]   # the reference's -1/3
+
+
+def match(r, q):
+    """init_bonus_matrices as a predicate (pemapper.c:2006-2035), the form pm_match takes without bisulfite"""
+    m = (r == q) | (q == ord("N")) | (q == ord("n"))
+    m |= (r == ord("N")) & (q >= ord("N"))
+    m |= (r == ord("n")) & (q >= ord("n"))
+    return m
+
+
+def gapless_rule(ref, read, max_x=2):
+    """-> None (left to the DP) or (score, row of the start cell)"""
+    nn, mm = len(ref), len(read)
+    nd = nn - mm + 1
+    if nd <= 0:
+        return None
+    idx = np.arange(nd)[:, None] + np.arange(mm)[None, :]
+    eq = match(ref[idx], read[None, :])
+    x = (~eq).sum(axis=1)
+    if (x <= 1).any():
+        cand = np.nonzero(x <= 1)[0]
+    elif max_x >= 2 and (x == 2).any():
+        first = np.where(eq.all(axis=1), mm, np.argmin(eq, axis=1))            # perfect prefix length
+        last = np.where(eq.all(axis=1), -1, mm - 1 - np.argmin(eq[:, ::-1], axis=1))
+        suf = mm - 1 - last
+        before = np.concatenate([[0], np.maximum.accumulate(first)[:-1]])
+        if ((before + suf) >= mm).any():
+            return None                                                          # a one-deletion alignment without mismatch
+        cand = np.nonzero(x == 2)[0]
+    else:
+        return None
+    best, bd = None, -1
+    for d in cand:                      # ascending rows, strict '>'
+        s = np.float64(0.0)
+        for j in range(mm):             # the DP's left fold along the diagonal
+            s = s + (np.float64(1.0) if eq[d, j] else MISS)
+        if best is None or s > best:
+            best, bd = s, int(d)
+    return best, bd + mm
+
+
+def windows(seed, n):
+    rng = np.random.default_rng(seed)
+    for k in range(n):
+        mm = int(rng.integers(16, 44))
+        slack = int(rng.integers(0, 22))
+        alpha = np.frombuffer((b"AC", b"ACGT", b"ACG")[k % 3], np.uint8)
+        ref = alpha[rng.integers(0, len(alpha), mm + slack)].copy()
+        if k % 5 == 0:                                     # a tandem repeat window
+            per = int(rng.integers(1, 7))
+            ref = np.tile(ref[:per], len(ref) // per + 1)[:len(ref)].copy()
+        d = int(rng.integers(0, slack + 1))
+        kind = k % 8
+        if kind == 6 and slack - d >= 1:                   # the read skips b reference bases
+            b = int(rng.integers(1, slack - d + 1))
+            p = int(rng.integers(1, mm))
+            read = np.concatenate([ref[d:d + p], ref[d + p + b:d + mm + b]]).copy()
+        elif kind == 7:                                    # an inserted base
+            p = int(rng.integers(1, mm - 1))
+            read = np.concatenate([ref[d:d + p], alpha[rng.integers(0, len(alpha), 1)], ref[d + p:d + mm - 1]]).copy()
+        else:
+            read = ref[d:d + mm].copy()
+        for q in rng.choice(mm, size=(0, 1, 2, 2, 3, 1, 0, 1)[kind], replace=False):
+            read[q] = alpha[(int(np.nonzero(alpha == read[q])[0][0]) + 1) % len(alpha)] if len(alpha) > 1 else read[q]
+        if k % 11 == 0:
+            read[int(rng.integers(0, mm))] = ord("N")
+        if k % 13 == 0:
+            ref[int(rng.integers(0, len(ref)))] = ord("N")
+        yield ref, read
+
+
+def test_rule_agrees_with_the_full_dp():
+    decided = {1: 0, 2: 0}
+    deferred = 0
+    for ref, read in windows(20241004, 40000):
+        r1 = gapless_rule(ref, read, max_x=1)
+        r2 = gapless_rule(ref, read, max_x=2)
+        if r2 is None:
+            deferred += 1
+            continue
+        score, st, pl = oracle_py.sw(ref, read, planes=True)
+        mm = len(read)
+        assert np.float64(score).view(np.uint64) == np.float64(r2[0]).view(np.uint64), (ref.tobytes(), read.tobytes(), score, r2)
+        assert (int(st[0]), int(st[1]), int(st[2])) == (0, r2[1], mm), (ref.tobytes(), read.tobytes(), st, r2)
+        # the traceback from plane 0 looks at the three planes of the previous cell of the diagonal (pemapper.c:1799-1813):
+        # plane 0 must win there at every step that is followed by another one
+        i = r2[1]
+        for j in range(mm, 1, -1):
+            a, b, c = pl[0, i - 1, j - 1], pl[1, i - 1, j - 1], pl[2, i - 1, j - 1]
+            assert not (b > a) and not (c > max(a, b)), (ref.tobytes(), read.tobytes(), i, j)
+            i -= 1
+        if r1 is not None:
+            assert r1 == r2
+            decided[1] += 1
+        else:
+            decided[2] += 1
+    # both cases and the deferral all occurred in numbers
+    assert decided[1] > 10000 and decided[2] > 1500 and deferred > 4000, (decided, deferred)
