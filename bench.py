@@ -184,8 +184,8 @@ def main():
         n_multi = (agg["sw_score"] - (agg["sw_dirs"] - agg["redo"]) - agg.get("gapless", 0)) / ends
         # SW geometry as pick_geom (pemap_capi.hip): lanes per alignment, columns per lane
         lanes, W = (8, 13) if L <= 104 else (8, 19) if L <= 152 else (8, 26) if L <= 208 else (8, 32) if L <= 256 else (8, 38)
-        if 104 < L <= 160 and os.environ.get("PEMAP_GAPLESS", "2") != "0" and "PEMAP_SW_LANES" not in os.environ:
-            lanes, W = 16, 10       # the default beside the gapless rule
+        if L > 104 and os.environ.get("PEMAP_GAPLESS", "2") != "0" and "PEMAP_SW_LANES" not in os.environ:
+            lanes, W = (16, 10) if L <= 160 else (16, 13) if L <= 208 else (16, 16) if L <= 256 else (16, 19)   # the default beside the gapless rule
         slab = lanes * ((L + 21 + lanes + 15) // 16 * 16) * ((W * 4 + 31) // 32) * 4
         per_end = {
             "seed": S * 49 * 2 * 8 + 4.0 * P_e + L,                     # pos_index pairs + bucket payload + the read

@@ -719,17 +719,11 @@ static bool pm_gapless_on ()
 
 static void pick_geom (int L, int *lanes, int *w)
 {
-  // PEMAP_SW_LANES unset: 16 lanes for 105..160 bases when the gapless rule leaves the DP few problems per launch (measured
-  // 44.8 ms per step against 46.2), 8 otherwise
+  // PEMAP_SW_LANES unset: 16 lanes for reads over 104 bases when the gapless rule leaves the DP few problems per launch
+  // (2 x 150 bp: 44.8 ms per step against 46.2), 8 otherwise
   static const int lanes_env = getenv ("PEMAP_SW_LANES") ? atoi (getenv ("PEMAP_SW_LANES")) : (pm_gapless_on () ? -16 : 0);
   static const int want16 = lanes_env == 16 || lanes_env == -16;
-  if (lanes_env == -16 && !(L > 8 * 13 && L <= 16 * 10))
-    {
-      // the default only changes the 105..160 range
-      if (L <= 8 * 13) { *lanes = 8; *w = 13; }
-      else { *lanes = 8; *w = L <= 8 * 26 ? 26 : L <= 8 * 32 ? 32 : 38; }
-      return;
-    }
+  // (the default leaves reads of up to 104 bases on 8 x 13; 2 x 250 bp: 111.8 ms per step with 16 lanes against 120.5)
   static const int want12 = getenv ("PEMAP_SW_LANES") && atoi (getenv ("PEMAP_SW_LANES")) == 12;
   // experiment: 12 lanes x 13 columns, 5 alignments per wave, 128 VGPRs -> 4 waves per SIMD; measured 33 ms of SW per step
   // alone against 27.5 for 8 x 19 and much worse beside the look-up waves (27 spilled VGPRs): not the default
