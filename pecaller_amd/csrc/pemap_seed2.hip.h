@@ -523,28 +523,40 @@ __device__ __forceinline__ void pm_lookup_rep_one_end (SH & sh, const PmIndex & 
       }
   }
   pm_wave_sync ();
-  // ---- the 2 x S x 49 entries (get_mers, pemapper.c:2158-2165, in fill_mers' order)
+  // ---- the 2 x S x 49 entries (get_mers, pemapper.c:2158-2165, in fill_mers' order): one (strand, segment) per round, lane j =
+  //      neighbour j, so that which field a lane replaces, by which alternative, and in which replica's line the entry lies
+  //      are constants of the lane (pm_neighbour written out)
   int n_multi = 0;
   const uint32_t multi_base = ix.multi_base;
-  for (int x0 = 0; x0 < 2 * S * 49; x0 += 64)
-    {
-      const int x = x0 + lane;
-      bool is_multi = false;
-      if (x < 2 * S * 49)
-        {
-          const int sg = x / 49, j = x - sg * 49;
-          const int p = (j == 0) ? 0 : (j - 1) / 6;
-          const uint32_t nb = pm_neighbour (sh.kmer[sg], j);
-          const uint32_t ent = sh.lines[(sg * 8 + p) * 16 + ((nb >> (4 * p)) & 15u)];
-          sh.it_start[x] = ent;
-          is_multi = ent >= multi_base && ent < 0xFFFFFFFEu;
-          sh.it_off[x] = (ent == 0xFFFFFFFFu) ? (uint16_t) 0 : (ent == 0xFFFFFFFEu) ? (uint16_t) 0xFFFF : (uint16_t) 1;
-        }
-      const unsigned long long bal = __ballot (is_multi);
-      if (is_multi)
-        sh.mlist[n_multi + __popcll (bal & ((1ull << lane) - 1ull))] = (uint16_t) x;
-      n_multi += __popcll (bal);
-    }
+  {
+    const int nb_f = lane > 0 ? (lane - 1) / 3 : 0;
+    const uint32_t nb_a = lane > 0 ? (uint32_t) ((lane - 1) % 3) : 0u;
+    const uint32_t nb_sh = 2u * (uint32_t) (nb_f & 15);
+    const uint32_t nb_keep = lane > 0 ? ~(3u << nb_sh) : 0xFFFFFFFFu;  // lane 0: the k-mer itself
+    const uint32_t nb_alt_on = lane > 0 ? 0xFFFFFFFFu : 0u;
+    const int nb_p = (nb_f >> 1) & 7;
+    const uint32_t nb_p4 = 4u * (uint32_t) nb_p, nb_pw = 16u * (uint32_t) nb_p;
+    for (int sg = 0; sg < 2 * S; sg++)
+      {
+        const int x = sg * 49 + lane;
+        bool is_multi = false;
+        if (lane < 49)
+          {
+            const uint32_t k = sh.kmer[sg];
+            const uint32_t cur = (k >> nb_sh) & 3u;
+            const uint32_t alt = nb_a + (nb_a >= cur ? 1u : 0u);
+            const uint32_t nbk = (k & nb_keep) | ((alt << nb_sh) & nb_alt_on);
+            const uint32_t ent = sh.lines[sg * 128 + nb_pw + ((nbk >> nb_p4) & 15u)];
+            sh.it_start[x] = ent;
+            is_multi = ent >= multi_base && ent < 0xFFFFFFFEu;
+            sh.it_off[x] = (ent == 0xFFFFFFFFu) ? (uint16_t) 0 : (ent == 0xFFFFFFFEu) ? (uint16_t) 0xFFFF : (uint16_t) 1;
+          }
+        const unsigned long long bal = __ballot (is_multi);
+        if (is_multi)
+          sh.mlist[n_multi + __popcll (bal & ((1ull << lane) - 1ull))] = (uint16_t) x;
+        n_multi += __popcll (bal);
+      }
+  }
   pm_wave_sync ();
   // ---- sizes of the buckets that have a record: its first 16 bytes, 4 rounds in flight
 #pragma unroll 1
