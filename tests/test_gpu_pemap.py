@@ -255,7 +255,7 @@ def test_gapless_rule_counts_and_can_be_switched_off(dev):
     assert stats["gapless"] > stats["sw_score"] // 3, stats
     assert stats["gapless"] + (stats["sw_dirs"] - stats["redo"]) <= stats["sw_score"]
     code = r'''
-import numpy as np, fixtures, oracle_py
+import os, numpy as np, fixtures, oracle_py
 from pecaller_amd import PemapDev
 ix = fixtures.index()
 dev = PemapDev(0)
@@ -266,7 +266,7 @@ for name in ("r150", "r100"):
     dev.set_params(paired=s["paired"], min_dist=0, max_dist=500, min_align=0.85)
     dev.reset_pileup()
     m1, m2, mt = dev.map_batch(r1, l1, r2, l2)
-    assert dev.run_stats()[0]["gapless"] == 0
+    assert (dev.run_stats()[0]["gapless"] == 0) == (os.environ.get("PEMAP_GAPLESS") == "0")
     assert np.array_equal(m1, fixtures.golden_m(name, 1))
     if s["paired"]:
         assert np.array_equal(m2, fixtures.golden_m(name, 2))
@@ -276,6 +276,9 @@ dev.close()
 print("full dp ok")
 '''
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, PEMAP_GAPLESS="0", PYTHONPATH=os.pathsep.join([os.path.dirname(here), here]))
-    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
-    assert r.returncode == 0 and b"full dp ok" in r.stdout, r.stdout[-2000:]
+    # the full DP in the default pipeline; and the one-stream form of the pipeline (monolithic seed kernel on the reference's
+    # table layout), which shares no launch code with the default
+    for extra in (dict(PEMAP_GAPLESS="0"), dict(PEMAP_PIPELINE="0", PEMAP_REPLICAS="0")):
+        env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.dirname(here), here]), **extra)
+        r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        assert r.returncode == 0 and b"full dp ok" in r.stdout, (extra, r.stdout[-2000:])
