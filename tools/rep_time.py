@@ -1,5 +1,7 @@
-import sys, time, numpy as np
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+"""Start-up cost of the look-up replicas: index build without them, their allocation + build, a second index on the same object."""
+import os, sys, time, numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import fixtures
 from pecaller_amd import PemapDev
 ix = fixtures.index()
