@@ -208,6 +208,8 @@ extern "C" int pemap_dev_create (pemap_dev ** out, int device_id)
   { const char *sg = getenv ("PEMAP_SEED_BLOCKS_PER_CU"); d->seed_grid = cus * (sg ? atoi (sg) : 8); }
   { const char *sg = getenv ("PEMAP_SW_WAVES_PER_CU"); d->sw_grid = cus * (sg ? atoi (sg) : 16); }
   d->big_grid = cus * 4;
+  if (d->big_grid > d->seed_grid)
+    d->big_grid = d->seed_grid;        // the per-block spill scratch (d_seed_scratch) is sized by seed_grid
   d->n_cus = cus;
   if (hipStreamCreateWithFlags (&d->stream, hipStreamNonBlocking) != hipSuccess)
     {
