@@ -14,13 +14,16 @@
  *   pemap_dev_map_batch              pthread_create(..., map_everything, batch) + the result fold,
  *                                    pemapper.c:684, 759, 907-1309 (initial_map, find_matches, smith_waterman_align,
  *                                    find_mate_pairs, smith_waterman_backtrack)
+ *   pemap_dev_submit_batch / _wait_batch  the same seam, asynchronous like the reference's (pthread_create returns at once, the
+ *                                    batch mutex is released at pemapper.c:1307)
  *   pemap_dev_stage_reads/_run/_collect   the same call split in three, so that a caller can time the device part
  *   pemap_dev_fetch_pileup           the final genome walk that feeds the pileup / indel writers, pemapper.c:819-866
  *   pemap_dev_summary                total_reads/total_bases/total_dist/no_dists/mate_counts, pemapper.c:144-149, 1238-1265
  *   pecall_dev_*                     fill_sample_like and its callers, pecaller.c:2448-2507 (see below)
  *
  * Threading: calls on different pemap_dev objects may run concurrently from different host threads; calls on one
- * object must be serialised by the caller (the reference serialises a batch behind its own mutex, pemapper.c:661).
+ * object must be serialised by the caller (the reference serialises a batch behind its own mutex, pemapper.c:661),
+ * except pemap_dev_submit_batch / _wait_batch / _map_batch, which several host threads may call on one object.
  * Ownership: the caller owns every host buffer and may reuse it as soon as a call returns; the object owns all
  * device memory.
  */
@@ -105,6 +108,25 @@ int pemap_dev_set_params (pemap_dev * dev, int paired, int min_dist, int max_dis
  * mapping_type the class.  The pileup and the summary counters accumulate on the object. */
 int pemap_dev_map_batch (pemap_dev * dev, const char *reads1, const int *len1, const char *reads2, const int *len2,
                          int n, int stride, uint32_t * m1, uint32_t * m2, int *mapping_type);
+
+/* The same call split at the point where the reference's reader thread lets go of a batch: pthread_create (pemapper.c:684)
+ * returns at once and the batch's mutex is released when the worker is done (1307).  submit queues the batch (host-to-device
+ * copies on a copy stream, kernels on the object's pipeline, device-to-host copy of the results) and returns a ticket; wait
+ * blocks until that batch's m1 / m2 / mapping_type are in the buffers given to submit and its summary counters are folded.
+ * Up to 3 batches are in flight per object; a 4th submit first delivers the oldest.  With at least 2 in flight the copies hide
+ * under the kernels and the kernel pipeline never drains between batches: the host sees the device-resident rate.
+ * The caller's buffers (reads, lengths, results) belong to the library from submit until the batch is delivered.
+ * submit / wait / map_batch may be called from several host threads on one object (they serialise on an internal lock
+ * that is released while a thread blocks in wait); everything else on the object still needs the caller's serialisation.
+ * pemap_dev_map_batch == submit + wait. */
+int pemap_dev_submit_batch (pemap_dev * dev, const char *reads1, const int *len1, const char *reads2, const int *len2,
+                            int n, int stride, uint32_t * m1, uint32_t * m2, int *mapping_type, uint64_t * ticket);
+int pemap_dev_wait_batch (pemap_dev * dev, uint64_t ticket);
+/* Optional: page-lock a host range that read rows will be submitted from (the reference allocates its batch buffers once,
+ * pd_node_alloc at pemapper.c:2340-2372, and reuses them: pin them once after that).  Rows submitted from other memory are
+ * registered on first sight (the last 8 such ranges are kept), which costs about a millisecond per 4 MB the first time. */
+int pemap_dev_pin_host (pemap_dev * dev, const void *host_ptr, uint64_t n_bytes);
+int pemap_dev_unpin_host (pemap_dev * dev, const void *host_ptr);
 
 /* The same in three steps.  stage: host -> device copy of a batch; run: the kernels (asynchronous on the object's
  * stream unless sync != 0); collect: device -> host copy of the results + summary fold.  After stage, run may be

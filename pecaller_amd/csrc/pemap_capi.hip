@@ -8,6 +8,7 @@
 #include <stdarg.h>
 #include <unistd.h>
 #include <cstring>
+#include <mutex>
 #include <vector>
 #include "../../include/pemap_hip.h"
 #include "pemap_kernels.hip.h"
@@ -17,9 +18,108 @@
 static char g_create_err[512] = "";
 struct PmChunkCtr;
 
+// ---- batches in flight (pemap_dev_submit_batch / pemap_dev_wait_batch).  The staged-read arrays of the object are cut in
+// PM_RING slots of ring_cap rows; a submitted batch owns one slot from its host-to-device copy to the device-to-host copy of
+// its m1 / m2 / mapping_type.  Lengths and results pass through pinned staging buffers of the slot; the read rows are copied
+// straight from the caller's buffers (pinned through pemap_dev_pin_host, or registered on first use).
+#define PM_RING 3
+struct PmRingSlot
+{
+  bool active;
+  unsigned long long seq;       // ticket of the batch that owns the slot
+  int n, first;
+  uint32_t *m1, *m2;            // the caller's result buffers
+  int *mt;
+  int *h_len;                   // pinned: len1 | len2
+  uint32_t *h_res;              // pinned: m1 | m2 | mapping_type
+  hipEvent_t ev_done;           // recorded behind the device-to-host copy of the results
+  std::vector < hipEvent_t > ev_copy;   // one per slice: the slice's rows are on the device
+};
+
+struct PmPinned
+{
+  char *base;
+  size_t bytes;
+  bool by_user;                 // pemap_dev_pin_host (kept until unpin / destroy) or registered on first use (LRU)
+  unsigned long long last_use;
+};
+
+
+// Tuning knobs.  The environment is read ONCE, by pemap_dev_create, into the object: nothing below
+// calls getenv again, so two objects of one process may run with different settings and a setting cannot change under a
+// run.  None is needed in normal use.  The two timing probes that cut kernels short (and so return wrong results) exist
+// only in a library built with -DPEMAP_TIMING_PROBES, which the product build does not define.
+struct PmKnobs
+{
+  int seed_blocks_per_cu, big_blocks_per_cu, sw_waves_per_cu;
+  int replicas;                 // -1 unset, 0 never, 1 as the default
+  int gapless;                  // 0 off, 1 first case only, 2 both
+  int sw_lanes;                 // 0 unset
+  double dir_budget_gb;
+  int lookup_lds_pad_kb, lookup_waves /* -1 unset */, lookup_v, lookup_batch /* -1 unset */;
+  int lookup_prio, vote_prio, sw_prio;
+  int vote_rest_on_alu, vote_waves, vote_persist /* -1 unset */;
+  int walk_blocks_per_cu, pile_blocks_per_cu;
+  int mem_cus, mem_prio;
+  int pipeline, walk_on_mem, vote_on_mem /* -1 unset */;
+  int vote_stream_prio;
+  bool vote_stream_prio_set;
+  int chunk_pairs;
+  int seed_phase, vote_probe;   // always 0 without PEMAP_TIMING_PROBES
+};
+
+static int env_int (const char *name, int dflt)
+{
+  const char *e = getenv (name);
+  return (e && *e) ? atoi (e) : dflt;
+}
+
+static void read_knobs (PmKnobs & k)
+{
+  k.seed_blocks_per_cu = env_int ("PEMAP_SEED_BLOCKS_PER_CU", 8);
+  k.big_blocks_per_cu = env_int ("PEMAP_BIG_BLOCKS_PER_CU", 4);
+  k.sw_waves_per_cu = env_int ("PEMAP_SW_WAVES_PER_CU", 16);
+  // a grid of zero or fewer blocks is not a setting
+  if (k.seed_blocks_per_cu < 1) k.seed_blocks_per_cu = 1;
+  if (k.big_blocks_per_cu < 1) k.big_blocks_per_cu = 1;
+  if (k.sw_waves_per_cu < 1) k.sw_waves_per_cu = 1;
+  k.replicas = getenv ("PEMAP_REPLICAS") ? (env_int ("PEMAP_REPLICAS", 1) ? 1 : 0) : -1;
+  k.gapless = env_int ("PEMAP_GAPLESS", 2);
+  k.sw_lanes = env_int ("PEMAP_SW_LANES", 0);
+  { const char *e = getenv ("PEMAP_DIR_BUDGET_GB"); k.dir_budget_gb = e ? atof (e) : 40.0; if (k.dir_budget_gb < 0.25) k.dir_budget_gb = 0.25; }
+  k.lookup_lds_pad_kb = env_int ("PEMAP_LOOKUP_LDS_PAD_KB", 20);
+  k.lookup_waves = env_int ("PEMAP_LOOKUP_WAVES", -1);
+  k.lookup_v = env_int ("PEMAP_LOOKUP_V", 1);
+  k.lookup_batch = env_int ("PEMAP_LOOKUP_BATCH", -1);
+  k.lookup_prio = env_int ("PEMAP_LOOKUP_PRIO", 0);
+  k.vote_prio = env_int ("PEMAP_VOTE_PRIO", 0);
+  k.sw_prio = env_int ("PEMAP_SW_PRIO", 0);
+  k.vote_rest_on_alu = env_int ("PEMAP_VOTE_REST_ON_ALU", 0);
+  k.vote_waves = env_int ("PEMAP_VOTE_WAVES", 1024);
+  k.vote_persist = env_int ("PEMAP_VOTE_PERSIST", -1);
+  k.walk_blocks_per_cu = env_int ("PEMAP_WALK_BLOCKS_PER_CU", 4);
+  k.pile_blocks_per_cu = env_int ("PEMAP_PILE_BLOCKS_PER_CU", 8);
+  if (k.walk_blocks_per_cu < 1) k.walk_blocks_per_cu = 1;
+  if (k.pile_blocks_per_cu < 1) k.pile_blocks_per_cu = 1;
+  k.mem_cus = env_int ("PEMAP_MEM_CUS", 0);
+  k.mem_prio = env_int ("PEMAP_MEM_PRIO", 0);
+  k.pipeline = env_int ("PEMAP_PIPELINE", 1);
+  k.walk_on_mem = env_int ("PEMAP_WALK_ON_MEM_STREAM", 0);
+  k.vote_on_mem = env_int ("PEMAP_VOTE_ON_MEM", -1);
+  k.vote_stream_prio_set = getenv ("PEMAP_VOTE_STREAM_PRIO") != nullptr;
+  k.vote_stream_prio = env_int ("PEMAP_VOTE_STREAM_PRIO", 0);
+  k.chunk_pairs = env_int ("PEMAP_CHUNK_PAIRS", 131072);
+  k.seed_phase = k.vote_probe = 0;
+#ifdef PEMAP_TIMING_PROBES
+  k.seed_phase = env_int ("PEMAP_SEED_PHASE", 0);
+  k.vote_probe = env_int ("PEMAP_VOTE_PROBE", 0);
+#endif
+}
+
 struct pemap_dev
 {
   int device;
+  PmKnobs kn;
   hipStream_t stream;
   char err[512];
   // index
@@ -84,10 +184,19 @@ struct pemap_dev
   int lists_cap;
   PmChunkCtr *d_chunk_ctr;
   std::vector < hipEvent_t > evs;
-  int big_grid;
+  int big_grid, scratch_blocks;
   uint64_t last_big;
   PmCounters last_ctr;          // summed over the chunks of the last run
   PmInsCursor last_cur;
+  // batches in flight
+  std::mutex mu;                // guards the enqueue state: submit / wait may be called from several host threads
+  PmRingSlot ring[PM_RING];
+  int ring_cap;                 // rows per slot, 0 = the ring is not set up (the staged arrays hold a resident read set)
+  unsigned long long ring_seq;
+  hipStream_t stream_h2d, stream_d2h;
+  hipEvent_t ev_batch_alu;
+  std::vector < PmPinned > pinned;
+  unsigned long long pin_clock;
   float last_ms[8];
   std::vector < uint8_t > h_ins;        // host copy of all insertion-log bytes so far
   long summary[13];
@@ -184,6 +293,19 @@ extern "C" int pemap_dev_create (pemap_dev ** out, int device_id)
   d->lists_cap = 0;
   d->d_chunk_ctr = nullptr;
   d->last_big = 0;
+  d->ring_cap = 0;
+  d->ring_seq = 0;
+  d->stream_h2d = d->stream_d2h = nullptr;
+  d->ev_batch_alu = nullptr;
+  d->pin_clock = 0;
+  for (int i = 0; i < PM_RING; i++)
+    {
+      d->ring[i].active = false;
+      d->ring[i].seq = 0;
+      d->ring[i].h_len = nullptr;
+      d->ring[i].h_res = nullptr;
+      d->ring[i].ev_done = nullptr;
+    }
   memset (&d->last_ctr, 0, sizeof (d->last_ctr));
   memset (d->last_ms, 0, sizeof (d->last_ms));
   memset (d->summary, 0, sizeof (d->summary));
@@ -205,11 +327,16 @@ extern "C" int pemap_dev_create (pemap_dev ** out, int device_id)
       return 1;
     }
   int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  { const char *sg = getenv ("PEMAP_SEED_BLOCKS_PER_CU"); d->seed_grid = cus * (sg ? atoi (sg) : 8); }
-  { const char *sg = getenv ("PEMAP_SW_WAVES_PER_CU"); d->sw_grid = cus * (sg ? atoi (sg) : 16); }
-  d->big_grid = cus * 4;
-  if (d->big_grid > d->seed_grid)
-    d->big_grid = d->seed_grid;        // the per-block spill scratch (d_seed_scratch) is sized by seed_grid
+  read_knobs (d->kn);
+  // pm_seed_kernel is launched with seed_grid blocks (monolithic form) or big_grid blocks (list mode, the big read-ends of the
+  // split pipeline); every block owns one spill area of d_seed_scratch, which is sized for the LARGER of the two grids
+  // (scratch_blocks) and passed to the kernel as its capacity.  (Round 1: the area was sized by seed_grid alone, an A/B run
+  // raised big_grid above it through an environment knob, and the blocks beyond it wrote past the allocation: the memory
+  // access fault of gpurun_out/ab_rep15.log.  DESIGN.md section 8.)
+  d->seed_grid = cus * d->kn.seed_blocks_per_cu;
+  d->sw_grid = cus * d->kn.sw_waves_per_cu;
+  d->big_grid = cus * d->kn.big_blocks_per_cu;
+  d->scratch_blocks = d->seed_grid > d->big_grid ? d->seed_grid : d->big_grid;
   d->n_cus = cus;
   if (hipStreamCreateWithFlags (&d->stream, hipStreamNonBlocking) != hipSuccess)
     {
@@ -306,6 +433,25 @@ extern "C" void pemap_dev_destroy (pemap_dev * d)
   hipFree (d->d_dirbuf);
   hipFree (d->d_dirbuf2);
   hipFree (d->d_ins_log);
+  for (int i = 0; i < PM_RING; i++)
+    {
+      if (d->ring[i].h_len)
+        hipHostFree (d->ring[i].h_len);
+      if (d->ring[i].h_res)
+        hipHostFree (d->ring[i].h_res);
+      if (d->ring[i].ev_done)
+        hipEventDestroy (d->ring[i].ev_done);
+      for (size_t k = 0; k < d->ring[i].ev_copy.size (); k++)
+        hipEventDestroy (d->ring[i].ev_copy[k]);
+    }
+  for (size_t i = 0; i < d->pinned.size (); i++)
+    (void) hipHostUnregister (d->pinned[i].base);
+  if (d->stream_h2d)
+    {
+      hipStreamDestroy (d->stream_h2d);
+      hipStreamDestroy (d->stream_d2h);
+      hipEventDestroy (d->ev_batch_alu);
+    }
   for (int i = 0; i < 7; i++)
     hipEventDestroy (d->ev[i]);
   if (d->stream2)
@@ -342,6 +488,8 @@ extern "C" void pemap_dev_destroy (pemap_dev * d)
 // ------------------------------------------------------------------------------------------------------------
 static const uint64_t POS_INDEX_N = (1ull << 32) + 1ull;
 static int drain_ins (pemap_dev * d);
+static int ring_leave (pemap_dev * d);
+static void fold_summary (pemap_dev * d, int first, int n, const uint32_t * m1, const uint32_t * m2, const int *mapping_type);
 
 extern "C" int pemap_dev_index_alloc (pemap_dev * d, uint64_t n_mers, uint64_t genome_size, int n_contigs, int idepth)
 {
@@ -373,7 +521,8 @@ static int build_replicas (pemap_dev * d)
   d->d_multi = nullptr;
   d->n_rep = 0;
   int want = d->rep_want;
-  { const char *e = getenv ("PEMAP_REPLICAS"); if (e && want < 0) want = atoi (e) ? 8 : 0; }
+  if (want < 0 && d->kn.replicas >= 0)
+    want = d->kn.replicas ? 8 : 0;
   if (want == 0)
     {
       hipFree (d->d_rep);
@@ -432,7 +581,11 @@ static int build_replicas (pemap_dev * d)
         {
           if (want == 8)
             return fail (d, "look-up replicas: the device cannot hold %.1f GB beside the index and %.1f GB of work arrays", rep_bytes / 1e9, reserve / 1e9);
-          return 0;             // the reference's layout serves the look-ups (pm_lookup_wave_kernel)
+          // the reference's layout serves the look-ups (pm_lookup_wave_kernel): same results, about 1.6x the time per step
+          fprintf (stderr, "libpemap_hip: device %d has no room for the %.0f GB of look-up replicas beside the index and %.0f GB of work arrays; "
+                   "the look-ups read the reference's table instead (slower, same results; PEMAP_REPLICAS=0 silences this)\n", d->device,
+                   rep_bytes / 1e9, reserve / 1e9);
+          return 0;
         }
     }
   uint32_t *units = d->d_rep + (1ull << 32);    // replica 1's place holds the record offsets until replica 0 is encoded
@@ -708,25 +861,24 @@ static int ensure_reads (pemap_dev * d, int n, int stride, int paired)
 // 2 x 250 bases (112 ms of SW per 1 M pairs either way), so it stays an option.
 // PEMAP_GAPLESS=0: every problem goes through the DP (the rule of pm_gapless_kernel off); 1: its first case only (diagonals
 // with at most one mismatch); default 2: both cases
-static int pm_gapless_max_x ()
+static int pm_gapless_max_x (const pemap_dev * d)
 {
-  static const int g = getenv ("PEMAP_GAPLESS") ? atoi (getenv ("PEMAP_GAPLESS")) : 2;
-  return g;
+  return d->kn.gapless;
 }
 
-static bool pm_gapless_on ()
+static bool pm_gapless_on (const pemap_dev * d)
 {
-  return pm_gapless_max_x () != 0;
+  return d->kn.gapless != 0;
 }
 
-static void pick_geom (int L, int *lanes, int *w)
+static void pick_geom (const pemap_dev * d, int L, int *lanes, int *w)
 {
   // PEMAP_SW_LANES unset: 16 lanes for reads over 104 bases when the gapless rule leaves the DP few problems per launch
   // (2 x 150 bp: 44.8 ms per step against 46.2), 8 otherwise
-  static const int lanes_env = getenv ("PEMAP_SW_LANES") ? atoi (getenv ("PEMAP_SW_LANES")) : (pm_gapless_on () ? -16 : 0);
-  static const int want16 = lanes_env == 16 || lanes_env == -16;
+  const int lanes_env = d->kn.sw_lanes ? d->kn.sw_lanes : (pm_gapless_on (d) ? -16 : 0);
+  const bool want16 = lanes_env == 16 || lanes_env == -16;
   // (the default leaves reads of up to 104 bases on 8 x 13; 2 x 250 bp: 111.8 ms per step with 16 lanes against 120.5)
-  static const int want12 = getenv ("PEMAP_SW_LANES") && atoi (getenv ("PEMAP_SW_LANES")) == 12;
+  const bool want12 = d->kn.sw_lanes == 12;
   // experiment: 12 lanes x 13 columns, 5 alignments per wave, 128 VGPRs -> 4 waves per SIMD; measured 33 ms of SW per step
   // alone against 27.5 for 8 x 19 and much worse beside the look-up waves (27 spilled VGPRs): not the default
   if (want12 && L > 8 * 13 && L <= 12 * 13) { *lanes = 12; *w = 13; return; }
@@ -742,28 +894,24 @@ static void pick_geom (int L, int *lanes, int *w)
 }
 
 // rows of one lane's region in a direction slab: window rows + the skew steps, rounded up to the 16-step flush unit
-static int tstride_for (int L)
+static int tstride_for (const pemap_dev * d, int L)
 {
   int lanes, w;
-  pick_geom (L, &lanes, &w);
+  pick_geom (d, L, &lanes, &w);
   return (L + 21 + lanes + 15) & ~15;
 }
 
-static size_t slab_dwords_for (int L)
+static size_t slab_dwords_for (const pemap_dev * d, int L)
 {
   int lanes, W;
-  pick_geom (L, &lanes, &W);
-  return (size_t) lanes * (size_t) tstride_for (L) * (size_t) ((W * 4 + 31) / 32);
+  pick_geom (d, L, &lanes, &W);
+  return (size_t) lanes * (size_t) tstride_for (d, L) * (size_t) ((W * 4 + 31) / 32);
 }
 
 // device bytes the direction slabs of one chunk may take (one slab per read-end); PEMAP_DIR_BUDGET_GB overrides
-static size_t dir_budget_bytes ()
+static size_t dir_budget_bytes (const pemap_dev * d)
 {
-  const char *e = getenv ("PEMAP_DIR_BUDGET_GB");
-  double gb = e ? atof (e) : 40.0;
-  if (gb < 0.25)
-    gb = 0.25;
-  return (size_t) (gb * 1073741824.0);
+  return (size_t) (d->kn.dir_budget_gb * 1073741824.0);
 }
 
 static int alloc_hits (pemap_dev * d, PmHits & h, int n_ends)
@@ -802,8 +950,8 @@ static int ensure_work (pemap_dev * d, int n_ends, bool two_sets)
       d->cap_ends = n_ends;
     }
   if (!d->d_seed_scratch)
-    TRY (dev_alloc (d, &d->d_seed_scratch, (size_t) d->seed_grid * 6 * PM_MAX_SEG * PM_SEG_LIST_MAX));
-  size_t need = ((size_t) n_ends + 1) * slab_dwords_for (d->max_len_staged);       // + 1: dump slab for task-less lane groups
+    TRY (dev_alloc (d, &d->d_seed_scratch, (size_t) d->scratch_blocks * 6 * PM_MAX_SEG * PM_SEG_LIST_MAX));
+  size_t need = ((size_t) n_ends + 1) * slab_dwords_for (d, d->max_len_staged);       // + 1: dump slab for task-less lane groups
   if (need > d->dirbuf_dwords || (two_sets && !d->d_dirbuf2))
     {
       hipFree (d->d_dirbuf);
@@ -882,7 +1030,8 @@ extern "C" int pemap_dev_stage_reads (pemap_dev * d, const char *reads1, const i
     TRY (check_lengths (d, len2, n, &mx, &mn));
   if (mx > stride)
     return fail (d, "stage_reads: a read is longer than the row stride %d", stride);
-  HIPCHK (d, hipStreamSynchronize (d->stream));
+  TRY (ring_leave (d));
+  TRY (pemap_dev_sync (d));
   TRY (ensure_reads (d, n, stride, d->paired));
   HIPCHK (d, hipMemcpy (d->d_reads1, reads1, (size_t) n * stride, hipMemcpyHostToDevice));
   HIPCHK (d, hipMemcpy (d->d_len1, len1, (size_t) n * sizeof (int), hipMemcpyHostToDevice));
@@ -946,22 +1095,20 @@ static void launch_lookup (pemap_dev * d, const RunCtx & c, int slot, PmChunkCtr
   hipEventRecord (ev[0], st);
   // occupancy knob of the look-up kernel (diagnostic): dynamic LDS padding in KB limits its workgroups per CU, so that
   // the latency-bound vote kernel running beside it keeps its wave slots
-  const char *padenv = getenv ("PEMAP_LOOKUP_LDS_PAD_KB");
-  const unsigned pad = (padenv ? (unsigned) atoi (padenv) : 20u) * 1024u;    // 5 look-up workgroups per CU (swept: 8..44 KB)
+  const unsigned pad = (unsigned) d->kn.lookup_lds_pad_kb * 1024u;    // 20 KB: 5 look-up workgroups per CU (swept: 8..44 KB)
   // PEMAP_LOOKUP_WAVES=n (default 6, swept 2..24): n persistent one-wave workgroups per CU; 0 = the workgroup-per-end kernel
-  const char *lwenv = getenv ("PEMAP_LOOKUP_WAVES");
   // PEMAP_LOOKUP_V (with replicas): 1 = pm_lookup_rep_kernel (default), 2 = the pipelined pm_lookup_rep2_kernel (measured
   // slower: 68 ms per step at its best point, 3 waves per CU, against 65 -- see DESIGN.md)
-  static const int lv = getenv ("PEMAP_LOOKUP_V") ? atoi (getenv ("PEMAP_LOOKUP_V")) : 1;
+  const int lv = d->kn.lookup_v;
   // waves per CU: 6 (with the replicas 4 was the optimum while the SW kernel scored every problem: one per SIMD; since the
   // gapless rule took 78 % of its problems away the two streams balance at 6)
-  const int lw = lwenv ? atoi (lwenv) : (c.ix.n_rep == 8) ? (lv == 2 ? 3 : 6) : 6;
+  const int lw = d->kn.lookup_waves >= 0 ? d->kn.lookup_waves : (c.ix.n_rep == 8) ? (lv == 2 ? 3 : 6) : 6;
   int lgrid = lw * d->n_cus;
   if (lgrid > c.b.n_ends)
     lgrid = c.b.n_ends;
-  const char *lbenv = getenv ("PEMAP_LOOKUP_BATCH");     // look-up rounds (x 64 lanes) a wave keeps in flight: 4, 8 or 16
-  const int lb = lbenv ? atoi (lbenv) : (c.ix.n_rep == 8 ? 8 : 4);
-  static const int lprio = getenv ("PEMAP_LOOKUP_PRIO") ? atoi (getenv ("PEMAP_LOOKUP_PRIO")) : 0;
+  // PEMAP_LOOKUP_BATCH: look-up rounds (x 64 lanes) a wave keeps in flight: 4, 8 or 16
+  const int lb = d->kn.lookup_batch >= 0 ? d->kn.lookup_batch : (c.ix.n_rep == 8 ? 8 : 4);
+  const int lprio = d->kn.lookup_prio;
 #define PM_LKW(SM, B) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_lookup_wave_kernel < SM, B >), dim3 (lgrid), dim3 (64), 0, st, c.ix, c.b, c.prm, L, lprio)
 #define PM_LKR(SM, B) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_lookup_rep_kernel < SM, B >), dim3 (lgrid), dim3 (64), 0, st, c.ix, c.b, c.prm, L, lprio)
 #define PM_LK(SM) do { if (lw > 0 && c.ix.n_rep == 8 && lv == 2) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_lookup_rep2_kernel < SM >), dim3 (lgrid), dim3 (64), sizeof (PmLookupRep2Shared < SM >), st, c.ix, c.b, c.prm, L, lprio); \
@@ -988,10 +1135,9 @@ static void launch_lookup (pemap_dev * d, const RunCtx & c, int slot, PmChunkCtr
 // of the big read-ends and the emit kernel (part 2) go to the ALU stream in front of the chunk's SW, so that the next chunk's
 // vote starts 0.5 ms earlier.  Measured 43.3 ms per step against 41.7 (the vote kernel itself slows down by as much as it
 // gains: 4.95 ms per launch against 4.5), so it is off by default.
-static bool pm_vote_rest_on_alu ()
+static bool pm_vote_rest_on_alu (const pemap_dev * d)
 {
-  static const int v = getenv ("PEMAP_VOTE_REST_ON_ALU") ? atoi (getenv ("PEMAP_VOTE_REST_ON_ALU")) : 0;
-  return v != 0;
+  return d->kn.vote_rest_on_alu != 0;
 }
 
 // part 0: the whole stage; 1: the vote kernel only; 2: what follows it
@@ -1002,8 +1148,7 @@ static void launch_vote (pemap_dev * d, const RunCtx & c, bool split, int slot, 
   uint32_t *tasks_s = set2 ? d->d_tasks_s2 : d->d_tasks_s, *tasks_m = set2 ? d->d_tasks_m2 : d->d_tasks_m;
   const int n_ends = c.b.n_ends;
   PmCounters *ctr = &cc->c;
-  const char *pl = getenv ("PEMAP_SEED_PHASE");      // timing probe only: results are meaningless when set
-  const int phase_limit = pl ? atoi (pl) : 0;
+  const int phase_limit = d->kn.seed_phase;  // timing probe, 0 unless built with -DPEMAP_TIMING_PROBES
   if (part != 2)
     {
       hipLaunchKernelGGL (pm_nop_kernel, dim3 (1), dim3 (1), 0, st);
@@ -1011,29 +1156,31 @@ static void launch_vote (pemap_dev * d, const RunCtx & c, bool split, int slot, 
     }
   if (split)
     {
-      static const int vote_probe = getenv ("PEMAP_VOTE_PROBE") ? atoi (getenv ("PEMAP_VOTE_PROBE")) : 0;     // timing experiments only
+      const int vote_probe = d->kn.vote_probe;     // timing probe, 0 unless built with -DPEMAP_TIMING_PROBES
       PmLists L = d->lists[slot];
       L.n_big = &cc->n_big;
       L.positions = &cc->positions;
       // PEMAP_VOTE_WAVES=n: at most n one-wave workgroups per CU, each striding over the ends; 0 = the workgroup-per-end kernel.
       // Default 1024 = one wave per end: the dispatcher then places vote waves wherever the look-up and SW waves of the
       // other stream leave room (measured 71.6 ms per step against 74.9 with 12 persistent waves per CU)
-      static const int vw = getenv ("PEMAP_VOTE_WAVES") ? atoi (getenv ("PEMAP_VOTE_WAVES")) : 1024;
-      static const int vprio = getenv ("PEMAP_VOTE_PRIO") ? atoi (getenv ("PEMAP_VOTE_PRIO")) : 0;
+      const int vw = d->kn.vote_waves;
+      const int vprio = d->kn.vote_prio;
       int vgrid = vw * d->n_cus;
       if (vgrid > n_ends)
         vgrid = n_ends;
       // PEMAP_VOTE_PERSIST=0 selects the lean one-end-per-wave form (120 VGPRs instead of 161).  A/B on one box, three runs each:
       // 77.6 ms per step against 74.3 -- more resident vote waves take slots from the look-up waves -- so the fat form stays
       // (with the look-up replicas the look-ups are off the critical path and the lean form wins: 55.3 ms against 56.2)
-      static const int vpersist_env = getenv ("PEMAP_VOTE_PERSIST") ? atoi (getenv ("PEMAP_VOTE_PERSIST")) : -1;
+      const int vpersist_env = d->kn.vote_persist;
       const int vpersist = vpersist_env >= 0 ? vpersist_env : (c.ix.n_rep == 8 ? 0 : 1);
 #define PM_VT(SM) do { if (vw > 0 && vgrid == n_ends && !vpersist) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_vote_wave_kernel < SM, false >), dim3 (vgrid), dim3 (64), 0, st, c.ix, c.b, c.prm, H, L, vprio); \
     else if (vw > 0) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_vote_wave_kernel < SM, true >), dim3 (vgrid), dim3 (64), 0, st, c.ix, c.b, c.prm, H, L, vprio); \
     else hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_vote_kernel < SM >), dim3 (n_ends), dim3 (PM_SEED_THREADS), 0, st, c.ix, c.b, c.prm, \
                                       H, tasks_s, tasks_m, ctr, L, vote_probe); } while (0)
-#define PM_SEEDL(SM) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_seed_kernel < SM >), dim3 (d->big_grid), dim3 (PM_SEED_THREADS), 0, st, c.ix, c.b, \
-                                         c.prm, H, tasks_s, tasks_m, ctr, d->d_seed_scratch, 0, L.big_list, L.n_big)
+      // (the grid never exceeds the blocks d_seed_scratch holds a spill area for; the kernel checks it against its capacity too)
+      const int bgrid = d->big_grid < d->scratch_blocks ? d->big_grid : d->scratch_blocks;
+#define PM_SEEDL(SM) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_seed_kernel < SM >), dim3 (bgrid), dim3 (PM_SEED_THREADS), 0, st, c.ix, c.b, \
+                                         c.prm, H, tasks_s, tasks_m, ctr, d->d_seed_scratch, d->scratch_blocks, 0, L.big_list, L.n_big)
       switch (seg_template (c.L))
         {
         // ev[2]..ev[3] = the vote kernel alone; the list-mode remainder and the emit kernel end at ev[10]
@@ -1051,8 +1198,10 @@ static void launch_vote (pemap_dev * d, const RunCtx & c, bool split, int slot, 
   else
     {
       int sgrid = d->seed_grid < n_ends ? d->seed_grid : n_ends;
+      if (sgrid > d->scratch_blocks)
+        sgrid = d->scratch_blocks;
 #define PM_SEED(SM) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_seed_kernel < SM >), dim3 (sgrid), dim3 (PM_SEED_THREADS), 0, st, c.ix, c.b, c.prm, \
-                                        H, tasks_s, tasks_m, ctr, d->d_seed_scratch, phase_limit, (const uint32_t *) nullptr, \
+                                        H, tasks_s, tasks_m, ctr, d->d_seed_scratch, d->scratch_blocks, phase_limit, (const uint32_t *) nullptr, \
                                         (const unsigned *) nullptr)
       switch (seg_template (c.L))
         {
@@ -1077,7 +1226,7 @@ template < int W, int LPA > static void launch_chunk (pemap_dev * d, const RunCt
                                              PmChunkCtr * cc, hipEvent_t * ev)
 {
   // the arrays the walk reads alternate between two sets in the split pipeline
-  static const int swprio = getenv ("PEMAP_SW_PRIO") ? atoi (getenv ("PEMAP_SW_PRIO")) : 0;
+  const int swprio = d->kn.sw_prio;
   const bool set2 = split && slot;
   const PmHits & H = set2 ? d->hits2 : d->hits;
   uint32_t *wins = set2 ? d->d_wins2 : d->d_wins;
@@ -1088,16 +1237,16 @@ template < int W, int LPA > static void launch_chunk (pemap_dev * d, const RunCt
   PmCounters *ctr = &cc->c;
   if (!(split && d->vote_on_mem))
     launch_vote (d, c, split, slot, cc, ev, d->stream);
-  else if (d->vote_stream == 3 && pm_vote_rest_on_alu ())
+  else if (d->vote_stream == 3 && pm_vote_rest_on_alu (d))
     launch_vote (d, c, split, slot, cc, ev, d->stream, 2);
-  if (pm_gapless_on ())
+  if (pm_gapless_on (d))
     {
       uint32_t *tasks_dp = tasks_s + d->cap_ends;
       int ggrid = (n_ends + 7) / 8;
       if (ggrid > d->n_cus * 16)
         ggrid = d->n_cus * 16;
       hipLaunchKernelGGL (pm_gapless_kernel, dim3 (ggrid), dim3 (256), 0, d->stream, c.ix, c.b, c.prm, H, tasks_s, &ctr->n_tasks_s, tasks_dp,
-                          &ctr->n_tasks_dp, pm_gapless_max_x ());
+                          &ctr->n_tasks_dp, pm_gapless_max_x (d));
       hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, LPA, true >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, H,
                           tasks_dp, &ctr->n_tasks_dp, ctr, dirbuf, dump_slab, c.tstride, c.L, swprio, &ctr->sw_next[0]);
     }
@@ -1105,13 +1254,13 @@ template < int W, int LPA > static void launch_chunk (pemap_dev * d, const RunCt
     hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, LPA, true >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, H,
                         tasks_s, &ctr->n_tasks_s, ctr, dirbuf, dump_slab, c.tstride, c.L, swprio, &ctr->sw_next[0]);
   hipEventRecord (ev[4], d->stream);
-  if (pm_gapless_on ())
+  if (pm_gapless_on (d))
     {
       // the same rule on the problems of the multi-hit ends (scores only; a winner it decided is not scored again);
       // sw_next[3] counts what is left to the DP
       uint32_t *tasks_mdp = tasks_m + (size_t) d->cap_ends * PM_MAX_HITS;
       hipLaunchKernelGGL (pm_gapless_kernel, dim3 (d->n_cus * 16), dim3 (256), 0, d->stream, c.ix, c.b, c.prm, H, tasks_m, &ctr->n_tasks_m, tasks_mdp,
-                          &ctr->sw_next[3], pm_gapless_max_x ());
+                          &ctr->sw_next[3], pm_gapless_max_x (d));
       hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, LPA, false >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, H,
                           tasks_mdp, &ctr->sw_next[3], ctr, dirbuf, dump_slab, c.tstride, c.L, swprio, &ctr->sw_next[1]);
     }
@@ -1128,7 +1277,7 @@ template < int W, int LPA > static void launch_chunk (pemap_dev * d, const RunCt
   hipEventRecord (ev[9], d->stream);
   // PEMAP_WALK_BLOCKS_PER_CU (default 4, swept 1..16): resident 256-lane blocks of the walk per CU; few enough walkers that
   // their direction lines stay in L2 between steps
-  static const int wbp = getenv ("PEMAP_WALK_BLOCKS_PER_CU") ? atoi (getenv ("PEMAP_WALK_BLOCKS_PER_CU")) : 4;
+  const int wbp = d->kn.walk_blocks_per_cu;
   int wgrid = (n_ends + 255) / 256;
   if (wgrid > d->n_cus * wbp)
     wgrid = d->n_cus * wbp;
@@ -1147,7 +1296,7 @@ template < int W, int LPA > static void launch_chunk (pemap_dev * d, const RunCt
                       dirbuf, c.tstride, d->d_counts, d->d_ins_log, d->ins_cap, path, d->path_words, nsteps);
   {
     // one wave per winning alignment applies the recorded steps to the pileup
-    static const int pbp = getenv ("PEMAP_PILE_BLOCKS_PER_CU") ? atoi (getenv ("PEMAP_PILE_BLOCKS_PER_CU")) : 8;
+    const int pbp = d->kn.pile_blocks_per_cu;
     int pgrid = (n_ends + 3) / 4;
     if (pgrid > d->n_cus * pbp)
       pgrid = d->n_cus * pbp;
@@ -1175,8 +1324,8 @@ static int absorb_run (pemap_dev * d)
       const PmCounters & c = hc[k].c;
       t.n_tasks_s += c.n_tasks_s;
       t.n_tasks_m += c.n_tasks_m;
-      t.n_tasks_dp += pm_gapless_on () ? c.n_tasks_dp : c.n_tasks_s;
-      t.sw_next[3] += pm_gapless_on () ? c.sw_next[3] : c.n_tasks_m;
+      t.n_tasks_dp += pm_gapless_on (d) ? c.n_tasks_dp : c.n_tasks_s;
+      t.sw_next[3] += pm_gapless_on (d) ? c.sw_next[3] : c.n_tasks_m;
       t.n_slots += c.n_slots;
       t.n_redo += c.n_redo;
       t.n_wins += c.n_wins;
@@ -1213,8 +1362,7 @@ static int ensure_pipeline (pemap_dev * d, int chunk_ends)
   if (!d->stream2)
     {
       // PEMAP_MEM_CUS=n: the look-up stream only runs on n CUs of every XCD (CU-mask bit i is CU i/8 of XCD i%8)
-      const char *mc = getenv ("PEMAP_MEM_CUS");
-      int ncu = mc ? atoi (mc) : 0;
+      const int ncu = d->kn.mem_cus;
       if (ncu > 0 && ncu < 32)
         {
           uint32_t mask[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -1225,11 +1373,10 @@ static int ensure_pipeline (pemap_dev * d, int chunk_ends)
       else
         {
           // PEMAP_MEM_PRIO=1 / -1: look-up stream at the highest / lowest priority the device offers (experiment)
-          const char *pe = getenv ("PEMAP_MEM_PRIO");
           int lo = 0, hi = 0;
           hipDeviceGetStreamPriorityRange (&lo, &hi);     // lo = least (numerically largest), hi = greatest
-          if (pe && atoi (pe) != 0)
-            HIPCHK (d, hipStreamCreateWithPriority (&d->stream2, hipStreamNonBlocking, atoi (pe) > 0 ? hi : lo));
+          if (d->kn.mem_prio != 0)
+            HIPCHK (d, hipStreamCreateWithPriority (&d->stream2, hipStreamNonBlocking, d->kn.mem_prio > 0 ? hi : lo));
           else
             HIPCHK (d, hipStreamCreateWithFlags (&d->stream2, hipStreamNonBlocking));
         }
@@ -1276,41 +1423,37 @@ static int run_slice (pemap_dev * d, int first, int n, int sync)
     return fail (d, "run: reads were staged in %s mode", d->staged_paired ? "paired" : "single");
   const int L = d->max_len_staged;
   const int per = d->paired ? 2 : 1;
-  const char *pe = getenv ("PEMAP_PIPELINE");
   // PEMAP_PIPELINE: 1 (default) look-up kernel on a second stream beside vote/SW/walk of the previous chunk;
   // 0 monolithic seed kernel, one stream; 2 split kernels on one stream (diagnostic).
-  const bool split = !(pe && atoi (pe) == 0) && !getenv ("PEMAP_SEED_PHASE");
-  d->serial_split = pe && atoi (pe) == 2;
-  { const char *we = getenv ("PEMAP_WALK_ON_MEM_STREAM"); d->walk_on_mem = we && atoi (we) != 0; }
+  const bool split = d->kn.pipeline != 0 && !d->kn.seed_phase;
+  d->serial_split = d->kn.pipeline == 2;
+  d->walk_on_mem = d->kn.walk_on_mem != 0;
   // PEMAP_VOTE_ON_MEM=1: the vote runs behind its look-ups on the memory stream, beside the SW / walk of the previous chunk
   // PEMAP_VOTE_ON_MEM=1: the vote runs behind its look-ups on the memory stream; 2: on a third stream of its own, beside
   // the SW / walk of the previous chunk and the look-ups of the next
   // Default: 2 with the look-up replicas (measured 41.5 ms per step against 44.7 with the vote on the ALU stream: with the
   // cheap look-ups and the gapless rule no stream is saturated any more, and the vote of chunk k+1 fills the gaps), 0 without
   // (it was slower beside the look-ups of the reference's layout).
-  { const char *ve = getenv ("PEMAP_VOTE_ON_MEM");
-    const int vm = ve ? atoi (ve) : (d->n_rep == 8 ? 2 : 0);
+  { const int vm = d->kn.vote_on_mem >= 0 ? d->kn.vote_on_mem : (d->n_rep == 8 ? 2 : 0);
     d->vote_on_mem = split && !d->serial_split && vm != 0;
     d->vote_stream = (d->vote_on_mem && vm == 2) ? 3 : 2; }
   if (d->vote_on_mem && d->vote_stream == 3 && !d->stream3)
     {
       // PEMAP_VOTE_STREAM_PRIO: queue priority of the vote's stream (-1 high, 0 normal, 1 low)
-      const char *vp = getenv ("PEMAP_VOTE_STREAM_PRIO");
-      if (vp)
-        HIPCHK (d, hipStreamCreateWithPriority (&d->stream3, hipStreamNonBlocking, atoi (vp)));
+      if (d->kn.vote_stream_prio_set)
+        HIPCHK (d, hipStreamCreateWithPriority (&d->stream3, hipStreamNonBlocking, d->kn.vote_stream_prio));
       else
         HIPCHK (d, hipStreamCreateWithFlags (&d->stream3, hipStreamNonBlocking));
       for (int i = 0; i < 2; i++)
         HIPCHK (d, hipEventCreateWithFlags (&d->ev_lookup_done[i], hipEventDisableTiming));
     }
   // chunk: one direction slab per read-end must fit the budget; the two-stream pipeline wants several chunks per run
-  size_t slab_bytes = slab_dwords_for (L) * 4;
-  long max_ends = (long) (dir_budget_bytes () / slab_bytes);
+  size_t slab_bytes = slab_dwords_for (d, L) * 4;
+  long max_ends = (long) (dir_budget_bytes (d) / slab_bytes);
   if (max_ends > 20000000)
     max_ends = 20000000;        // task ids are end * 200 + hit in 32 bits
   int chunk = (int) (max_ends / per);
-  const char *ce = getenv ("PEMAP_CHUNK_PAIRS");
-  const int want = ce ? atoi (ce) : 131072;
+  const int want = d->kn.chunk_pairs;
   if (split && want > 0 && chunk > want)
     chunk = want;
   if (chunk < 1)
@@ -1355,8 +1498,8 @@ static int run_slice (pemap_dev * d, int first, int n, int sync)
   c.prm.min_align = d->min_align;
   c.prm.bisulfite = d->bisulfite;
   c.L = L;
-  c.tstride = tstride_for (L);
-  c.dump_slab = d->d_dirbuf + (size_t) (chunk * per) * slab_dwords_for (L);
+  c.tstride = tstride_for (d, L);
+  c.dump_slab = d->d_dirbuf + (size_t) (chunk * per) * slab_dwords_for (d, L);
   if (k0 == 0)
     {
       memset (&d->last_ctr, 0, sizeof (d->last_ctr));
@@ -1409,7 +1552,7 @@ static int run_slice (pemap_dev * d, int first, int n, int sync)
           }
         if (g >= 2)
           HIPCHK (d, hipStreamWaitEvent (vs, d->ev_walk_done[slot], 0));
-        launch_vote (d, cl, true, slot, d->d_chunk_ctr + g, &d->evs[(size_t) g * PM_NEV], vs, (d->vote_stream == 3 && pm_vote_rest_on_alu ()) ? 1 : 0);
+        launch_vote (d, cl, true, slot, d->d_chunk_ctr + g, &d->evs[(size_t) g * PM_NEV], vs, (d->vote_stream == 3 && pm_vote_rest_on_alu (d)) ? 1 : 0);
         HIPCHK (d, hipEventRecord (d->ev_lists_ready[slot], vs));
         return 0;
       }
@@ -1440,7 +1583,7 @@ static int run_slice (pemap_dev * d, int first, int n, int sync)
       int *mt = d->d_mtype + f;
       {
         int lanes, w;
-        pick_geom (L, &lanes, &w);
+        pick_geom (d, L, &lanes, &w);
 #define PM_CH(WW, LL) launch_chunk < WW, LL > (d, c, m1, m2, mt, split, slot, cc, ev)
         if (lanes == 12)
           PM_CH (13, 12);
@@ -1529,7 +1672,20 @@ extern "C" int pemap_dev_collect (pemap_dev * d, uint32_t * m1, uint32_t * m2, i
     HIPCHK (d, hipMemcpy (m2, d->d_m2 + first, (size_t) n * sizeof (uint32_t), hipMemcpyDeviceToHost));
   HIPCHK (d, hipMemcpy (mapping_type, d->d_mtype + first, (size_t) n * sizeof (int), hipMemcpyDeviceToHost));
   TRY (drain_ins (d));
-  // result fold, pemapper.c:1238-1265
+  fold_summary (d, first, n, m1, m2, mapping_type);
+  return 0;
+}
+
+// ---- batches in flight -------------------------------------------------------------------------------------
+// The reference hands a filled batch to a worker thread and goes on reading (pthread_create at pemapper.c:684; the batch's
+// mutex is released when the worker is done, 1307).  submit / wait are that seam: submit queues the batch's host-to-device
+// copies (their own stream) and its kernels (the object's pipeline, continued from the batch before) and returns; wait blocks
+// until the batch's m1 / m2 / mapping_type are in the caller's buffers.  With two or three batches in flight the copies of
+// batch k + 1 and the results of batch k - 1 move while batch k is computed, and the pipeline never drains between calls.
+
+// result fold of one finished batch, pemapper.c:1238-1265
+static void fold_summary (pemap_dev * d, int first, int n, const uint32_t * m1, const uint32_t * m2, const int *mapping_type)
+{
   long *S = d->summary;
   for (int j = 0; j < n; j++)
     {
@@ -1558,55 +1714,310 @@ extern "C" int pemap_dev_collect (pemap_dev * d, uint32_t * m1, uint32_t * m2, i
           S[1] += lb;
         }
     }
+}
+
+// is [p, p + bytes) inside a pinned range?  (mu held)
+static bool pin_lookup (pemap_dev * d, const void *p, size_t bytes)
+{
+  const char *c = (const char *) p;
+  for (size_t i = 0; i < d->pinned.size (); i++)
+    if (c >= d->pinned[i].base && c + bytes <= d->pinned[i].base + d->pinned[i].bytes)
+      {
+        d->pinned[i].last_use = ++d->pin_clock;
+        return true;
+      }
+  return false;
+}
+
+// register a host range for DMA (mu held).  Ranges the library registered itself are dropped oldest first beyond 8.
+static bool pin_range (pemap_dev * d, const void *p, size_t bytes, bool by_user)
+{
+  if (pin_lookup (d, p, bytes))
+    return true;
+  // a range that overlaps a registered one without being inside it (a buffer that grew in place): drop the old registration
+  const char *c = (const char *) p;
+  for (size_t i = 0; i < d->pinned.size ();)
+    if (c < d->pinned[i].base + d->pinned[i].bytes && d->pinned[i].base < c + bytes)
+      {
+        (void) hipHostUnregister (d->pinned[i].base);
+        d->pinned.erase (d->pinned.begin () + i);
+      }
+    else
+      i++;
+  if (hipHostRegister ((void *) p, bytes, hipHostRegisterDefault) != hipSuccess)
+    {
+      (void) hipGetLastError ();
+      return false;
+    }
+  PmPinned e;
+  e.base = (char *) p;
+  e.bytes = bytes;
+  e.by_user = by_user;
+  e.last_use = ++d->pin_clock;
+  d->pinned.push_back (e);
+  int own = 0;
+  for (size_t i = 0; i < d->pinned.size (); i++)
+    own += d->pinned[i].by_user ? 0 : 1;
+  while (own > 8)
+    {
+      size_t victim = d->pinned.size ();
+      for (size_t i = 0; i < d->pinned.size (); i++)
+        if (!d->pinned[i].by_user && (victim == d->pinned.size () || d->pinned[i].last_use < d->pinned[victim].last_use))
+          victim = i;
+      (void) hipHostUnregister (d->pinned[victim].base);
+      d->pinned.erase (d->pinned.begin () + victim);
+      own--;
+    }
+  return true;
+}
+
+extern "C" int pemap_dev_pin_host (pemap_dev * d, const void *host_ptr, uint64_t n_bytes)
+{
+  std::lock_guard < std::mutex > lk (d->mu);
+  HIPCHK (d, hipSetDevice (d->device));
+  if (!host_ptr || !n_bytes)
+    return fail (d, "pin_host: empty range");
+  if (!pin_range (d, host_ptr, (size_t) n_bytes, true))
+    return fail (d, "pin_host: hipHostRegister of %llu bytes failed", (unsigned long long) n_bytes);
   return 0;
 }
 
-extern "C" int pemap_dev_map_batch (pemap_dev * d, const char *reads1, const int *len1, const char *reads2, const int *len2,
-                                    int n, int stride, uint32_t * m1, uint32_t * m2, int *mapping_type)
+extern "C" int pemap_dev_unpin_host (pemap_dev * d, const void *host_ptr)
 {
-  // The reads go to the device slice by slice, each slice queued behind the previous one (asynchronous runs continue the same
-  // two-stream pipeline), so the host-to-device copy of slice i + 1 overlaps the kernels of slice i.
+  std::lock_guard < std::mutex > lk (d->mu);
   HIPCHK (d, hipSetDevice (d->device));
+  for (size_t i = 0; i < d->pinned.size (); i++)
+    if (d->pinned[i].base == (const char *) host_ptr)
+      {
+        // copies out of the range may still be queued
+        if (d->stream_h2d)
+          HIPCHK (d, hipStreamSynchronize (d->stream_h2d));
+        HIPCHK (d, hipHostUnregister (d->pinned[i].base));
+        d->pinned.erase (d->pinned.begin () + i);
+        return 0;
+      }
+  return fail (d, "unpin_host: %p was not pinned through this object", host_ptr);
+}
+
+// wait for the batch in `slot` and deliver it (mu held through lk; released while the host blocks on the event)
+static int ring_finish (pemap_dev * d, int slot, std::unique_lock < std::mutex > &lk)
+{
+  PmRingSlot & r = d->ring[slot];
+  if (!r.active)
+    return 0;
+  const unsigned long long seq = r.seq;
+  hipEvent_t ev = r.ev_done;
+  lk.unlock ();
+  hipError_t e = hipEventSynchronize (ev);
+  lk.lock ();
+  if (e != hipSuccess)
+    return fail (d, "wait_batch: %s", hipGetErrorString (e));
+  if (!r.active || r.seq != seq)
+    return 0;                   // another thread delivered it meanwhile
+  const int n = r.n;
+  memcpy (r.m1, r.h_res, (size_t) n * 4);
+  if (d->paired && r.m2)
+    memcpy (r.m2, r.h_res + d->ring_cap, (size_t) n * 4);
+  memcpy (r.mt, r.h_res + 2 * (size_t) d->ring_cap, (size_t) n * 4);
+  fold_summary (d, r.first, n, r.m1, r.m2, r.mt);
+  r.active = false;
+  return 0;
+}
+
+static int ring_finish_all (pemap_dev * d, std::unique_lock < std::mutex > &lk)
+{
+  // oldest first, so that the summary folds in submission order
+  for (;;)
+    {
+      int pick = -1;
+      for (int i = 0; i < PM_RING; i++)
+        if (d->ring[i].active && (pick < 0 || d->ring[i].seq < d->ring[pick].seq))
+          pick = i;
+      if (pick < 0)
+        return 0;
+      TRY (ring_finish (d, pick, lk));
+    }
+}
+
+// the staged arrays go back to holding one resident read set (stage_reads, synth_reads): no batch may be in flight
+static int ring_leave (pemap_dev * d)
+{
+  std::unique_lock < std::mutex > lk (d->mu);
+  TRY (ring_finish_all (d, lk));
+  d->ring_cap = 0;
+  return 0;
+}
+
+static int ring_setup (pemap_dev * d, int n, int stride, std::unique_lock < std::mutex > &lk)
+{
+  if (!d->stream_h2d)
+    {
+      HIPCHK (d, hipStreamCreateWithFlags (&d->stream_h2d, hipStreamNonBlocking));
+      HIPCHK (d, hipStreamCreateWithFlags (&d->stream_d2h, hipStreamNonBlocking));
+      HIPCHK (d, hipEventCreateWithFlags (&d->ev_batch_alu, hipEventDisableTiming));
+    }
+  if (d->ring_cap >= n && d->stride == stride && d->staged_paired == d->paired && (!d->paired || d->d_reads2))
+    return 0;
+  // a different geometry: everything in flight is delivered and accounted first
+  TRY (ring_finish_all (d, lk));
+  if (d->run_pending)
+    {
+      TRY (absorb_run (d));
+      d->run_pending = false;
+    }
+  HIPCHK (d, hipDeviceSynchronize ());
+  int cap = n > d->ring_cap ? n : d->ring_cap;
+  if (cap < 1024)
+    cap = 1024;
+  if ((long) cap * PM_RING > 2000000000L)
+    return fail (d, "submit_batch: %d reads per batch are too many", n);
+  TRY (ensure_reads (d, cap * PM_RING, stride, d->paired));
+  for (int i = 0; i < PM_RING; i++)
+    {
+      PmRingSlot & r = d->ring[i];
+      if (r.h_len)
+        hipHostFree (r.h_len);
+      if (r.h_res)
+        hipHostFree (r.h_res);
+      r.h_len = nullptr;
+      r.h_res = nullptr;
+      HIPCHK (d, hipHostMalloc ((void **) &r.h_len, (size_t) cap * 2 * sizeof (int), hipHostMallocDefault));
+      HIPCHK (d, hipHostMalloc ((void **) &r.h_res, (size_t) cap * 3 * sizeof (uint32_t), hipHostMallocDefault));
+      if (!r.ev_done)
+        HIPCHK (d, hipEventCreateWithFlags (&r.ev_done, hipEventDisableTiming));
+    }
+  d->ring_cap = cap;
+  d->n_staged = cap * PM_RING;
+  d->staged_paired = d->paired;
+  d->max_len_staged = 0;
+  d->min_len_staged = 1 << 30;
+  d->h_len1.assign ((size_t) cap * PM_RING, 0);
+  d->h_len2.assign (d->paired ? (size_t) cap * PM_RING : 0, 0);
+  return 0;
+}
+
+extern "C" int pemap_dev_submit_batch (pemap_dev * d, const char *reads1, const int *len1, const char *reads2, const int *len2,
+                                       int n, int stride, uint32_t * m1, uint32_t * m2, int *mapping_type, uint64_t * ticket)
+{
+  std::unique_lock < std::mutex > lk (d->mu);
+  HIPCHK (d, hipSetDevice (d->device));
+  if (!d->index_ready)
+    return fail (d, "submit_batch: no index loaded");
   if (n <= 0)
-    return fail (d, "map_batch: n = %d", n);
-  if (d->paired && (!reads2 || !len2))
-    return fail (d, "map_batch: paired mode needs reads2/len2");
+    return fail (d, "submit_batch: n = %d", n);
+  if (!reads1 || !len1 || !m1 || !mapping_type || !ticket)
+    return fail (d, "submit_batch: a required pointer is NULL");
+  if (d->paired && (!reads2 || !len2 || !m2))
+    return fail (d, "submit_batch: paired mode needs reads2 / len2 / m2");
   if (stride < PEMAP_MIN_READ)
-    return fail (d, "map_batch: stride %d", stride);
+    return fail (d, "submit_batch: stride %d", stride);
   int mx = 0, mn = 1 << 30;
   TRY (check_lengths (d, len1, n, &mx, &mn));
   if (d->paired)
     TRY (check_lengths (d, len2, n, &mx, &mn));
   if (mx > stride)
-    return fail (d, "map_batch: a read is longer than the row stride %d", stride);
-  TRY (pemap_dev_sync (d));
-  TRY (ensure_reads (d, n, stride, d->paired));
-  HIPCHK (d, hipMemcpy (d->d_len1, len1, (size_t) n * sizeof (int), hipMemcpyHostToDevice));
-  d->h_len1.assign (len1, len1 + n);
-  d->h_len2.clear ();
+    return fail (d, "submit_batch: a read is longer than the row stride %d", stride);
+  TRY (ring_setup (d, n, stride, lk));
+  const int slot = (int) (d->ring_seq % PM_RING);
+  PmRingSlot & r = d->ring[slot];
+  TRY (ring_finish (d, slot, lk));      // the batch that used the slot PM_RING submissions ago
+  const int first = slot * d->ring_cap;
+  // the kernels' geometry follows the longest read seen since the ring was set up (any upper bound gives the same results;
+  // a bound that never shrinks keeps consecutive batches in one pipeline)
+  if (mx > d->max_len_staged)
+    d->max_len_staged = mx;
+  if (mn < d->min_len_staged)
+    d->min_len_staged = mn;
+  memcpy (&d->h_len1[first], len1, (size_t) n * sizeof (int));
+  memcpy (r.h_len, len1, (size_t) n * sizeof (int));
+  HIPCHK (d, hipMemcpyAsync (d->d_len1 + first, r.h_len, (size_t) n * sizeof (int), hipMemcpyHostToDevice, d->stream_h2d));
   if (d->paired)
     {
-      HIPCHK (d, hipMemcpy (d->d_len2, len2, (size_t) n * sizeof (int), hipMemcpyHostToDevice));
-      d->h_len2.assign (len2, len2 + n);
+      memcpy (&d->h_len2[first], len2, (size_t) n * sizeof (int));
+      memcpy (r.h_len + d->ring_cap, len2, (size_t) n * sizeof (int));
+      HIPCHK (d, hipMemcpyAsync (d->d_len2 + first, r.h_len + d->ring_cap, (size_t) n * sizeof (int), hipMemcpyHostToDevice, d->stream_h2d));
     }
-  d->n_staged = n;
-  d->staged_paired = d->paired;
-  d->max_len_staged = mx;
-  d->min_len_staged = mn;
-  const char *ce = getenv ("PEMAP_CHUNK_PAIRS");
-  const int slice = (ce && atoi (ce) > 0) ? atoi (ce) : 131072;
-  for (int first = 0; first < n; first += slice)
+  // the rows move by DMA straight out of the caller's buffers: pinned by the caller, or registered here on first sight (a caller
+  // that reuses its batch buffers, as the reference does, pays that once); when registration is refused the copy still works
+  // (staged by the runtime, slower)
+  (void) pin_range (d, reads1, (size_t) n * stride, false);
+  if (d->paired)
+    (void) pin_range (d, reads2, (size_t) n * stride, false);
+  const int slice = d->kn.chunk_pairs > 0 ? d->kn.chunk_pairs : 131072;
+  const int n_slices = (n + slice - 1) / slice;
+  if (!d->stream2)
+    TRY (ensure_pipeline (d, 0));       // the pipeline's streams must exist before the first copy event is waited on
+  while ((int) r.ev_copy.size () < n_slices)
     {
-      const int m = n - first < slice ? n - first : slice;
-      HIPCHK (d, hipMemcpy (d->d_reads1 + (size_t) first * stride, reads1 + (size_t) first * stride, (size_t) m * stride, hipMemcpyHostToDevice));
-      if (d->paired)
-        HIPCHK (d, hipMemcpy (d->d_reads2 + (size_t) first * stride, reads2 + (size_t) first * stride, (size_t) m * stride, hipMemcpyHostToDevice));
-      TRY (run_slice (d, first, m, 0));
+      hipEvent_t e;
+      HIPCHK (d, hipEventCreateWithFlags (&e, hipEventDisableTiming));
+      r.ev_copy.push_back (e);
     }
-  TRY (pemap_dev_sync (d));
-  d->run_first = 0;
-  d->run_n = n;
-  return pemap_dev_collect (d, m1, m2, mapping_type);
+  r.active = true;
+  r.seq = d->ring_seq;
+  r.n = n;
+  r.first = first;
+  r.m1 = m1;
+  r.m2 = m2;
+  r.mt = mapping_type;
+  for (int k = 0, off = 0; off < n; off += slice, k++)
+    {
+      const int m = n - off < slice ? n - off : slice;
+      HIPCHK (d, hipMemcpyAsync (d->d_reads1 + (size_t) (first + off) * stride, reads1 + (size_t) off * stride, (size_t) m * stride,
+                                 hipMemcpyHostToDevice, d->stream_h2d));
+      if (d->paired)
+        HIPCHK (d, hipMemcpyAsync (d->d_reads2 + (size_t) (first + off) * stride, reads2 + (size_t) off * stride, (size_t) m * stride,
+                                   hipMemcpyHostToDevice, d->stream_h2d));
+      HIPCHK (d, hipEventRecord (r.ev_copy[k], d->stream_h2d));
+      // whichever stream touches the slice's rows first (the look-ups on the memory stream, the seed kernel on the ALU stream)
+      HIPCHK (d, hipStreamWaitEvent (d->stream, r.ev_copy[k], 0));
+      if (d->stream2)
+        HIPCHK (d, hipStreamWaitEvent (d->stream2, r.ev_copy[k], 0));
+      TRY (run_slice (d, first + off, m, 0));
+    }
+  // results: behind the batch's last kernel on the ALU stream (every other stream's work for the batch precedes it)
+  HIPCHK (d, hipEventRecord (d->ev_batch_alu, d->stream));
+  HIPCHK (d, hipStreamWaitEvent (d->stream_d2h, d->ev_batch_alu, 0));
+  HIPCHK (d, hipMemcpyAsync (r.h_res, d->d_m1 + first, (size_t) n * 4, hipMemcpyDeviceToHost, d->stream_d2h));
+  if (d->paired)
+    HIPCHK (d, hipMemcpyAsync (r.h_res + d->ring_cap, d->d_m2 + first, (size_t) n * 4, hipMemcpyDeviceToHost, d->stream_d2h));
+  HIPCHK (d, hipMemcpyAsync (r.h_res + 2 * (size_t) d->ring_cap, d->d_mtype + first, (size_t) n * 4, hipMemcpyDeviceToHost, d->stream_d2h));
+  HIPCHK (d, hipEventRecord (r.ev_done, d->stream_d2h));
+  *ticket = d->ring_seq++;
+  return 0;
+}
+
+extern "C" int pemap_dev_wait_batch (pemap_dev * d, uint64_t ticket)
+{
+  std::unique_lock < std::mutex > lk (d->mu);
+  HIPCHK (d, hipSetDevice (d->device));
+  if (ticket >= d->ring_seq)
+    return fail (d, "wait_batch: ticket %llu was never handed out", (unsigned long long) ticket);
+  const int slot = (int) (ticket % PM_RING);
+  if (!d->ring[slot].active || d->ring[slot].seq != ticket)
+    return 0;                   // delivered already (by a later submit that needed the slot, or by another wait)
+  return ring_finish (d, slot, lk);
+}
+
+extern "C" int pemap_dev_map_batch (pemap_dev * d, const char *reads1, const int *len1, const char *reads2, const int *len2,
+                                    int n, int stride, uint32_t * m1, uint32_t * m2, int *mapping_type)
+{
+  // submit + wait.  Called from one thread this fills and drains the pipeline once per call; several host threads calling it
+  // on the same object (the reference's worker threads, one batch each) overlap like explicit submit / wait pairs do.
+  uint64_t t = 0;
+  TRY (pemap_dev_submit_batch (d, reads1, len1, reads2, len2, n, stride, m1, m2, mapping_type, &t));
+  TRY (pemap_dev_wait_batch (d, t));
+  std::unique_lock < std::mutex > lk (d->mu);
+  bool idle = true;
+  for (int i = 0; i < PM_RING; i++)
+    idle = idle && !d->ring[i].active;
+  if (idle && d->run_pending)
+    {
+      // nothing else in flight: account the run now (counters, kernel times, insertion log), so that run_stats describes this call
+      TRY (absorb_run (d));
+      d->run_pending = false;
+    }
+  return 0;
 }
 
 extern "C" int pemap_dev_summary (pemap_dev * d, long *out13)
@@ -1617,6 +2028,7 @@ extern "C" int pemap_dev_summary (pemap_dev * d, long *out13)
 
 extern "C" int pemap_dev_run_stats (pemap_dev * d, uint64_t * s, float *t)
 {
+  TRY (pemap_dev_sync (d));     // a run still in flight is accounted first
   const PmCounters & c = d->last_ctr;
   if (s)
     {
@@ -1856,8 +2268,9 @@ extern "C" int pemap_dev_synth_reads (pemap_dev * d, uint64_t seed, int n, int r
   if (d->gsize < 2000)
     return fail (d, "synth_reads: genome too small");
   int stride = (read_len + 15) & ~15;
+  TRY (ring_leave (d));
+  TRY (pemap_dev_sync (d));
   d->paired = paired ? 1 : 0;
-  HIPCHK (d, hipStreamSynchronize (d->stream));
   TRY (ensure_reads (d, n, stride, paired));
   int ends = paired ? 2 * n : n;
   hipLaunchKernelGGL (sy_reads_kernel, dim3 ((ends + 255) / 256), dim3 (256), 0, d->stream, seed, d->d_genome, d->gsize, n, read_len, paired,

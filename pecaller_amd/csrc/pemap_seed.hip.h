@@ -20,6 +20,13 @@
 typedef uint32_t pm_u32x2 __attribute__ ((ext_vector_type (2), aligned (4)));
 #define PM_SEED_TABLE 2048
 #define PM_DIAG_BIAS 300
+// timing probes (kernels cut short after a phase: results are wrong) exist only in builds with -DPEMAP_TIMING_PROBES; the
+// product build compiles them out, whatever a caller passes
+#ifdef PEMAP_TIMING_PROBES
+#define PM_PROBE(x) (x)
+#else
+#define PM_PROBE(x) 0
+#endif
 
 template < int SMAX > struct __align__ (8) PmSeedShared
 {
@@ -144,7 +151,7 @@ __device__ void pm_vote_strand (SH & sh, const uint32_t * ekey, const uint8_t * 
       bseg[pos] = eseg[p];
     }
   pm_barrier < LDSP > ();
-  if (probe == 2)
+  if (PM_PROBE (probe) == 2)
     return;
   // ---- tot_found of every anchor the walk can reach: 1 + number of LATER segments holding a position whose diagonal
   //      differs by less than max_off.  An anchor of segment `loop` is only visited while loop <= 1 + max_depth - min_match
@@ -182,7 +189,7 @@ __device__ void pm_vote_strand (SH & sh, const uint32_t * ekey, const uint8_t * 
         }
     }
   pm_barrier < LDSP > ();
-  if (probe == 3)
+  if (PM_PROBE (probe) == 3)
     return;
   const int ns = (int) sh.n_surv;
   // walk order: segment ascending, position ascending inside a segment (same offset, so diagonal ascending)
@@ -199,7 +206,7 @@ __device__ void pm_vote_strand (SH & sh, const uint32_t * ekey, const uint8_t * 
       order[rank] = (IdxT) sv;
     }
   pm_barrier < LDSP > ();
-  if (probe == 4)
+  if (PM_PROBE (probe) == 4)
     return;
   if (tid < 64)
     {
@@ -463,7 +470,8 @@ __device__ __forceinline__ void pm_seed_stage_a (SH & sh, const PmIndex & ix, co
 
 template < int SMAX > __global__ __launch_bounds__ (PM_SEED_THREADS, 4) void pm_seed_kernel (PmIndex ix, PmBatch b, PmParams prm, PmHits h,
                                                                                           uint32_t * tasks_s, uint32_t * tasks_m,
-                                                                                          PmCounters * ctr, uint32_t * gscratch, int phase_limit,
+                                                                                          PmCounters * ctr, uint32_t * gscratch, int scratch_blocks,
+                                                                                          int phase_limit,
                                                                                           const uint32_t * end_list, const unsigned *n_list)
 {
   // end_list != NULL: only the listed read-ends are processed (the ends the split look-up / vote kernels passed over)
@@ -475,7 +483,10 @@ template < int SMAX > __global__ __launch_bounds__ (PM_SEED_THREADS, 4) void pm_
   const int max_off = max (2, idepth - 4);
   // per-workgroup spill area for the rare strand whose positions exceed the LDS capacity: keys, survivors, order (u32 each),
   // segment numbers and counts (u8 each), PM_MAX_SEG * PM_SEG_LIST_MAX entries each
+  // gscratch holds scratch_blocks such areas: a grid larger than that would write past it (the host never launches one)
   constexpr size_t GN = (size_t) PM_MAX_SEG * PM_SEG_LIST_MAX;
+  if ((int) gridDim.x > scratch_blocks)
+    return;
   uint32_t *g_key = gscratch + (size_t) blockIdx.x * 6 * GN;
   uint32_t *g_bkey = g_key + GN;
   uint32_t *g_surv = g_bkey + GN;
@@ -527,7 +538,7 @@ template < int SMAX > __global__ __launch_bounds__ (PM_SEED_THREADS, 4) void pm_
       pm_lds_barrier ();
       int tot = 0;
       int T0 = 0, T1 = 0;
-      if (!skip && phase_limit != 1)
+      if (!skip && PM_PROBE (phase_limit) != 1)
         {
           // ---- a segment with any bucket >= too_many_spots is emptied (pemapper.c:1602-1606)
           if (tid < 2 * S)
@@ -591,7 +602,7 @@ template < int SMAX > __global__ __launch_bounds__ (PM_SEED_THREADS, 4) void pm_
       const int it2 = it + gridDim.x;
       if (it2 < n_iter)
         pm_seed_stage_a < SMAX, NI > (sh, ix, b, prm.bisulfite, end_list ? (int) end_list[it2] : it2, buf ^ 1, v0, v1);
-      if (!skip && phase_limit != 1 && phase_limit != 2)
+      if (!skip && PM_PROBE (phase_limit) != 1 && PM_PROBE (phase_limit) != 2)
         {
           int min_match = max (1, total_cuts);       // pemapper.c:1642-1645
           if (total_cuts > 4)

@@ -1182,7 +1182,7 @@ template < int SMAX > __global__ __launch_bounds__ (PM_SEED_THREADS) void pm_vot
         min_match = (4 * total_cuts) / 5;
       min_match = min (min_match, 4);
       bool go_on = true;
-      for (int strand = 0; strand < 2 && go_on && probe != 1; strand++)
+      for (int strand = 0; strand < 2 && go_on && PM_PROBE (probe) != 1; strand++)
         {
           if (strand == 1)
             {

@@ -17,6 +17,7 @@ SYMBOLS = [
     "pemap_dev_build_index_resident", "pemap_dev_index_alloc", "pemap_dev_index_commit", "pemap_dev_set_lookup_replicas",
     "pemap_dev_lookup_replicas", "pemap_dev_buffer",
     "pemap_dev_index_info", "pemap_dev_read_buffer", "pemap_dev_set_params", "pemap_dev_map_batch",
+    "pemap_dev_submit_batch", "pemap_dev_wait_batch", "pemap_dev_pin_host", "pemap_dev_unpin_host",
     "pemap_dev_stage_reads", "pemap_dev_run", "pemap_dev_run_slice", "pemap_dev_collect", "pemap_dev_sync",
     "pemap_dev_synth_genome", "pemap_dev_synth_reads", "pemap_dev_staged_reads", "pemap_dev_staged_info",
     "pemap_dev_free", "pemap_dev_fetch_pileup", "pemap_dev_fetch_records", "pemap_dev_reset_pileup", "pemap_dev_summary",
@@ -60,6 +61,10 @@ def load_library():
         L.pemap_dev_read_buffer.argtypes = [vp, i, u64, vp, u64]
         L.pemap_dev_set_params.argtypes = [vp, i, i, i, dbl, i]
         L.pemap_dev_map_batch.argtypes = [vp, vp, vp, vp, vp, i, i, vp, vp, vp]
+        L.pemap_dev_submit_batch.argtypes = [vp, vp, vp, vp, vp, i, i, vp, vp, vp, C.POINTER(u64)]
+        L.pemap_dev_wait_batch.argtypes = [vp, u64]
+        L.pemap_dev_pin_host.argtypes = [vp, vp, u64]
+        L.pemap_dev_unpin_host.argtypes = [vp, vp]
         L.pemap_dev_stage_reads.argtypes = [vp, vp, vp, vp, vp, i, i]
         L.pemap_dev_run.argtypes = [vp, i]
         L.pemap_dev_run_slice.argtypes = [vp, i, i, i]
@@ -177,6 +182,31 @@ class PemapDev:
         self._ck(self.L.pemap_dev_map_batch(self.h, _p(r1), _p(l1), _p(r2), _p(l2), n, r1.shape[1], _p(m1), _p(m2), _p(mt)))
         self._n = n
         return m1, m2, mt
+
+    def submit_batch(self, r1, l1, r2=None, l2=None):
+        """-> ticket; the result arrays are filled when wait_batch(ticket) returns (they, and the inputs, are kept alive here)"""
+        n = len(l1)
+        m1 = np.zeros(n, np.uint32)
+        m2 = np.zeros(n, np.uint32) if self.paired else None
+        mt = np.zeros(n, np.int32)
+        t = C.c_uint64()
+        self._ck(self.L.pemap_dev_submit_batch(self.h, _p(r1), _p(l1), _p(r2), _p(l2), n, r1.shape[1], _p(m1), _p(m2), _p(mt),
+                                               C.byref(t)))
+        if not hasattr(self, "_inflight"):
+            self._inflight = {}
+        self._inflight[t.value] = (m1, m2, mt, r1, l1, r2, l2)
+        return t.value
+
+    def wait_batch(self, ticket):
+        self._ck(self.L.pemap_dev_wait_batch(self.h, ticket))
+        m1, m2, mt = self._inflight.pop(ticket)[:3]
+        return m1, m2, mt
+
+    def pin_host(self, a):
+        self._ck(self.L.pemap_dev_pin_host(self.h, a.ctypes.data, a.nbytes))
+
+    def unpin_host(self, a):
+        self._ck(self.L.pemap_dev_unpin_host(self.h, a.ctypes.data))
 
     def stage_reads(self, r1, l1, r2=None, l2=None):
         self._ck(self.L.pemap_dev_stage_reads(self.h, _p(r1), _p(l1), _p(r2), _p(l2), len(l1), r1.shape[1]))

@@ -92,3 +92,25 @@ def test_index_builder_cli_writes_reference_files(tmp_path):
     assert refio.md5(np.fromfile(tmp_path / "out.mdx", dtype="<u4")) == fixtures.meta()["index"]["mdx_md5"]
     uk, us = refio.idx_to_compact(str(tmp_path / "out.idx"))
     assert np.array_equal(uk, ix["ukmer"]) and np.array_equal(us, ix["ustart"])
+
+
+def test_cli_maps_from_the_index_files_of_the_builder(tmp_path, monkeypatch):
+    """index_genome_hip's four files chained into pemapper_hip with PEMAP_INDEX_FROM_FILES=1: the .idx is inflated and the .mdx
+    read as the reference does (init_index_buffer, pemapper.c:2129-2155) and handed to pemap_dev_load_index; the outputs must be
+    the reference's r150 files."""
+    exe = os.path.join(ROOT, "pecaller_amd", "index_genome_hip")
+    names, contigs = fixtures.genome()
+    fa = tmp_path / "g1.fa"
+    with gzip.open(os.path.join(fixtures.GOLD, "g1.fa.gz"), "rb") as f, open(fa, "wb") as o:
+        shutil.copyfileobj(f, o)
+    ans = "S\n%d\n%s\n%s\nN\n" % (len(names) + 2, fa, tmp_path / "gx")
+    subprocess.run([exe], input=ans.encode(), stdout=subprocess.DEVNULL, check=True)
+    f1 = str(tmp_path / "g1_1_.fastq.gz")
+    f2 = str(tmp_path / "g1_2_.fastq.gz")
+    shutil.copy(os.path.join(fixtures.GOLD, "g1_1_.fastq.gz"), f1)
+    shutil.copy(os.path.join(fixtures.GOLD, "g1_2_.fastq.gz"), f2)
+    out = str(tmp_path / "outf")
+    monkeypatch.setenv("PEMAP_INDEX_FROM_FILES", "1")
+    r = subprocess.run([EXE, out, str(tmp_path / "gx.sdx"), "p", f1, f2, "500", "0", "N", "0.85", "8", "200000000"], stdout=subprocess.PIPE)
+    assert r.returncode == 0, r.stdout[-2000:]
+    _compare("r150", out, f1, f2)

@@ -208,3 +208,100 @@ def test_gapless_rule_on_repeats_and_competing_gaps(L):
     # the rule decided a good share and left a good share to the DP; multi-hit ends (repeats) occurred
     assert stats["gapless"] > n // 2 and stats["sw_dirs"] > n // 4 and multi > 50, (stats, multi)
     dev.close()
+
+
+def _repeat_family_genome(seed):
+    """10 contigs of unique sequence with one repeat family planted in them: 95 exact copies of a 260-base tile and 95 copies of a
+    variant that differs from it in every 16th base.  Every 16-mer of a read from the family then has a bucket of 95 positions
+    (below too_many_spots, pemapper.c:163) plus a single-substitution neighbour bucket of 95: about 1,900 positions on the
+    read's strand, over the 1,024 the look-up / vote kernels keep in LDS, so the end goes to the big-end list and through
+    pm_seed_kernel's global spill area."""
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    contigs = [acgt[rng.integers(0, 4, 80000)].copy() for _ in range(10)]
+    tile = acgt[rng.integers(0, 4, 260)].copy()
+    var = tile.copy()
+    for q in range(5, 260, 16):
+        var[q] = acgt[(int(np.nonzero(acgt == var[q])[0][0]) + 1 + q % 3) % 4]
+    spots = []
+    for k in range(190):
+        c = k % 10
+        s = 1500 + (k // 10) * 3900 + int(rng.integers(0, 600))
+        contigs[c][s:s + 260] = tile if k < 95 else var
+        spots.append((c, s))
+    return contigs, spots
+
+
+def _family_reads(contigs, spots, seed, n, L):
+    """pairs with one end inside a copy of the family and the mate in the unique flank (so that the pair resolves), and pairs
+    with both ends inside copies; 1 % substitutions"""
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    r1, r2 = [], []
+    for k in range(n):
+        c, s = spots[int(rng.integers(0, len(spots)))]
+        g = contigs[c]
+        lo = s + int(rng.integers(0, 260 - L + 1)) if k % 4 else s - int(rng.integers(1, 40))
+        fl = int(rng.integers(L + 150, 480))
+        if k % 3 == 0:
+            lo = lo - fl + L                  # the family end is the fragment's far end
+        lo = max(0, min(lo, len(g) - fl - 1))
+        a = g[lo:lo + L].copy()
+        b = COMP[g[lo + fl - L:lo + fl]][::-1].copy()
+        for x in (a, b):
+            m = rng.random(len(x)) < 0.01
+            x[m] = acgt[rng.integers(0, 4, int(m.sum()))]
+        if rng.random() < 0.5:
+            a, b = b, a
+        r1.append(a.tobytes())
+        r2.append(b.tobytes())
+    return refio.pack_reads(r1) + refio.pack_reads(r2)
+
+
+@pytest.mark.parametrize("env", [{}, {"PEMAP_SEED_BLOCKS_PER_CU": "1"}, {"PEMAP_SEED_BLOCKS_PER_CU": "1", "PEMAP_BIG_BLOCKS_PER_CU": "8"},
+                                 {"PEMAP_PIPELINE": "0", "PEMAP_SEED_BLOCKS_PER_CU": "2"}])
+def test_big_ends_take_the_spill_path(env, monkeypatch):
+    """Read-ends with more than 1,024 positions on a strand leave the wave-per-end kernels and are seeded by pm_seed_kernel in
+    list mode with its per-block spill area in HBM.  Asserted: such ends occur (stats["big_ends"]), and hits, scores,
+    coordinates, classes, pileup and insertions equal the oracle's.  The grid knobs cover the geometry that faulted in round 1
+    (list-mode grid larger than the grid the spill scratch was sized for: gpurun_out/ab_rep15.log) -- the scratch is now sized
+    for the larger grid and the kernel is told its capacity -- and the monolithic one-stream form of the seed stage."""
+    from pecaller_amd import PemapDev
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)           # the knobs are read by pemap_dev_create, once per object
+    contigs, spots = _repeat_family_genome(4242)
+    mers, ukmer, ustart, cs = refio.kmer_index(contigs)
+    ix = dict(mers=mers, ukmer=ukmer, ustart=ustart, genome=np.concatenate(contigs), contig_starts=cs,
+              contig_len=np.array([len(c) for c in contigs], dtype=np.uint32))
+    n, L = 700, 150
+    b1, l1, b2, l2 = _family_reads(contigs, spots, 99, n, L)
+    dev = PemapDev(0)
+    dev.build_index(ix["genome"], ix["contig_len"])
+    dev.set_params(paired=True, min_dist=0, max_dist=500, min_align=0.85)
+    m1, m2, mt = dev.map_batch(b1, l1, b2, l2)
+    stats, _ = dev.run_stats()
+    dbg = dev.debug_hits(2 * n)
+    counts, ins = dev.fetch_pileup()
+    dev.close()
+    o = oracle_py.Oracle(ix, paired=True, min_dist=0, max_dist=500, min_align=0.85)
+    om1, om2, omt, d1, d2 = o.map_batch(b1, l1, b2, l2, debug=True, threads=8)
+    if env.get("PEMAP_PIPELINE") != "0":
+        assert stats["big_ends"] > n // 4, stats        # (the monolithic form has no big-end list: every end is its own)
+    assert np.array_equal(m1, om1), np.nonzero(m1 != om1)[0][:10]
+    assert np.array_equal(m2, om2), np.nonzero(m2 != om2)[0][:10]
+    assert np.array_equal(mt, omt)
+    assert np.array_equal(counts, o.counts())
+    assert sorted(ins) == sorted(o.insertions())
+    many = 0
+    for which, od in ((0, d1), (1, d2)):
+        nh = dbg["n_hits"][which::2]
+        assert np.array_equal(nh, od["n_hits"])
+        for i in np.nonzero(nh)[0]:
+            k = nh[i]
+            e = 2 * i + which
+            assert np.array_equal(dbg["spot"][e, :k], od["spot"][i, :k]), e
+            assert np.array_equal(dbg["orient"][e, :k], od["orient"][i, :k]), e
+            assert np.array_equal(dbg["score"][e, :k].view(np.uint64), od["score"][i, :k].view(np.uint64)), (e, k)
+            many += k >= 90
+    assert many > n // 4, many              # the family's ends really had ~95 or ~190 candidate hits each
+    assert (m1 > 0).sum() > n // 2

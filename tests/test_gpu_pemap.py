@@ -142,6 +142,35 @@ def test_map_matches_reference_golden(dev, name, replicas):
         assert rows["Unique Mapping"] == sm[6] and rows["Non-Unique Mapping, discarded"] == sm[11]
 
 
+def test_load_index_entry_takes_the_reference_arrays():
+    """pemap_dev_load_index, the first entry of the drop-in ABI and the one INTEGRATION.md's patch calls: the reference's own
+    in-memory index (init_index_buffer, pemapper.c:2129-2155: the 2^32+1-entry prefix table of the .idx file, the .mdx position
+    lists, the .seq letters, the compressed contig starts) handed over from host memory.  The look-up replicas are built from
+    the host-supplied tables; the r150 goldens must come out, with the replicas and with the reference's layout."""
+    from pecaller_amd import PemapDev
+    ix = fixtures.index()
+    uk, us = ix["ukmer"].astype(np.int64), ix["ustart"]
+    # pos_index[k] = number of indexed positions whose 16-mer is < k
+    lens = np.concatenate([[uk[0] + 1], np.diff(uk), [(1 << 32) - uk[-1]]])
+    pos_index = np.repeat(us, lens)
+    assert pos_index.dtype == np.uint32 and len(pos_index) == (1 << 32) + 1 and pos_index[-1] == len(ix["mers"])
+    d = PemapDev(0)
+    d.load_index(pos_index, ix["mers"], ix["genome"], ix["contig_starts"])
+    del pos_index
+    assert d.index_info() == (len(ix["mers"]), len(ix["genome"]), 10, 16)
+    assert d.lookup_replicas()[0] == 8
+    r1, l1, r2, l2 = fixtures.reads("r150")
+    for replicas in (8, 0):
+        d.set_lookup_replicas(replicas)
+        d.set_params(paired=True, min_dist=0, max_dist=500, min_align=0.85)
+        d.reset_pileup()
+        m1, m2, mt = d.map_batch(r1, l1, r2, l2)
+        assert np.array_equal(m1, fixtures.golden_m("r150", 1)) and np.array_equal(m2, fixtures.golden_m("r150", 2))
+        counts, ins = d.fetch_pileup()
+        fixtures.check_pileup_against_golden("r150", counts)
+    d.close()
+
+
 def test_hits_and_scores_match_oracle(dev):
     """per read-end: the hit list (spot, strand) in order, the SW window, and per hit the fp64 score bits and start cell"""
     ix = fixtures.index()
@@ -201,6 +230,55 @@ def test_rerun_is_additive_and_slices_compose(dev):
     assert np.array_equal(c3, c1) and i3 == i1
     assert np.array_equal(np.concatenate([b1[0], b2[0]]), a1[0])
     assert np.array_equal(np.concatenate([b1[1], b2[1]]), a1[1])
+
+
+def test_batches_in_flight_equal_one_call(dev):
+    """pemap_dev_submit_batch / pemap_dev_wait_batch: uneven batches queued three deep (copies, kernels and result copies of
+    different batches overlap, the fourth submit delivers the oldest), waited for out of order, must give what one synchronous
+    call gives -- coordinates, classes, pileup, insertions, summary -- and so must two host threads calling map_batch on one object."""
+    import threading
+    r1, l1, r2, l2 = fixtures.reads("r150")
+    dev.set_lookup_replicas(8)
+    dev.set_params(paired=True, min_dist=0, max_dist=500, min_align=0.85)
+    cuts = [0, 3000, 3001, 9000, 12000, 16500, 20000]
+    dev.reset_pileup()
+    dev.pin_host(r1)                   # one buffer pinned by the caller, the other registered by the library on first use
+    tickets = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        tickets.append((a, b, dev.submit_batch(r1[a:b], l1[a:b], r2[a:b], l2[a:b])))
+    m1 = np.zeros(20000, np.uint32)
+    m2 = np.zeros(20000, np.uint32)
+    mt = np.zeros(20000, np.int32)
+    for a, b, t in reversed(tickets):
+        x1, x2, xt = dev.wait_batch(t)
+        m1[a:b], m2[a:b], mt[a:b] = x1, x2, xt
+    dev.unpin_host(r1)
+    assert np.array_equal(m1, fixtures.golden_m("r150", 1)) and np.array_equal(m2, fixtures.golden_m("r150", 2))
+    counts, ins = dev.fetch_pileup()
+    fixtures.check_pileup_against_golden("r150", counts)
+    names, contigs = fixtures.genome()
+    assert fixtures.ins_to_named(ins, names, contigs) == fixtures.golden_insertions("r150")[0]
+    tot, head, rows = fixtures.golden_summary("r150")
+    sm = dev.summary()
+    assert sm[0] == tot and rows["Unique Mate-Paired"] == sm[4] and rows["Neither Map"] == sm[12]
+    assert head[3] == "%g" % (sm[1] / sm[0]) and head[7] == "%g" % (sm[2] / sm[3])
+    # two host threads, one batch each at a time (the reference's worker threads)
+    dev.reset_pileup()
+    out = {}
+
+    def worker(k):
+        for a in range(k * 2500, 20000, 5000):
+            out[a] = dev.map_batch(r1[a:a + 2500], l1[a:a + 2500], r2[a:a + 2500], l2[a:a + 2500])
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert np.array_equal(np.concatenate([out[a][0] for a in sorted(out)]), fixtures.golden_m("r150", 1))
+    assert np.array_equal(np.concatenate([out[a][2] for a in sorted(out)]), mt)
+    counts, ins = dev.fetch_pileup()
+    fixtures.check_pileup_against_golden("r150", counts)
+    assert dev.summary()[0] == tot
 
 
 def test_torch_tensors_alias_the_library_buffers():
