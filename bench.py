@@ -3,22 +3,32 @@
 
 Metric (BASELINE.json): million reads mapped per second, whole job, synthetic 2 x 150 bp paired-end reads against an
 hg38-sized index resident in HBM.  A "step" is one pass of the hot path (seed gather + diagonal vote, SW scoring,
-pair selection, traceback + pileup) over one batch of `--batch-pairs` read pairs that are already resident in HBM.
-Both ends of a pair count as reads; every read of the batch counts (mapped or not), as it does for the reference.
+pair selection, traceback + pileup) over one batch of `--batch-pairs` read pairs.  Both ends of a pair count as reads;
+every read of the batch counts (mapped or not), as it does for the reference; the mapped share is printed beside it.
+
+`value` is timed at the reference's seam (first batch submitted to last result returned): every step hands
+HOST buffers of reads to pemap_dev_submit_batch -- the call that stands where pthread_create(map_everything) stands,
+pemapper.c:684 -- and takes m1 / m2 / mapping_type back in host memory, two batches in flight as the reference's reader
+thread keeps its workers fed.  `resident_value` is the same K steps with the reads already in HBM and the results left
+there (what round 1 printed as `value`).
 
   python bench.py --gpus 1 --steps 8 --warmup 2
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One process per GPU.  Rank 0 generates the genome and builds the index on its GPU; the other ranks receive
 pos_index / mers / genome / contig table through an RCCL broadcast at start-up (nothing is exchanged while mapping);
-every rank maps its own reads (weak scaling) into its own pileup counters.
-The last line printed by rank 0 is the JSON record.
+every rank maps its own reads (weak scaling) into its own pileup counters, which are summed once at the end
+(`timings.pileup_reduce_s`, outside the timed region as the reference's final genome walk is).
+The same JSON line carries two more measurements: `secondary` = BASELINE config 3's shape (pemapper_tsw reads: 2 x 250
+bases trimmed 3 / 2, 5 % of the read-ends with one 1..10-base indel), and `pecaller` = BASELINE config 4 (the per-site
+caller on 64-sample 30x pileup columns).  The last line printed by rank 0 is the JSON record.
 """
 import argparse
 import json
 import os
 import sys
 import time
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -27,24 +37,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E peak (MI355X_MICROARCH.md), GB/s
-
-
-class DevArray:
-    """exposes a device pointer handed out by the C-ABI to torch through __cuda_array_interface__"""
-
-    def __init__(self, ptr, n_items, typestr):
-        self.__cuda_array_interface__ = {"shape": (n_items,), "typestr": typestr, "data": (ptr, False), "version": 2}
-
-
-def dev_tensor(torch, dev, which, typestr, itemsize):
-    ptr, nbytes = dev.buffer(which)
-    return torch.as_tensor(DevArray(ptr, nbytes // itemsize, typestr), device="cuda")
-
-
-def bcast_chunks(dist, t, src=0, chunk=1 << 28):
-    n = t.numel()
-    for o in range(0, n, chunk):
-        dist.broadcast(t[o:min(n, o + chunk)], src=src)
+PECALL_BYTES_PER_SITE = 64 * 12 + 64 * 14 * 8      # 64 x 12 B in + 64 x 14 x 8 B likelihoods = 7,936 B
 
 
 def algorithmic_bytes_per_end(L, P_per_end, H_per_end):
@@ -52,6 +45,158 @@ def algorithmic_bytes_per_end(L, P_per_end, H_per_end):
     + L [read] + 4L [pileup read-modify-write] + 4 [mfile]"""
     S = L // 16 + (0 if L % 16 == 0 else 1)
     return S * 49 * 2 * 8 + 4.0 * P_per_end + H_per_end * (L + 21) + L + 4 * L + 4
+
+
+def sw_geometry(L):
+    """lanes per alignment and columns per lane as pick_geom (pemap_capi.hip) chooses them by default"""
+    lanes, W = (8, 13) if L <= 104 else (8, 19) if L <= 152 else (8, 26) if L <= 208 else (8, 32) if L <= 256 else (8, 38)
+    if L > 104 and os.environ.get("PEMAP_GAPLESS", "2") != "0" and "PEMAP_SW_LANES" not in os.environ:
+        lanes, W = (16, 10) if L <= 160 else (16, 13) if L <= 208 else (16, 16) if L <= 256 else (16, 19)
+    return lanes, W
+
+
+def lookup_kernel_name(n_rep):
+    if os.environ.get("PEMAP_LOOKUP_WAVES", "6") == "0":
+        return "pm_lookup_kernel"
+    if not n_rep:
+        return "pm_lookup_wave_kernel"
+    return {"2": "pm_lookup_rep2_kernel", "3": "pm_lookup_rep3_kernel"}.get(os.environ.get("PEMAP_LOOKUP_V", ""), None) or DEFAULT_LOOKUP
+
+
+DEFAULT_LOOKUP = "pm_lookup_rep_kernel"
+
+
+def mapper_leg(dev, a, L, B, steps, warmup, rank, world, barrier, allmax, indel_read_frac=0.0, seed_off=7, seam=True):
+    """K steps of the mapping path on batches of B pairs of L-base reads: at the seam (host buffers in, results out) and on
+    resident reads.  -> dict of rates, per-step kernel times and counters of the seam run (or of the resident run if seam=False)"""
+    n_batches = steps + warmup
+    first_read = rank * B * n_batches
+
+    def synth():
+        if indel_read_frac > 0:
+            dev.synth_reads_indel(a.seed + seed_off, B * n_batches, L, paired=True, sub_rate=a.sub_rate, indel_read_frac=indel_read_frac,
+                                  first_read=first_read)
+        else:
+            dev.synth_reads(a.seed + seed_off, B * n_batches, L, paired=True, sub_rate=a.sub_rate, indel_rate=a.indel_rate, first_read=first_read)
+
+    out = {}
+    synth()
+    host = None
+    if seam:
+        # ---- at the seam: the reads start in host memory (the reference's batch buffers), the results end there
+        t0 = time.time()
+        r1, l1, r2, l2 = host = dev.staged_reads()
+        dev.pin_host(r1)            # the reference allocates its batch buffers once (pd_node_alloc) and reuses them: pinned once, here
+        dev.pin_host(r2)
+        out["host_staging_s"] = time.time() - t0
+        res = {}
+
+        def run(k_from, k_to, depth=2):
+            tick = []
+            for k in range(k_from, k_to):
+                s = slice(k * B, (k + 1) * B)
+                tick.append((k, dev.submit_batch(r1[s], l1[s], r2[s], l2[s])))
+                if len(tick) > depth:
+                    kk, t = tick.pop(0)
+                    res[kk] = dev.wait_batch(t)
+            for kk, t in tick:
+                res[kk] = dev.wait_batch(t)
+        run(0, warmup)
+        dev.sync()                  # the warm-up's kernels are accounted and out of the counters
+        barrier()
+        t0 = time.perf_counter()
+        run(warmup, n_batches)
+        dt = allmax(time.perf_counter() - t0)
+        st, tm = dev.run_stats()        # totals over the K timed steps
+        out.update(seam_dt=dt, stats=st, times=tm, results=res)
+        mapped = sum(int((res[k][0] > 0).sum() + (res[k][1] > 0).sum()) for k in range(warmup, n_batches))
+        out["mapped_frac"] = mapped / float(2 * B * steps)
+        dev.unpin_host(r1)
+        dev.unpin_host(r2)
+        synth()                     # back to one resident read set (same reads)
+    # ---- resident: reads already in HBM, results left there; the K steps queued back to back and synchronised once (the library
+    #      pipelines the look-ups of a step's first chunk under the previous step's last chunk)
+    for w in range(warmup):
+        dev.run_slice(w * B, B, sync=True)
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(steps):
+        dev.run_slice((warmup + s) * B, B, sync=False)
+    dev.sync()
+    out["resident_dt"] = allmax(time.perf_counter() - t0)
+    if not seam:
+        st, tm = dev.run_stats()
+        out.update(stats=st, times=tm)
+    out["host"] = host
+    return out
+
+
+def roofline_of(leg, dt, steps, L, n_rep, gs, B):
+    """roofline of the dominant kernel of a mapper leg: SURVEY.md 8(d)'s algorithmic bytes per read-end x the read-ends one
+    launch carries / that kernel's average launch duration (HIP events on the kernel's own stream, taken over the timed region)"""
+    agg, tm = leg["stats"], leg["times"]
+    avg_ms = {k: v / steps for k, v in tm.items()}
+    split = avg_ms["lookup"] > 0
+    cand = {k: v for k, v in avg_ms.items() if k != ("seed" if split else "lookup") and (split or k != "vote")}
+    dom = max(cand, key=cand.get)
+    ends = agg["ends"]
+    P_e = agg["positions"] / ends
+    H_e = agg["sw_score"] / ends
+    S = L // 16 + (0 if L % 16 == 0 else 1)
+    n_single = (agg["sw_dirs"] - agg["redo"]) / ends      # single-hit problems the DP scored, with nibbles (the rest: gapless rule)
+    n_multi = (agg["sw_score"] - (agg["sw_dirs"] - agg["redo"]) - agg.get("gapless", 0)) / ends
+    lanes, W = sw_geometry(L)
+    slab = lanes * ((L + 21 + lanes + 15) // 16 * 16) * ((W * 4 + 31) // 32) * 4
+    per_end = {
+        "seed": S * 49 * 2 * 8 + 4.0 * P_e + L,                     # pos_index pairs + bucket payload + the read
+        # ... + the (key, segment) lists written for the vote; with the look-up replicas an entry is 4 bytes, not a pair
+        "lookup": S * 49 * 2 * (4 if n_rep else 8) + 4.0 * P_e + L + 5.0 * P_e,
+        "vote": 5.0 * P_e + H_e * 16,
+        "sw_single": n_single * (L + 21 + L + slab),                # window + read in, direction nibbles out
+        "sw_multi": n_multi * (L + 21 + L),
+        "select": H_e * 16 + 12,
+        "sw_redo": (agg["redo"] / ends) * (L + 21 + L + slab),
+        "walk": (agg["walks"] / ends) * ((L + 21) * 0.5 + 4 * L) + 4,   # nibbles along the path + pileup RMW + mfile
+    }
+    # one "launch" of the dominant kernel = one chunk of the step (the run is cut into chunks that pipeline on several
+    # streams).  `achieved` prices the launch with SURVEY.md 8(d)'s per-unit figure B(L) (the whole path's algorithmic bytes per
+    # read-end); the kernel's own algorithmic bytes are reported beside it
+    launches = max(1, agg["chunks"] // steps)
+    launch_ms = avg_ms[dom] / launches
+    total_b = algorithmic_bytes_per_end(L, P_e, H_e)
+    alg_bytes = total_b * (ends / steps) / launches
+    kernel_bytes = per_end[dom] * (ends / steps) / launches
+    achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
+    kname = "pm_%s_kernel" % dom
+    if dom == "lookup":
+        kname = lookup_kernel_name(n_rep)
+    elif dom == "vote" and os.environ.get("PEMAP_VOTE_WAVES", "1024") != "0":
+        kname = "pm_vote_wave_kernel"
+    elif dom.startswith("sw_"):
+        kname = "pm_sw_kernel"
+    traffic, tsrc = pmc_traffic(kname, gs, B, L)
+    step_traffic, _ = pmc_traffic(None, gs, B, L)
+    roof = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc,
+            "launches_per_step": launches, "avg_launch_ms": round(launch_ms, 3), "algorithmic_bytes_per_launch": round(alg_bytes),
+            "kernel_algorithmic_bytes_per_launch": round(kernel_bytes),
+            "kernel_achieved": round(kernel_bytes / (launch_ms * 1e-3) / 1e9, 2),
+            "kernel_ms": {k: round(v, 3) for k, v in avg_ms.items()},
+            "bytes_per_end_path": round(total_b, 1), "P_per_end": round(P_e, 2), "H_per_end": round(H_e, 3),
+            "path_GBs": round(total_b * ends / steps / (dt / steps) / 1e9, 2),
+            "path_frac": round(total_b * ends / steps / (dt / steps) / 1e9 / HBM_PEAK_GBS, 5),
+            "step_traffic_bytes": step_traffic,
+            "step_traffic_over_algorithmic": (round(step_traffic / (total_b * ends / steps), 2) if step_traffic else None),
+            "cells_per_s": round((agg["cells_score"] + agg["cells_dirs"]) / dt, 0)}
+    if dom != "lookup" and split:
+        # the path's HBM-heavy kernel beside the dominant one: same accounting
+        lk_name = lookup_kernel_name(n_rep)
+        lk_ms = avg_ms["lookup"] / launches
+        lk_traffic, lk_src = pmc_traffic(lk_name, gs, B, L)
+        roof["lookup_kernel"] = {"kernel": lk_name, "avg_launch_ms": round(lk_ms, 3), "achieved": round(alg_bytes / (lk_ms * 1e-3) / 1e9, 2),
+                                 "frac": round(alg_bytes / (lk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": lk_traffic, "traffic_source": lk_src,
+                                 "kernel_algorithmic_bytes_per_launch": round(per_end["lookup"] * (ends / steps) / launches)}
+    return roof
 
 
 def main():
@@ -70,6 +215,13 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the pemapper_tsw 2x250 leg")
+    ap.add_argument("--no-pecaller", action="store_true", help="skip the PECaller leg")
+    ap.add_argument("--config", default="hg38_150", choices=["hg38_150", "tsw250"],
+                    help="tsw250: only BASELINE config 3's leg is run and printed as the record's headline fields (profiling)")
+    ap.add_argument("--secondary-steps", type=int, default=3)
+    ap.add_argument("--pecall-sites", type=int, default=400000)
+    ap.add_argument("--pecall-cpu-seconds", type=float, default=10.0)
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--index-mode", default="bcast", choices=["bcast", "build"],
                     help="bcast: rank 0 builds, RCCL broadcast; build: every rank builds its own replica (tests)")
@@ -78,6 +230,7 @@ def main():
     import torch
     import torch.distributed as dist
     from pecaller_amd import PemapDev
+    from pecaller_amd import dist as pd
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -94,10 +247,22 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group(backend=a.backend, rank=rank, world_size=world)
+    on_gpu = a.backend == "nccl"
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
+        torch.cuda.synchronize()
+
+    def allmax(x):
+        """the bracketing barrier + max over ranks of a rank's wall time"""
+        barrier()
+        if world > 1:
+            tt = torch.tensor([x], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item())
+        return x
 
     gsize = int(a.genome_size)
     dev = PemapDev(dev_id)
@@ -117,161 +282,119 @@ def main():
         n_mers, gs, n_contigs, idepth = info[0]
         if rank != 0:
             dev.index_alloc(n_mers, gs, n_contigs, idepth)
-        cuda_dev = torch.device("cuda", dev_id)
-        for which, ts, isz in ((0, "<i4", 4), (1, "<i4", 4), (2, "|u1", 1), (3, "<i4", 4)):
-            t = dev_tensor(torch, dev, which, ts, isz)
-            if a.backend == "nccl":
-                bcast_chunks(dist, t, 0)
-            else:       # gloo rehearsal on one box: through host memory
-                h = t.cpu()
-                bcast_chunks(dist, h, 0)
-                if rank != 0:
-                    t.copy_(h.to(cuda_dev))
+        # torch views of the library's device buffers: RCCL writes straight into the index the kernels read (a gloo rehearsal on
+        # one box goes through host copies, pecaller_amd/dist.py)
+        pd.broadcast_tensors(dist, [pd.device_tensor(torch, dev, which) for which in (0, 1, 2, 3)], src=0)
         torch.cuda.synchronize()
         if rank != 0:
             dev.index_commit()
         timings["index_bcast_s"] = time.time() - t0
     n_mers, gs, n_contigs, idepth = dev.index_info()
-
-    # ---- reads: (steps + warmup) batches resident in HBM, different reads per rank
-    B = a.batch_pairs
-    n_batches = a.steps + a.warmup
+    n_rep, rec_bytes = dev.lookup_replicas()
     dev.set_params(paired=True, min_dist=0, max_dist=500, min_align=0.85)
-    dev.synth_reads(a.seed + 7, B * n_batches, a.read_len, paired=True, sub_rate=a.sub_rate, indel_rate=a.indel_rate,
-                    first_read=rank * B * n_batches)
     timings["setup_s"] = time.time() - t_setup
 
-    for w in range(a.warmup):
-        dev.run_slice(w * B, B, sync=True)
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    kt = {"seed": [], "sw_single": [], "sw_multi": [], "select": [], "sw_redo": [], "walk": [], "lookup": [], "vote": []}
-    agg = None
-    # the K steps are queued back to back (each step = one slice of the resident reads) and synchronised once: the
-    # library pipelines the look-ups of a step's first chunk under the previous step's last chunk
-    for s in range(a.steps):
-        dev.run_slice((a.warmup + s) * B, B, sync=False)
-    dev.sync()
-    st, tm = dev.run_stats()        # totals over the K queued steps
-    for k in kt:
-        kt[k].append(tm[k] / a.steps)
-    agg = st
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    B = a.batch_pairs
+    tsw_only = a.config == "tsw250"
+    TSW_L = 245                     # 250-base reads after pemapper_tsw's trims of 3 / 2 (pemapper_tsw.c:693-704; the golden's values)
+    main_leg = None
+    if not tsw_only:
+        main_leg = mapper_leg(dev, a, a.read_len, B, a.steps, a.warmup, rank, world, barrier, allmax)
+    sec_leg = None
+    if tsw_only or not a.no_secondary:
+        k, w = (a.steps, a.warmup) if tsw_only else (a.secondary_steps, 1)
+        sec_leg = mapper_leg(dev, a, TSW_L, B, k, w, rank, world, barrier, allmax, indel_read_frac=0.05, seed_off=11, seam=tsw_only)
+        sec_leg["steps"] = k
 
-    reads_per_step = 2 * B
-    value = world * a.steps * reads_per_step / dt / 1e6
+    # ---- end of the run: the per-GPU pileup partials are summed (the reference's one shared all_base_list, pemapper.c:156)
+    if world > 1:
+        cnt = pd.device_tensor(torch, dev, 4)
+        local = cnt.sum(dtype=torch.int64).reshape(1)
+        tot = local.clone() if on_gpu else local.cpu()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        barrier()
+        t0 = time.perf_counter()
+        pd.reduce_pileup(dist, cnt)
+        timings["pileup_reduce_s"] = allmax(time.perf_counter() - t0)
+        after = int(cnt.sum(dtype=torch.int64).item())
+        # every rank now holds the sum: the grand total of the counters equals the sum of the ranks' totals before
+        assert after == int(tot.item()), (after, int(tot.item()))
+        timings["pileup_reduce_checked_total"] = after
 
     if rank == 0:
-        # ---- roofline of the dominant kernel, live HIP-event durations on the kernels' own stream
-        avg_ms = {k: float(np.mean(v)) for k, v in kt.items()}
-        split = avg_ms["lookup"] > 0
-        cand = {k: v for k, v in avg_ms.items() if k != ("seed" if split else "lookup") and (split or k != "vote")}
-        dom = max(cand, key=cand.get)
-        ends = agg["ends"]
-        n_rep, rec_bytes = dev.lookup_replicas()
-        P_e = agg["positions"] / ends
-        H_e = agg["sw_score"] / ends
-        L = a.read_len
-        S = L // 16 + (0 if L % 16 == 0 else 1)
-        n_single = (agg["sw_dirs"] - agg["redo"]) / ends      # single-hit problems the DP scored, with nibbles (the rest: gapless rule)
-        n_multi = (agg["sw_score"] - (agg["sw_dirs"] - agg["redo"]) - agg.get("gapless", 0)) / ends
-        # SW geometry as pick_geom (pemap_capi.hip): lanes per alignment, columns per lane
-        lanes, W = (8, 13) if L <= 104 else (8, 19) if L <= 152 else (8, 26) if L <= 208 else (8, 32) if L <= 256 else (8, 38)
-        if L > 104 and os.environ.get("PEMAP_GAPLESS", "2") != "0" and "PEMAP_SW_LANES" not in os.environ:
-            lanes, W = (16, 10) if L <= 160 else (16, 13) if L <= 208 else (16, 16) if L <= 256 else (16, 19)   # the default beside the gapless rule
-        slab = lanes * ((L + 21 + lanes + 15) // 16 * 16) * ((W * 4 + 31) // 32) * 4
-        per_end = {
-            "seed": S * 49 * 2 * 8 + 4.0 * P_e + L,                     # pos_index pairs + bucket payload + the read
-            # ... + the (key, segment) lists written for the vote; with the look-up replicas an entry is 4 bytes, not a pair
-            "lookup": S * 49 * 2 * (4 if n_rep else 8) + 4.0 * P_e + L + 5.0 * P_e,
-            "vote": 5.0 * P_e + H_e * 16,
-            "sw_single": n_single * (L + 21 + L + slab),                # window + read in, direction nibbles out
-            "sw_multi": n_multi * (L + 21 + L),
-            "select": H_e * 16 + 12,
-            "sw_redo": (agg["redo"] / ends) * (L + 21 + L + slab),
-            "walk": (agg["walks"] / ends) * ((L + 21) * 0.5 + 4 * L) + 4,   # nibbles along the path + pileup RMW + mfile
-        }
-        # one "launch" of the dominant kernel = one chunk of the step (the run is cut into chunks that pipeline on two
-        # streams); algorithmic bytes per launch / average launch duration (HIP events on the kernel's own stream)
-        # `achieved` prices the launch with SURVEY.md 8(d)'s per-unit figure B(L) (the whole path's algorithmic bytes per read-end:
-        # one launch of the dominant kernel carries one chunk of ends through the path's bound); the kernel's own algorithmic
-        # bytes (for the look-up kernel: B's index and payload terms plus the lists it writes for the vote) are reported beside it
-        launches = max(1, agg["chunks"] // a.steps)
-        launch_ms = avg_ms[dom] / launches
-        total_b = algorithmic_bytes_per_end(L, P_e, H_e)
-        alg_bytes = total_b * (ends / a.steps) / launches
-        kernel_bytes = per_end[dom] * (ends / a.steps) / launches
-        achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
-        kname = "pm_%s_kernel" % dom
-        if dom == "lookup" and os.environ.get("PEMAP_LOOKUP_WAVES", "6") != "0":
-            # the persistent wave-per-end forms of the look-up kernel: against the 8 replicas of the table (default on an
-            # MI355X), or against the reference's table
-            kname = ("pm_lookup_rep2_kernel" if os.environ.get("PEMAP_LOOKUP_V", "1") == "2" else "pm_lookup_rep_kernel") if n_rep \
-                else "pm_lookup_wave_kernel"
-        elif dom == "vote" and os.environ.get("PEMAP_VOTE_WAVES", "1024") != "0":
-            kname = "pm_vote_wave_kernel"
-        elif dom.startswith("sw_"):
-            kname = "pm_sw_kernel"
-        traffic, tsrc = pmc_traffic(kname, gs, B, L)
-        roof = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc,
-                "launches_per_step": launches, "avg_launch_ms": round(launch_ms, 3), "algorithmic_bytes_per_launch": round(alg_bytes),
-                "kernel_algorithmic_bytes_per_launch": round(kernel_bytes),
-                "kernel_achieved": round(kernel_bytes / (launch_ms * 1e-3) / 1e9, 2),
-                "kernel_ms": {k: round(v, 3) for k, v in avg_ms.items()},
-                "bytes_per_end_path": round(total_b, 1), "P_per_end": round(P_e, 2), "H_per_end": round(H_e, 3),
-                "path_GBs": round(total_b * ends / a.steps / (dt / a.steps) / 1e9, 2),
-                "cells_per_s": round((agg["cells_score"] + agg["cells_dirs"]) / dt, 0)}
-        if dom != "lookup" and split:
-            # the path's HBM-heavy kernel beside the dominant one: same accounting
-            lk_name = ("pm_lookup_rep2_kernel" if os.environ.get("PEMAP_LOOKUP_V", "1") == "2" else "pm_lookup_rep_kernel") if n_rep else "pm_lookup_wave_kernel"
-            lk_ms = avg_ms["lookup"] / launches
-            lk_traffic, lk_src = pmc_traffic(lk_name, gs, B, L)
-            roof["lookup_kernel"] = {"kernel": lk_name, "avg_launch_ms": round(lk_ms, 3), "achieved": round(alg_bytes / (lk_ms * 1e-3) / 1e9, 2),
-                                     "frac": round(alg_bytes / (lk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": lk_traffic, "traffic_source": lk_src,
-                                     "kernel_algorithmic_bytes_per_launch": round(per_end["lookup"] * (ends / a.steps) / launches)}
+        L = TSW_L if tsw_only else a.read_len
+        leg = sec_leg if tsw_only else main_leg
+        steps = a.steps
+        reads_per_step = 2 * B
+        dt = leg["seam_dt"]
+        value = world * steps * reads_per_step / dt / 1e6
+        resident = world * steps * reads_per_step / leg["resident_dt"] / 1e6
+        roof = roofline_of(leg, dt, steps, L, n_rep, gs, B)
         cpu = None
         if world == 1 and not a.no_cpu:
-            cpu = cpu_baseline(dev, a, B)
+            cpu = cpu_baseline(dev, a, B, leg, a.warmup)
         rec = {
             "metric": "M reads mapped/sec (whole node), 2x150bp PE synthetic hg38",
-            "value": round(value, 4), "unit": "M reads/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": round(value, 4), "unit": "M reads/s", "n_gpus": world, "steps": steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
+            "timed_region": "host buffers of reads in -> m1/m2/mapping_type in host memory (pemap_dev_submit_batch / pemap_dev_wait_batch, "
+                            "2 batches in flight, PCIe both ways included)",
+            "resident_value": round(resident, 4), "resident_ms_per_step": round(leg["resident_dt"] / steps * 1e3, 3),
+            "mapped_frac": round(leg["mapped_frac"], 4), "mapped_reads_per_s_M": round(value * leg["mapped_frac"], 4),
             "config": {"workload": "hg38-sized synthetic index resident in HBM (%.2f Gbp, %d contigs, %d%% repeat tiles), "
                                    "2x%dbp paired-end reads, %d pairs per step per GPU" % (gs / 1e9, n_contigs, int(a.repeat_frac * 100), L, B),
                        "genome_size": gs, "n_mers": n_mers, "batch_pairs": B, "read_len": L, "sub_rate": a.sub_rate,
                        "indel_rate": a.indel_rate, "sharding": "reads split by rank, index replica per GPU",
                        "lookup_replicas": n_rep, "lookup_record_bytes": rec_bytes},
-            "roofline": roof, "cpu_baseline": cpu, "timings": {k: round(v, 2) for k, v in timings.items()},
-            "counters_per_step": {k: int(v / a.steps) for k, v in agg.items()},
+            "roofline": roof, "cpu_baseline": cpu, "timings": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in timings.items()},
+            "counters_per_step": {k: int(v / steps) for k, v in leg["stats"].items()},
         }
+        if tsw_only:
+            rec["metric"] = "M reads mapped/sec, pemapper_tsw path, 2x250bp (trimmed 3/2) 5% indel-enriched reads"
+        elif sec_leg is not None:
+            ks = sec_leg["steps"]
+            sdt = sec_leg["resident_dt"]
+            rec["secondary"] = {
+                "config": "pemapper_tsw path: 2x250bp reads trimmed 3/2 (245-base rows at the seam), 5% of the read-ends with one 1..10-base "
+                          "indel, %d pairs per step, same index" % B,
+                "value": round(world * ks * reads_per_step / sdt / 1e6, 4), "unit": "M reads/s", "steps": ks, "ms_per_step": round(sdt / ks * 1e3, 3),
+                "timed_region": "reads resident in HBM",
+                "roofline": roofline_of(sec_leg, sdt, ks, TSW_L, n_rep, gs, B),
+                "counters_per_step": {k: int(v / ks) for k, v in sec_leg["stats"].items()}}
+        if world == 1 and not a.no_pecaller and not tsw_only:
+            dev.close()
+            dev = None
+            rec["pecaller"] = pecaller_leg(a)
         print(json.dumps(rec), flush=True)
     barrier()
-    dev.close()
+    if dev is not None:
+        dev.close()
     if world > 1:
         dist.destroy_process_group()
 
 
 def pmc_traffic(kernel, gsize, B, L):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs
-    of this same command, profiles/r01_bench_pmc_*.json, newest pipeline first), valid for the default workload only.
-    FETCH_SIZE is taken at face value: on this path's random 8- to 64-byte reads it equals TCC_EA0_RDREQ x 64 B, one 64-byte
-    request each (calibrated with tools/micro/gather_calib.hip; the 1/2 factor of MI355X_MICROARCH.md applies to coalesced
-    streams)."""
+    """HBM bytes per launch of `kernel` (or, kernel=None, per step over all kernels) from the committed rocprofv3 PMC passes
+    (separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, profiles/r0N_bench_pmc_*.json, newest first), valid for
+    the default workload only.  FETCH_SIZE is taken at face value: on this path's random 8- to 64-byte reads it equals
+    TCC_EA0_RDREQ x 64 B, one 64-byte request each (calibrated with tools/micro/gather_calib.hip; the 1/2 factor of
+    MI355X_MICROARCH.md applies to coalesced streams)."""
     if not (gsize == 3100000000 and B == 1000000 and L == 150):
         return None, None
-    for name in ("r01_bench_pmc_final3.json", "r01_bench_pmc_v12.json", "r01_bench_pmc_replicas.json", "r01_bench_pmc_final.json"):
+    for name in ("r02_bench_pmc.json", "r01_bench_pmc_final3.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             pm = json.load(open(path))
+            if kernel is None:
+                tot = 0.0
+                for cn in ("FETCH_SIZE", "WRITE_SIZE"):
+                    for k, v in pm[cn].items():
+                        if k.startswith("pm_"):       # the mapping path's kernels (not the index build or the generators)
+                            tot += v["mean_KB_per_launch"] * v["launches"] / pm.get("steps", 3)
+                return round(tot * 1024.0), "profiles/" + name
+            if name.startswith("r01") and kernel != "pm_vote_wave_kernel" and kernel != "pm_lookup_rep_kernel":
+                continue
             f = [v for k, v in pm["FETCH_SIZE"].items() if k.startswith(kernel)][0]["mean_KB_per_launch"]
             w = [v for k, v in pm["WRITE_SIZE"].items() if k.startswith(kernel)][0]["mean_KB_per_launch"]
             return round((f + w) * 1024.0), "profiles/" + name
@@ -280,7 +403,7 @@ def pmc_traffic(kernel, gsize, B, L):
     return None, None
 
 
-def cpu_baseline(dev, a, B):
+def cpu_baseline(dev, a, B, leg, warmup):
     """the oracle (CPU restatement of the reference loop, pthreads) on a bounded sample of the same workload, same index;
     its coordinates and classes are also compared with what the GPU produced for the same reads (checker role)"""
     import oracle_py
@@ -290,34 +413,130 @@ def cpu_baseline(dev, a, B):
     genome = dev.read_buffer(2, np.uint8)
     cs = dev.read_buffer(3, np.uint32)
     t_copy = time.time() - t0
-    r1, l1, r2, l2 = dev.staged_reads()
-    first = a.warmup * B
+    r1, l1, r2, l2 = leg["host"]
+    first = warmup * B
+    g1, g2, gt = leg["results"][warmup]       # what the GPU returned for the first timed batch, through the seam
     ix = dict(pos_index=pos_index, mers=mers, genome=genome, contig_starts=cs)
     o = oracle_py.Oracle(ix, paired=True, min_dist=0, max_dist=500, min_align=0.85)
-    # GPU results of the first timed batch, for the comparison
-    dev.run_slice(first, B, sync=True)
-    g1, g2, gt = dev.collect(B)
-    n = 4000
-    done = 0
-    spent = 0.0
-    mism = 0
-    while True:
-        lo, hi = first + done, first + done + n
-        if hi > first + B:
-            break
-        t1 = time.time()
-        m1, m2, mt, _, _ = o.map_batch(r1[lo:hi], l1[lo:hi], r2[lo:hi], l2[lo:hi], threads=a.cpu_threads)
-        spent += time.time() - t1
-        mism += int((m1 != g1[done:done + n]).sum() + (m2 != g2[done:done + n]).sum() + (mt != gt[done:done + n]).sum())
-        done += n
-        if spent >= a.cpu_seconds:
-            break
-        rate = done / spent
-        n = int(max(4000, min(rate * (a.cpu_seconds - spent), 200000)))
-    return {"value": round(2 * done / spent / 1e6, 5), "unit": "M reads/s", "cores": a.cpu_threads, "kind": "port",
-            "gpu_vs_cpu_mismatches": mism, "compared_pairs": done,
-            "sample": "%d pairs of the first timed batch, same index (copied back from HBM in %.1f s), %.1f s of CPU time"
-                      % (done, t_copy, spent)}
+
+    def sample(threads, seconds, start):
+        n = 4000
+        done = 0
+        spent = 0.0
+        mism = 0
+        while True:
+            lo, hi = first + start + done, first + start + done + n
+            if hi > first + B:
+                break
+            t1 = time.time()
+            m1, m2, mt, _, _ = o.map_batch(r1[lo:hi], l1[lo:hi], r2[lo:hi], l2[lo:hi], threads=threads)
+            spent += time.time() - t1
+            s = slice(start + done, start + done + n)
+            mism += int((m1 != g1[s]).sum() + (m2 != g2[s]).sum() + (mt != gt[s]).sum())
+            done += n
+            if spent >= seconds:
+                break
+            rate = done / spent
+            n = int(max(4000, min(rate * (seconds - spent), 200000)))
+        return done, spent, mism
+    done, spent, mism = sample(a.cpu_threads, a.cpu_seconds, 0)
+    out = {"value": round(2 * done / spent / 1e6, 5), "unit": "M reads/s", "cores": a.cpu_threads, "kind": "port",
+           "gpu_vs_cpu_mismatches": mism, "compared_pairs": done, "host_cpus": os.cpu_count(),
+           "sample": "%d pairs of the first timed batch, same index (copied back from HBM in %.1f s), %.1f s of CPU time"
+                     % (done, t_copy, spent)}
+    # the authors' default thread count (map_directory_array.pl:100), on the same cores: a short second sample
+    d24, s24, m24 = sample(24, min(5.0, a.cpu_seconds), done)
+    if d24:
+        out["threads_24"] = {"value": round(2 * d24 / s24 / 1e6, 5), "compared_pairs": d24, "gpu_vs_cpu_mismatches": m24}
+        out["gpu_vs_cpu_mismatches"] += m24
+        out["compared_pairs"] += d24
+    return out
+
+
+def pecall_columns(n_sites, n, seed=777, var_rate=0.001, depth=30, err=0.004):
+    """BASELINE config 4 / SURVEY.md 8(d): 30x Poisson depth, 0.4 % per-base error, one variant per kb with genotypes drawn
+    under Hardy-Weinberg; the six counters of the pileup record per (column, sample)"""
+    rng = np.random.default_rng(seed)
+    dom = rng.integers(0, 4, n_sites).astype(np.uint8)
+    d = rng.poisson(depth, (n_sites, n))
+    e = rng.binomial(d, err)                   # reads replaced by a uniformly random base
+    good = d - e
+    is_var = rng.random(n_sites) < var_rate
+    q = rng.uniform(0.02, 0.5, n_sites)
+    alt = (dom + rng.integers(1, 4, n_sites)) % 4
+    dose = np.where(is_var[:, None], rng.binomial(2, q[:, None], (n_sites, n)), 0)      # copies of the alternative allele
+    alt_reads = rng.binomial(good, dose / 2.0)
+    reads = np.zeros((n_sites, n, 6), np.int32)
+    idx = np.arange(n_sites)
+    for s in range(n):
+        reads[idx, s, dom] += good[:, s] - alt_reads[:, s]
+        reads[idx, s, alt] += alt_reads[:, s]
+        reads[idx, s, rng.integers(0, 4, n_sites)] += e[:, s]
+    return reads.astype(np.uint16), dom
+
+
+def pecaller_leg(a):
+    """BASELINE config 4: the per-site caller (call_single_base's body, pecaller.c:1207-1691, fill_sample_like 2448-2507 inside it)
+    on synthetic 30x pileup columns of 64 samples; device-resident and seam-inclusive rates, the kernel's roofline by SURVEY.md
+    8(d)'s 7.9 KB per column, the CPU oracle on a sample of the same columns with calls and posteriors compared"""
+    from pecaller_amd.pecall import PecallDev
+    import oracle_py
+    n, S = a.pecall_sites, 64
+    t0 = time.time()
+    reads, dom = pecall_columns(n, S)
+    t_gen = time.time() - t0
+    pc = PecallDev(0)
+    pc.call_sites(reads[:20000], dom[:20000])        # warm-up: tables, allocations
+    t0 = time.perf_counter()
+    call, post, typ, ac, npass = pc.call_sites(reads, dom)
+    seam_dt = time.perf_counter() - t0
+    pc.sites_stage(reads, dom)
+    kms = [pc.sites_run() for _ in range(3)]
+    kernel_ms = float(np.mean(kms))
+    c2, p2 = pc.sites_collect()[:2]
+    assert np.array_equal(c2, call) and np.array_equal(p2, post)
+    pc.close()
+    # CPU: the oracle, one caller per thread on disjoint slices of the same columns (columns are independent)
+    nt = a.cpu_threads
+    per = 2000
+    stop_at = time.time() + a.pecall_cpu_seconds
+    done = []
+
+    def work(i):
+        k = i
+        got = []
+        while time.time() < stop_at and (k + 1) * per <= n:
+            s = slice(k * per, (k + 1) * per)
+            got.append((s, oracle_py.call_sites(reads[s], dom[s])))
+            k += nt
+        return got
+    t0 = time.time()
+    with ThreadPoolExecutor(nt) as ex:
+        for got in ex.map(work, range(nt)):
+            done += got
+    cpu_dt = time.time() - t0
+    m = sum(s.stop - s.start for s, _ in done)
+    dmax = 0.0
+    calls_eq = types_eq = True
+    for s, (oc, op, otyp, oac, onp) in done:
+        dmax = max(dmax, float(np.max(np.abs(post[s] - op))))
+        calls_eq = calls_eq and bool(np.array_equal(call[s], oc)) and bool(np.array_equal(ac[s], oac))
+        types_eq = types_eq and bool(np.array_equal(typ[s], otyp))
+    achieved = PECALL_BYTES_PER_SITE * n / (kernel_ms * 1e-3) / 1e9
+    return {"metric": "M pileup columns called/sec, 64 samples, 30x", "value": round(n / (kernel_ms * 1e-3) / 1e6, 4), "unit": "M columns/s",
+            "timed_region": "pcs_call_kernel on columns resident in HBM (HIP events on its stream, mean of 3 launches)",
+            "seam_value": round(n / seam_dt / 1e6, 4), "seam_timed_region": "pecall_dev_call_sites: host columns in, calls + posteriors out (PCIe included)",
+            "dtype": "f64", "data": "synthetic", "n_gpus": 1,
+            "config": {"workload": "%d pileup columns x %d samples, 30x Poisson depth, 0.4%% error, 1 variant/kb under HWE, seed 777, "
+                                   "prob_to_call 0.95, theta 0.001, diploid, no pedigree" % (n, S), "generated_in_s": round(t_gen, 1)},
+            "variant_rows": int((typ > 0).sum()), "passes_histogram": np.bincount(npass).tolist(),
+            "roofline": {"bound": "hbm", "kernel": "pcs_call_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "avg_launch_ms": round(kernel_ms, 3),
+                         "algorithmic_bytes_per_launch": PECALL_BYTES_PER_SITE * n, "bytes_per_site": PECALL_BYTES_PER_SITE},
+            "cpu_baseline": {"value": round(m / cpu_dt / 1e6, 5), "unit": "M columns/s", "cores": nt, "kind": "port",
+                             "sample": "%d of the same columns, %d oracle callers on %d threads, %.1f s" % (m, nt, nt, cpu_dt),
+                             "calls_and_allele_counts_equal": calls_eq, "site_types_equal": types_eq, "max_abs_dposterior": dmax,
+                             "tolerance": 1e-6}}
 
 
 if __name__ == "__main__":

@@ -146,6 +146,10 @@ int pemap_dev_synth_genome (pemap_dev * dev, uint64_t seed, uint64_t genome_size
                             void **d_genome, uint32_t * contig_len);
 int pemap_dev_synth_reads (pemap_dev * dev, uint64_t seed, int n, int read_len, int paired, double sub_rate,
                            double indel_rate, uint64_t first_read);
+/* the same with ONE insertion or deletion of 1..10 bases in the given share of the read-ends instead of a per-base indel rate
+ * (BASELINE config "5 % indel-enriched 2x250bp reads") */
+int pemap_dev_synth_reads_indel (pemap_dev * dev, uint64_t seed, int n, int read_len, int paired, double sub_rate,
+                                 double indel_read_frac, uint64_t first_read);
 /* copy the staged batch back (for the CPU baseline): reads as stride-spaced rows */
 int pemap_dev_staged_reads (pemap_dev * dev, char *reads1, int *len1, char *reads2, int *len2, int stride);
 int pemap_dev_staged_info (pemap_dev * dev, int *n, int *stride, int *paired);
@@ -226,6 +230,13 @@ int pecall_dev_collect (pecall_dev * dev, int n_sites, int indiv, double *like, 
 int pecall_dev_call_sites (pecall_dev * dev, const uint16_t * reads, const uint8_t * ref_base, const uint8_t * chrom_type, long n_sites,
                            int indiv, int haploid, double threshold, double theta, int8_t * call, double *posterior,
                            int8_t * site_type, int32_t * allele_count, int8_t * n_pass, int32_t * denovo);
+/* the same call in three steps (host->device, kernel, device->host): bench.py times the kernel on resident columns with them.
+ * kernel_ms (may be NULL) receives the kernel's duration from HIP events on the object's stream. */
+int pecall_dev_sites_stage (pecall_dev * dev, const uint16_t * reads, const uint8_t * ref_base, const uint8_t * chrom_type, long n_sites,
+                            int indiv);
+int pecall_dev_sites_run (pecall_dev * dev, int haploid, double threshold, double theta, float *kernel_ms);
+int pecall_dev_sites_collect (pecall_dev * dev, int8_t * call, double *posterior, int8_t * site_type, int32_t * allele_count,
+                              int8_t * n_pass, int32_t * denovo);
 /* use_pedfile = y (pecaller.c:376-392, 561-604): parents as sample indices (-1 = not sampled), sex (1 male, 2 female), and each
  * sample's kids in ped-file order: kids of i = kid_list[kid_off[i] .. kid_off[i + 1]).  denovo_rate = argv[11] (<= theta).
  * The configuration prior then carries no_denovo * ln(denovo_rate) (add_denovo, 2396-2445, tables of main 312-374).

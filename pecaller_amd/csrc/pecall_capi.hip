@@ -40,6 +40,9 @@ struct pecall_dev
   uint8_t h_kid_off[PCS_MAXN + 1], h_kid_list[2 * PCS_MAXN];
   int8_t *d_ped;                // dad[64] mom[64] sex[64] kid_off[65 -> 72] kid_list[128]
   short *d_dyad, *d_trio;
+  long staged_sites;
+  int staged_indiv;
+  hipEvent_t ev_site[2];
 };
 
 static int pc_fail (pecall_dev * d, const char *fmt, ...)
@@ -382,8 +385,14 @@ extern "C" int pecall_dev_set_pedigree (pecall_dev * d, int indiv, const int *da
     return pc_fail (d, "set_pedigree: %d samples (1..%d)", indiv, PCS_MAXN);
   if (!(denovo_rate >= 1e-30))
     return pc_fail (d, "set_pedigree: de-novo mutation rate %g (pecaller.c:381-385)", denovo_rate);
-  if (kid_off[indiv] > 2 * PCS_MAXN)
-    return pc_fail (d, "set_pedigree: %d parent-child links", kid_off[indiv]);
+  if (!kid_off || !kid_list || kid_off[0] != 0 || kid_off[indiv] < 0 || kid_off[indiv] > 2 * PCS_MAXN)
+    return pc_fail (d, "set_pedigree: kid_off must start at 0 and end at no more than %d parent-child links", 2 * PCS_MAXN);
+  for (int i = 0; i < indiv; i++)
+    if (kid_off[i + 1] < kid_off[i])
+      return pc_fail (d, "set_pedigree: kid_off is not ascending at sample %d", i);
+  for (int i = 0; i < kid_off[indiv]; i++)
+    if (kid_list[i] < 0 || kid_list[i] >= indiv)
+      return pc_fail (d, "set_pedigree: kid_list[%d] = %d is not a sample index (0..%d)", i, kid_list[i], indiv - 1);
   for (int i = 0; i < indiv; i++)
     {
       if (dad[i] >= indiv || mom[i] >= indiv)
@@ -428,31 +437,46 @@ static int pcs_ensure_ped (pecall_dev * d, int haploid)
   return 0;
 }
 
-extern "C" int pecall_dev_call_sites (pecall_dev * d, const uint16_t * reads, const uint8_t * ref_base, const uint8_t * chrom_type, long n_sites,
-                                      int indiv, int haploid, double threshold, double theta, int8_t * call, double *posterior,
-                                      int8_t * site_type, int32_t * allele_count, int8_t * n_pass, int32_t * denovo)
+// the per-site caller in three steps (host -> device, kernel, device -> host), so that the kernel can be timed on resident
+// columns; pecall_dev_call_sites is the three in a row
+extern "C" int pecall_dev_sites_stage (pecall_dev * d, const uint16_t * reads, const uint8_t * ref_base, const uint8_t * chrom_type, long n_sites,
+                                       int indiv)
 {
   PCCHK (d, hipSetDevice (d->device));
   if (n_sites <= 0 || indiv <= 0 || indiv > PCS_MAXN)
     return pc_fail (d, "call_sites: n_sites %ld, indiv %d (1..%d samples per call)", n_sites, indiv, PCS_MAXN);
-  if (!(theta >= 1e-10 && theta <= 0.5))
-    return pc_fail (d, "call_sites: theta %g outside [1e-10, 0.5] (pecaller.c:305-309)", theta);
   int rc = pcs_ensure (d, n_sites, indiv);
   if (rc)
     return rc;
   long items = n_sites * indiv;
   PCCHK (d, hipMemcpyAsync (d->d_sreads, reads, items * PCS_NA * sizeof (uint16_t), hipMemcpyHostToDevice, d->stream));
   PCCHK (d, hipMemcpyAsync (d->d_dom, ref_base, n_sites, hipMemcpyHostToDevice, d->stream));
+  if (chrom_type)
+    PCCHK (d, hipMemcpyAsync (d->d_chromy, chrom_type, n_sites, hipMemcpyHostToDevice, d->stream));
+  else
+    PCCHK (d, hipMemsetAsync (d->d_chromy, 0, n_sites, d->stream));
+  PCCHK (d, hipStreamSynchronize (d->stream));
+  d->staged_sites = n_sites;
+  d->staged_indiv = indiv;
+  return 0;
+}
+
+extern "C" int pecall_dev_sites_run (pecall_dev * d, int haploid, double threshold, double theta, float *kernel_ms)
+{
+  PCCHK (d, hipSetDevice (d->device));
+  const long n_sites = d->staged_sites;
+  const int indiv = d->staged_indiv;
+  if (n_sites <= 0)
+    return pc_fail (d, "sites_run: nothing staged");
+  if (!(theta >= 1e-10 && theta <= 0.5))
+    return pc_fail (d, "call_sites: theta %g outside [1e-10, 0.5] (pecaller.c:305-309)", theta);
+  int rc;
   if (d->ped_indiv && d->ped_indiv != indiv)
     return pc_fail (d, "call_sites: the pedigree was set for %d samples, this call has %d", d->ped_indiv, indiv);
   if (d->ped_indiv && d->denovo_rate > theta)
     return pc_fail (d, "call_sites: de-novo mutation rate %g above theta %g (pecaller.c:381-385)", d->denovo_rate, theta);
   if (d->ped_indiv && (rc = pcs_ensure_ped (d, haploid ? 1 : 0)))
     return rc;
-  if (chrom_type)
-    PCCHK (d, hipMemcpyAsync (d->d_chromy, chrom_type, n_sites, hipMemcpyHostToDevice, d->stream));
-  else
-    PCCHK (d, hipMemsetAsync (d->d_chromy, 0, n_sites, d->stream));
   PcsParams P;
   P.indiv = indiv;
   P.haploid = haploid ? 1 : 0;
@@ -473,9 +497,30 @@ extern "C" int pecall_dev_call_sites (pecall_dev * d, const uint16_t * reads, co
   P.dyad = d->d_dyad;
   P.trio = d->d_trio;
   long grid = n_sites < d->site_grid ? n_sites : d->site_grid;
+  if (!d->ev_site[0])
+    {
+      PCCHK (d, hipEventCreate (&d->ev_site[0]));
+      PCCHK (d, hipEventCreate (&d->ev_site[1]));
+    }
+  PCCHK (d, hipEventRecord (d->ev_site[0], d->stream));
   hipLaunchKernelGGL (pcs_call_kernel, dim3 ((unsigned) grid), dim3 (64), 0, d->stream, P, d->d_sreads, d->d_dom, d->d_chromy, n_sites, d->d_call,
                       d->d_post, d->d_type, d->d_ac, d->d_npass, d->d_den, d->d_scratch);
   PCCHK (d, hipGetLastError ());
+  PCCHK (d, hipEventRecord (d->ev_site[1], d->stream));
+  PCCHK (d, hipStreamSynchronize (d->stream));
+  if (kernel_ms)
+    PCCHK (d, hipEventElapsedTime (kernel_ms, d->ev_site[0], d->ev_site[1]));
+  return 0;
+}
+
+extern "C" int pecall_dev_sites_collect (pecall_dev * d, int8_t * call, double *posterior, int8_t * site_type, int32_t * allele_count,
+                                         int8_t * n_pass, int32_t * denovo)
+{
+  PCCHK (d, hipSetDevice (d->device));
+  const long n_sites = d->staged_sites;
+  const long items = n_sites * d->staged_indiv;
+  if (n_sites <= 0)
+    return pc_fail (d, "sites_collect: nothing staged");
   PCCHK (d, hipMemcpyAsync (call, d->d_call, items, hipMemcpyDeviceToHost, d->stream));
   PCCHK (d, hipMemcpyAsync (posterior, d->d_post, items * sizeof (double), hipMemcpyDeviceToHost, d->stream));
   if (site_type)
@@ -488,4 +533,18 @@ extern "C" int pecall_dev_call_sites (pecall_dev * d, const uint16_t * reads, co
     PCCHK (d, hipMemcpyAsync (denovo, d->d_den, n_sites * sizeof (int32_t), hipMemcpyDeviceToHost, d->stream));
   PCCHK (d, hipStreamSynchronize (d->stream));
   return 0;
+}
+
+extern "C" int pecall_dev_call_sites (pecall_dev * d, const uint16_t * reads, const uint8_t * ref_base, const uint8_t * chrom_type, long n_sites,
+                                      int indiv, int haploid, double threshold, double theta, int8_t * call, double *posterior,
+                                      int8_t * site_type, int32_t * allele_count, int8_t * n_pass, int32_t * denovo)
+{
+  if (!(theta >= 1e-10 && theta <= 0.5))
+    return pc_fail (d, "call_sites: theta %g outside [1e-10, 0.5] (pecaller.c:305-309)", theta);
+  int rc = pecall_dev_sites_stage (d, reads, ref_base, chrom_type, n_sites, indiv);
+  if (!rc)
+    rc = pecall_dev_sites_run (d, haploid, threshold, theta, nullptr);
+  if (!rc)
+    rc = pecall_dev_sites_collect (d, call, posterior, site_type, allele_count, n_pass, denovo);
+  return rc;
 }

@@ -596,7 +596,7 @@ __device__ __forceinline__ uint8_t sy_comp (uint8_t c)
 // one thread per read end
 __global__ void sy_reads_kernel (uint64_t seed, const uint8_t * genome, uint64_t gsize, int n, int read_len, int paired,
                                  unsigned sub_thresh, unsigned indel_thresh, uint64_t first_read, uint8_t * reads1, int *len1,
-                                 uint8_t * reads2, int *len2, int stride)
+                                 uint8_t * reads2, int *len2, int stride, unsigned one_indel_thresh)
 {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   int ends = paired ? 2 * n : n;
@@ -616,10 +616,27 @@ __global__ void sy_reads_kernel (uint64_t seed, const uint8_t * genome, uint64_t
   const int64_t dir = endB ? -1 : 1;
   int k = 0;
   uint64_t salt = (uint64_t) t * 1315423911ull;
+  // one_indel_thresh (BASELINE config "5 % indel-enriched reads"): that share of the read-ends carries ONE insertion or deletion
+  // of 1..10 bases somewhere between base 20 and base read_len - 20, instead of the per-base indel rate
+  const uint64_t ih = sy_hash (seed ^ salt, 0x99, rn);
+  bool one_pending = one_indel_thresh && read_len > 60 && (unsigned) (ih & 0xFFFFFF) < one_indel_thresh;
+  const int one_pos = 20 + (int) ((ih >> 24) % (uint64_t) (read_len > 60 ? read_len - 40 : 1));
+  const int one_len = 1 + (int) ((ih >> 44) % 10);
+  const bool one_ins = (ih >> 60) & 1;
   while (k < read_len)
     {
       uint64_t mh = sy_hash (seed ^ salt, 0x77 + which, (uint64_t) k * 4 + (uint64_t) (cur & 3));
       unsigned r24 = (unsigned) (mh & 0xFFFFFF);
+      if (one_pending && k == one_pos)
+        {
+          one_pending = false;
+          if (one_ins)
+            for (int q = 0; q < one_len && k < read_len; q++)
+              dst[k++] = L[(sy_hash (seed ^ salt, 0x9a, (uint64_t) q) >> 30) & 3];
+          else
+            cur += dir * one_len;
+          continue;
+        }
       if (r24 < indel_thresh / 2)
         {
           dst[k++] = L[(mh >> 30) & 3];   // insertion

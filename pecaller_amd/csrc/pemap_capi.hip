@@ -36,13 +36,21 @@ struct PmRingSlot
   std::vector < hipEvent_t > ev_copy;   // one per slice: the slice's rows are on the device
 };
 
+// Page-locked host ranges.  HIP's registrations are process-wide and keyed by the pointer, so the table is too (one object
+// must not undo what another still copies from): a range pinned through pemap_dev_pin_host stays until its last unpin, ranges
+// the library registered on first use are dropped oldest first beyond 8.  A copy must lie inside ONE registration (a copy
+// that spans two adjacent ones is refused by the runtime: tools/micro/hostreg.hip), so a range that overlaps registered ones
+// replaces them by their union.
 struct PmPinned
 {
   char *base;
   size_t bytes;
-  bool by_user;                 // pemap_dev_pin_host (kept until unpin / destroy) or registered on first use (LRU)
+  int users;                    // pemap_dev_pin_host calls not yet undone; 0 = registered by the library on first use (LRU)
   unsigned long long last_use;
 };
+static std::mutex g_pin_mu;
+static std::vector < PmPinned > g_pinned;
+static unsigned long long g_pin_clock = 0;
 
 
 // Tuning knobs.  The environment is read ONCE, by pemap_dev_create, into the object: nothing below
@@ -195,8 +203,6 @@ struct pemap_dev
   unsigned long long ring_seq;
   hipStream_t stream_h2d, stream_d2h;
   hipEvent_t ev_batch_alu;
-  std::vector < PmPinned > pinned;
-  unsigned long long pin_clock;
   float last_ms[8];
   std::vector < uint8_t > h_ins;        // host copy of all insertion-log bytes so far
   long summary[13];
@@ -297,7 +303,6 @@ extern "C" int pemap_dev_create (pemap_dev ** out, int device_id)
   d->ring_seq = 0;
   d->stream_h2d = d->stream_d2h = nullptr;
   d->ev_batch_alu = nullptr;
-  d->pin_clock = 0;
   for (int i = 0; i < PM_RING; i++)
     {
       d->ring[i].active = false;
@@ -444,8 +449,6 @@ extern "C" void pemap_dev_destroy (pemap_dev * d)
       for (size_t k = 0; k < d->ring[i].ev_copy.size (); k++)
         hipEventDestroy (d->ring[i].ev_copy[k]);
     }
-  for (size_t i = 0; i < d->pinned.size (); i++)
-    (void) hipHostUnregister (d->pinned[i].base);
   if (d->stream_h2d)
     {
       hipStreamDestroy (d->stream_h2d);
@@ -1716,87 +1719,117 @@ static void fold_summary (pemap_dev * d, int first, int n, const uint32_t * m1, 
     }
 }
 
-// is [p, p + bytes) inside a pinned range?  (mu held)
-static bool pin_lookup (pemap_dev * d, const void *p, size_t bytes)
+// is [p, p + bytes) inside a pinned range?  (g_pin_mu held)
+static bool pin_lookup (const void *p, size_t bytes)
 {
   const char *c = (const char *) p;
-  for (size_t i = 0; i < d->pinned.size (); i++)
-    if (c >= d->pinned[i].base && c + bytes <= d->pinned[i].base + d->pinned[i].bytes)
+  for (size_t i = 0; i < g_pinned.size (); i++)
+    if (c >= g_pinned[i].base && c + bytes <= g_pinned[i].base + g_pinned[i].bytes)
       {
-        d->pinned[i].last_use = ++d->pin_clock;
+        g_pinned[i].last_use = ++g_pin_clock;
         return true;
       }
   return false;
 }
 
-// register a host range for DMA (mu held).  Ranges the library registered itself are dropped oldest first beyond 8.
-static bool pin_range (pemap_dev * d, const void *p, size_t bytes, bool by_user)
+// register a host range for DMA; by_user: on behalf of pemap_dev_pin_host.  Before a registration is dropped (merged into a
+// larger one, or the oldest of the library's own) the calling object's copy stream is drained: copies out of it may be queued.
+static bool pin_range (const void *p, size_t bytes, bool by_user, hipStream_t copy_stream)
 {
-  if (pin_lookup (d, p, bytes))
-    return true;
-  // a range that overlaps a registered one without being inside it (a buffer that grew in place): drop the old registration
-  const char *c = (const char *) p;
-  for (size_t i = 0; i < d->pinned.size ();)
-    if (c < d->pinned[i].base + d->pinned[i].bytes && d->pinned[i].base < c + bytes)
+  std::lock_guard < std::mutex > lk (g_pin_mu);
+  const size_t page = 4096;
+  char *lo = (char *) ((uintptr_t) p & ~(uintptr_t) (page - 1));
+  char *hi = (char *) (((uintptr_t) p + bytes + page - 1) & ~(uintptr_t) (page - 1));
+  int users = by_user ? 1 : 0;
+  for (size_t i = 0; i < g_pinned.size (); i++)
+    if (lo >= g_pinned[i].base && hi <= g_pinned[i].base + g_pinned[i].bytes)
       {
-        (void) hipHostUnregister (d->pinned[i].base);
-        d->pinned.erase (d->pinned.begin () + i);
+        g_pinned[i].last_use = ++g_pin_clock;
+        g_pinned[i].users += users;
+        return true;
+      }
+  // registered ranges that share pages with the new one are replaced by the union of all of them
+  for (size_t i = 0; i < g_pinned.size ();)
+    if (lo < g_pinned[i].base + g_pinned[i].bytes && g_pinned[i].base < hi)
+      {
+        if (g_pinned[i].base < lo)
+          lo = g_pinned[i].base;
+        if (g_pinned[i].base + g_pinned[i].bytes > hi)
+          hi = g_pinned[i].base + g_pinned[i].bytes;
+        users += g_pinned[i].users;
+        if (copy_stream)
+          (void) hipStreamSynchronize (copy_stream);
+        (void) hipHostUnregister (g_pinned[i].base);
+        (void) hipGetLastError ();
+        g_pinned.erase (g_pinned.begin () + i);
       }
     else
       i++;
-  if (hipHostRegister ((void *) p, bytes, hipHostRegisterDefault) != hipSuccess)
+  if (hipHostRegister (lo, (size_t) (hi - lo), hipHostRegisterDefault) != hipSuccess)
     {
       (void) hipGetLastError ();
       return false;
     }
   PmPinned e;
-  e.base = (char *) p;
-  e.bytes = bytes;
-  e.by_user = by_user;
-  e.last_use = ++d->pin_clock;
-  d->pinned.push_back (e);
-  int own = 0;
-  for (size_t i = 0; i < d->pinned.size (); i++)
-    own += d->pinned[i].by_user ? 0 : 1;
-  while (own > 8)
+  e.base = lo;
+  e.bytes = (size_t) (hi - lo);
+  e.users = users;
+  e.last_use = ++g_pin_clock;
+  g_pinned.push_back (e);
+  for (;;)
     {
-      size_t victim = d->pinned.size ();
-      for (size_t i = 0; i < d->pinned.size (); i++)
-        if (!d->pinned[i].by_user && (victim == d->pinned.size () || d->pinned[i].last_use < d->pinned[victim].last_use))
-          victim = i;
-      (void) hipHostUnregister (d->pinned[victim].base);
-      d->pinned.erase (d->pinned.begin () + victim);
-      own--;
+      int own = 0;
+      size_t victim = g_pinned.size ();
+      for (size_t i = 0; i < g_pinned.size (); i++)
+        if (g_pinned[i].users == 0)
+          {
+            own++;
+            if (victim == g_pinned.size () || g_pinned[i].last_use < g_pinned[victim].last_use)
+              victim = i;
+          }
+      if (own <= 8)
+        break;
+      if (copy_stream)
+        (void) hipStreamSynchronize (copy_stream);
+      (void) hipHostUnregister (g_pinned[victim].base);
+      (void) hipGetLastError ();
+      g_pinned.erase (g_pinned.begin () + victim);
     }
   return true;
 }
 
 extern "C" int pemap_dev_pin_host (pemap_dev * d, const void *host_ptr, uint64_t n_bytes)
 {
-  std::lock_guard < std::mutex > lk (d->mu);
   HIPCHK (d, hipSetDevice (d->device));
   if (!host_ptr || !n_bytes)
     return fail (d, "pin_host: empty range");
-  if (!pin_range (d, host_ptr, (size_t) n_bytes, true))
+  if (!pin_range (host_ptr, (size_t) n_bytes, true, d->stream_h2d))
     return fail (d, "pin_host: hipHostRegister of %llu bytes failed", (unsigned long long) n_bytes);
   return 0;
 }
 
 extern "C" int pemap_dev_unpin_host (pemap_dev * d, const void *host_ptr)
 {
-  std::lock_guard < std::mutex > lk (d->mu);
   HIPCHK (d, hipSetDevice (d->device));
-  for (size_t i = 0; i < d->pinned.size (); i++)
-    if (d->pinned[i].base == (const char *) host_ptr)
+  // copies out of the range may still be queued on this object's copy stream
+  {
+    std::lock_guard < std::mutex > lk (d->mu);
+    if (d->stream_h2d)
+      HIPCHK (d, hipStreamSynchronize (d->stream_h2d));
+  }
+  std::lock_guard < std::mutex > lk (g_pin_mu);
+  const char *c = (const char *) host_ptr;
+  for (size_t i = 0; i < g_pinned.size (); i++)
+    if (c >= g_pinned[i].base && c < g_pinned[i].base + g_pinned[i].bytes && g_pinned[i].users > 0)
       {
-        // copies out of the range may still be queued
-        if (d->stream_h2d)
-          HIPCHK (d, hipStreamSynchronize (d->stream_h2d));
-        HIPCHK (d, hipHostUnregister (d->pinned[i].base));
-        d->pinned.erase (d->pinned.begin () + i);
+        if (--g_pinned[i].users == 0)
+          {
+            HIPCHK (d, hipHostUnregister (g_pinned[i].base));
+            g_pinned.erase (g_pinned.begin () + i);
+          }
         return 0;
       }
-  return fail (d, "unpin_host: %p was not pinned through this object", host_ptr);
+  return fail (d, "unpin_host: %p is not inside a range pinned through pemap_dev_pin_host", host_ptr);
 }
 
 // wait for the batch in `slot` and deliver it (mu held through lk; released while the host blocks on the event)
@@ -1940,9 +1973,9 @@ extern "C" int pemap_dev_submit_batch (pemap_dev * d, const char *reads1, const 
   // the rows move by DMA straight out of the caller's buffers: pinned by the caller, or registered here on first sight (a caller
   // that reuses its batch buffers, as the reference does, pays that once); when registration is refused the copy still works
   // (staged by the runtime, slower)
-  (void) pin_range (d, reads1, (size_t) n * stride, false);
+  (void) pin_range (reads1, (size_t) n * stride, false, d->stream_h2d);
   if (d->paired)
-    (void) pin_range (d, reads2, (size_t) n * stride, false);
+    (void) pin_range (reads2, (size_t) n * stride, false, d->stream_h2d);
   const int slice = d->kn.chunk_pairs > 0 ? d->kn.chunk_pairs : 131072;
   const int n_slices = (n + slice - 1) / slice;
   if (!d->stream2)
@@ -2257,8 +2290,23 @@ extern "C" int pemap_dev_free (pemap_dev * d, void *d_ptr)
   return 0;
 }
 
+static int synth_reads (pemap_dev * d, uint64_t seed, int n, int read_len, int paired, double sub_rate, double indel_rate, double one_indel_frac,
+                        uint64_t first_read);
+
 extern "C" int pemap_dev_synth_reads (pemap_dev * d, uint64_t seed, int n, int read_len, int paired, double sub_rate,
                                       double indel_rate, uint64_t first_read)
+{
+  return synth_reads (d, seed, n, read_len, paired, sub_rate, indel_rate, 0.0, first_read);
+}
+
+extern "C" int pemap_dev_synth_reads_indel (pemap_dev * d, uint64_t seed, int n, int read_len, int paired, double sub_rate,
+                                            double indel_read_frac, uint64_t first_read)
+{
+  return synth_reads (d, seed, n, read_len, paired, sub_rate, 0.0, indel_read_frac, first_read);
+}
+
+static int synth_reads (pemap_dev * d, uint64_t seed, int n, int read_len, int paired, double sub_rate, double indel_rate, double one_indel_frac,
+                        uint64_t first_read)
 {
   HIPCHK (d, hipSetDevice (d->device));
   if (!d->index_ready)
@@ -2275,7 +2323,7 @@ extern "C" int pemap_dev_synth_reads (pemap_dev * d, uint64_t seed, int n, int r
   int ends = paired ? 2 * n : n;
   hipLaunchKernelGGL (sy_reads_kernel, dim3 ((ends + 255) / 256), dim3 (256), 0, d->stream, seed, d->d_genome, d->gsize, n, read_len, paired,
                       (unsigned) (sub_rate * 16777216.0), (unsigned) (indel_rate * 16777216.0), first_read, d->d_reads1, d->d_len1,
-                      d->d_reads2, d->d_len2, stride);
+                      d->d_reads2, d->d_len2, stride, (unsigned) (one_indel_frac * 16777216.0));
   HIPCHK (d, hipStreamSynchronize (d->stream));
   d->h_len1.assign (n, read_len);
   if (paired)

@@ -40,19 +40,34 @@ def _chunks(t, chunk):
         yield t[o:min(n, o + chunk)]
 
 
+def _host_bounce(dist, t):
+    """gloo moves host memory only: a device tensor goes through a host copy (rehearsals of several ranks on one GPU);
+    RCCL ("nccl") works on the device buffers directly"""
+    return t.is_cuda and dist.get_backend() != "nccl"
+
+
 def broadcast_tensors(dist, tensors, src=0, chunk=1 << 28):
     for t in tensors:
         for c in _chunks(t, chunk):
-            dist.broadcast(c, src=src)
+            if _host_bounce(dist, c):
+                h = c.cpu()
+                dist.broadcast(h, src=src)
+                if dist.get_rank() != src:
+                    c.copy_(h)
+            else:
+                dist.broadcast(c, src=src)
 
 
 def reduce_pileup(dist, counts, dst=None, chunk=1 << 28):
     """in-place sum of the int32-viewed counters over all ranks (all_reduce, or reduce to `dst`)"""
     for c in _chunks(counts.view(-1), chunk):
+        h = c.cpu() if _host_bounce(dist, c) else c
         if dst is None:
-            dist.all_reduce(c, op=dist.ReduceOp.SUM)
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
         else:
-            dist.reduce(c, dst=dst, op=dist.ReduceOp.SUM)
+            dist.reduce(h, dst=dst, op=dist.ReduceOp.SUM)
+        if h is not c:
+            c.copy_(h)
     return counts
 
 
@@ -63,7 +78,10 @@ def counts_to_u16(counts_i32):
 
 
 def merge_summaries(dist, torch, summary13):
-    """scalar totals and class histogram are plain sums over ranks (pemapper.c:1238-1265)"""
+    """scalar totals and class histogram are plain sums over ranks (pemapper.c:1238-1265).  RCCL has no host tensors: under
+    "nccl" the 13 numbers travel through the device."""
     t = torch.as_tensor(np.asarray(summary13, dtype=np.int64))
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return t.numpy()
+    return t.cpu().numpy()

@@ -26,6 +26,9 @@ class PecallDev:
         L.pecall_dev_collect.argtypes = [vp, i, i, vp, vp, vp]
         L.pecall_dev_call_sites.argtypes = [vp, vp, vp, vp, C.c_long, i, i, dbl, dbl, vp, vp, vp, vp, vp, vp]
         L.pecall_dev_set_pedigree.argtypes = [vp, i, vp, vp, vp, vp, vp, dbl]
+        L.pecall_dev_sites_stage.argtypes = [vp, vp, vp, vp, C.c_long, i]
+        L.pecall_dev_sites_run.argtypes = [vp, i, dbl, dbl, C.POINTER(C.c_float)]
+        L.pecall_dev_sites_collect.argtypes = [vp, vp, vp, vp, vp, vp, vp]
         self.L = L
         h = vp()
         if L.pecall_dev_create(C.byref(h), device_id):
@@ -80,6 +83,30 @@ class PecallDev:
             return
         a = [np.ascontiguousarray(x, np.int32) for x in (dad, mom, sex, kid_off, kid_list)]
         self._ck(self.L.pecall_dev_set_pedigree(self.h, len(a[0]), _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(a[4]), float(denovo_rate)))
+
+    def sites_stage(self, reads, ref_base, chrom=None):
+        reads = np.ascontiguousarray(reads, np.uint16)
+        ref_base = np.ascontiguousarray(ref_base, np.uint8)
+        cy = None if chrom is None else np.ascontiguousarray(chrom, np.uint8)
+        self._sshape = reads.shape[:2]
+        self._ck(self.L.pecall_dev_sites_stage(self.h, _p(reads), _p(ref_base), _p(cy), reads.shape[0], reads.shape[1]))
+
+    def sites_run(self, threshold=0.95, theta=0.001, haploid=False):
+        """the kernel on the staged columns -> its duration in ms (HIP events on the object's stream)"""
+        ms = C.c_float(0)
+        self._ck(self.L.pecall_dev_sites_run(self.h, int(haploid), float(threshold), float(theta), C.byref(ms)))
+        return ms.value
+
+    def sites_collect(self):
+        n_sites, indiv = self._sshape
+        call = np.zeros((n_sites, indiv), np.int8)
+        post = np.zeros((n_sites, indiv))
+        typ = np.zeros(n_sites, np.int8)
+        ac = np.zeros((n_sites, ALLELES), np.int32)
+        npass = np.zeros(n_sites, np.int8)
+        self.denovo = np.zeros(n_sites, np.int32)
+        self._ck(self.L.pecall_dev_sites_collect(self.h, _p(call), _p(post), _p(typ), _p(ac), _p(npass), _p(self.denovo)))
+        return call, post, typ, ac, npass
 
     def call_sites(self, reads, ref_base, threshold=0.95, theta=0.001, haploid=False, chrom=None):
         """the whole per-site caller (pecaller.c:1207-1691): reads [n_sites][indiv][6] u16, ref_base [n_sites] (0..3 = ACGT, else

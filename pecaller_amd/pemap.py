@@ -19,11 +19,12 @@ SYMBOLS = [
     "pemap_dev_index_info", "pemap_dev_read_buffer", "pemap_dev_set_params", "pemap_dev_map_batch",
     "pemap_dev_submit_batch", "pemap_dev_wait_batch", "pemap_dev_pin_host", "pemap_dev_unpin_host",
     "pemap_dev_stage_reads", "pemap_dev_run", "pemap_dev_run_slice", "pemap_dev_collect", "pemap_dev_sync",
-    "pemap_dev_synth_genome", "pemap_dev_synth_reads", "pemap_dev_staged_reads", "pemap_dev_staged_info",
+    "pemap_dev_synth_genome", "pemap_dev_synth_reads", "pemap_dev_synth_reads_indel", "pemap_dev_staged_reads", "pemap_dev_staged_info",
     "pemap_dev_free", "pemap_dev_fetch_pileup", "pemap_dev_fetch_records", "pemap_dev_reset_pileup", "pemap_dev_summary",
     "pemap_dev_run_stats", "pemap_dev_debug_hits",
     "pecall_dev_create", "pecall_dev_destroy", "pecall_dev_last_error", "pecall_dev_site_like", "pecall_dev_stage",
     "pecall_dev_run", "pecall_dev_collect", "pecall_dev_call_sites", "pecall_dev_set_pedigree",
+    "pecall_dev_sites_stage", "pecall_dev_sites_run", "pecall_dev_sites_collect",
 ]
 
 PILE_DT = np.dtype([("pos", "<u4"), ("c", "<u2", (6,))])
@@ -72,6 +73,7 @@ def load_library():
         L.pemap_dev_sync.argtypes = [vp]
         L.pemap_dev_synth_genome.argtypes = [vp, u64, u64, i, dbl, C.POINTER(vp), vp]
         L.pemap_dev_synth_reads.argtypes = [vp, u64, i, i, i, dbl, dbl, u64]
+        L.pemap_dev_synth_reads_indel.argtypes = [vp, u64, i, i, i, dbl, dbl, u64]
         L.pemap_dev_staged_reads.argtypes = [vp, vp, vp, vp, vp, i]
         L.pemap_dev_staged_info.argtypes = [vp, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
         L.pemap_dev_free.argtypes = [vp, vp]
@@ -242,6 +244,11 @@ class PemapDev:
     def synth_reads(self, seed, n, read_len, paired=True, sub_rate=0.01, indel_rate=0.0002, first_read=0):
         self.paired = bool(paired)
         self._ck(self.L.pemap_dev_synth_reads(self.h, seed, n, read_len, int(paired), sub_rate, indel_rate, first_read))
+        self._n = n
+
+    def synth_reads_indel(self, seed, n, read_len, paired=True, sub_rate=0.01, indel_read_frac=0.05, first_read=0):
+        self.paired = bool(paired)
+        self._ck(self.L.pemap_dev_synth_reads_indel(self.h, seed, n, read_len, int(paired), sub_rate, indel_read_frac, first_read))
         self._n = n
 
     def staged_info(self):

@@ -28,6 +28,8 @@ for ctr, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
             if r["Counter_Name"] == ctr:
                 acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
     out[ctr] = {k: {"launches": len(v), "mean_KB_per_launch": sum(v) / len(v), "max_KB": max(v)}
-                for k, v in acc.items() if k.startswith(("pm_", "pile_", "ix_"))}
+                for k, v in acc.items() if k.startswith(("pm_", "pile_", "ix_", "pcs_", "pc_"))}
+if len(sys.argv) > 2:
+    out["steps"] = int(sys.argv[2])     # steps of the main configuration the profiled command ran (for per-step totals)
 json.dump(out, open(os.path.join(d, "pmc.json"), "w"), indent=1)
 print("wrote", os.path.join(d, "pmc.json"), {k: len(v) for k, v in out.items()})

@@ -7,12 +7,12 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu --no-secondary > $OUT/stats.log 2>&1
 echo "stats pass done"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu > $OUT/fetch.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu --no-secondary --no-pecaller > $OUT/fetch.log 2>&1
 echo "FETCH_SIZE pass done"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu > $OUT/write.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu --no-secondary --no-pecaller > $OUT/write.log 2>&1
 echo "WRITE_SIZE pass done"
 cd $ROOT
-python3 tools/pmc_summary.py $OUT
+python3 tools/pmc_summary.py $OUT 6    # (2 timed + 1 warm-up) steps at the seam + the same resident
 tail -1 $OUT/stats.log | cut -c1-400
