@@ -356,7 +356,7 @@ def main():
             ks = sec_leg["steps"]
             sdt = sec_leg["resident_dt"]
             rec["secondary"] = {
-                "config": "pemapper_tsw path: 2x250bp reads trimmed 3/2 (245-base rows at the seam), 5% of the read-ends with one 1..10-base "
+                "config": "pemapper_tsw path: 2x250bp reads trimmed 3/2 (245-base rows at the seam), 5%% of the read-ends with one 1..10-base "
                           "indel, %d pairs per step, same index" % B,
                 "value": round(world * ks * reads_per_step / sdt / 1e6, 4), "unit": "M reads/s", "steps": ks, "ms_per_step": round(sdt / ks * 1e3, 3),
                 "timed_region": "reads resident in HBM",

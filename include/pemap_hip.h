@@ -122,9 +122,10 @@ int pemap_dev_map_batch (pemap_dev * dev, const char *reads1, const int *len1, c
 int pemap_dev_submit_batch (pemap_dev * dev, const char *reads1, const int *len1, const char *reads2, const int *len2,
                             int n, int stride, uint32_t * m1, uint32_t * m2, int *mapping_type, uint64_t * ticket);
 int pemap_dev_wait_batch (pemap_dev * dev, uint64_t ticket);
-/* Optional: page-lock a host range that read rows will be submitted from (the reference allocates its batch buffers once,
- * pd_node_alloc at pemapper.c:2340-2372, and reuses them: pin them once after that).  Rows submitted from other memory are
- * registered on first sight (the last 8 such ranges are kept), which costs about a millisecond per 4 MB the first time. */
+/* Optional: page-lock a host range that read rows will be submitted from, so that they move by DMA straight out of it (the
+ * reference allocates its batch buffers once, pd_node_alloc at pemapper.c:2340-2372, and reuses them: pin them once after
+ * that, unpin before freeing them).  Rows submitted from memory that is not pinned are first copied into a pinned staging
+ * buffer of the library (a few host threads, ~10 ms per million pairs).  The library never page-locks caller memory by itself. */
 int pemap_dev_pin_host (pemap_dev * dev, const void *host_ptr, uint64_t n_bytes);
 int pemap_dev_unpin_host (pemap_dev * dev, const void *host_ptr);
 

@@ -9,6 +9,7 @@
 #include <unistd.h>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <vector>
 #include "../../include/pemap_hip.h"
 #include "pemap_kernels.hip.h"
@@ -32,25 +33,25 @@ struct PmRingSlot
   int *mt;
   int *h_len;                   // pinned: len1 | len2
   uint32_t *h_res;              // pinned: m1 | m2 | mapping_type
+  char *h_rows;                 // pinned staging for read rows submitted from pageable memory: reads1 | reads2 (allocated on first need)
+  size_t h_rows_bytes;
   hipEvent_t ev_done;           // recorded behind the device-to-host copy of the results
   std::vector < hipEvent_t > ev_copy;   // one per slice: the slice's rows are on the device
 };
 
-// Page-locked host ranges.  HIP's registrations are process-wide and keyed by the pointer, so the table is too (one object
-// must not undo what another still copies from): a range pinned through pemap_dev_pin_host stays until its last unpin, ranges
-// the library registered on first use are dropped oldest first beyond 8.  A copy must lie inside ONE registration (a copy
-// that spans two adjacent ones is refused by the runtime: tools/micro/hostreg.hip), so a range that overlaps registered ones
-// replaces them by their union.
+// Host ranges page-locked through pemap_dev_pin_host.  HIP's registrations are process-wide and keyed by the pointer, so the
+// table is too (one object must not undo what another still copies from); a range stays until its last unpin.  The library
+// never registers memory on its own: a registration outlives the buffer it was made for, and any later copy of the process
+// that touches part of such a stale range is refused by the runtime (a copy must lie inside ONE registration or outside all:
+// tools/micro/hostreg.hip).  Rows submitted from memory that is not pinned go through the slot's own pinned staging buffer.
 struct PmPinned
 {
   char *base;
   size_t bytes;
-  int users;                    // pemap_dev_pin_host calls not yet undone; 0 = registered by the library on first use (LRU)
-  unsigned long long last_use;
+  int users;                    // pemap_dev_pin_host calls not yet undone
 };
 static std::mutex g_pin_mu;
 static std::vector < PmPinned > g_pinned;
-static unsigned long long g_pin_clock = 0;
 
 
 // Tuning knobs.  The environment is read ONCE, by pemap_dev_create, into the object: nothing below
@@ -309,6 +310,8 @@ extern "C" int pemap_dev_create (pemap_dev ** out, int device_id)
       d->ring[i].seq = 0;
       d->ring[i].h_len = nullptr;
       d->ring[i].h_res = nullptr;
+      d->ring[i].h_rows = nullptr;
+      d->ring[i].h_rows_bytes = 0;
       d->ring[i].ev_done = nullptr;
     }
   memset (&d->last_ctr, 0, sizeof (d->last_ctr));
@@ -444,6 +447,8 @@ extern "C" void pemap_dev_destroy (pemap_dev * d)
         hipHostFree (d->ring[i].h_len);
       if (d->ring[i].h_res)
         hipHostFree (d->ring[i].h_res);
+      if (d->ring[i].h_rows)
+        hipHostFree (d->ring[i].h_rows);
       if (d->ring[i].ev_done)
         hipEventDestroy (d->ring[i].ev_done);
       for (size_t k = 0; k < d->ring[i].ev_copy.size (); k++)
@@ -1719,36 +1724,33 @@ static void fold_summary (pemap_dev * d, int first, int n, const uint32_t * m1, 
     }
 }
 
-// is [p, p + bytes) inside a pinned range?  (g_pin_mu held)
+// is [p, p + bytes) inside a range pinned by the caller?
 static bool pin_lookup (const void *p, size_t bytes)
 {
+  std::lock_guard < std::mutex > lk (g_pin_mu);
   const char *c = (const char *) p;
   for (size_t i = 0; i < g_pinned.size (); i++)
     if (c >= g_pinned[i].base && c + bytes <= g_pinned[i].base + g_pinned[i].bytes)
-      {
-        g_pinned[i].last_use = ++g_pin_clock;
-        return true;
-      }
+      return true;
   return false;
 }
 
-// register a host range for DMA; by_user: on behalf of pemap_dev_pin_host.  Before a registration is dropped (merged into a
-// larger one, or the oldest of the library's own) the calling object's copy stream is drained: copies out of it may be queued.
-static bool pin_range (const void *p, size_t bytes, bool by_user, hipStream_t copy_stream)
+// register a host range for DMA on behalf of pemap_dev_pin_host.  Registered ranges that share pages with the new one are
+// replaced by the union of all of them (a copy must lie inside one registration); the calling object's copy stream is drained
+// before a registration is dropped, copies out of it may be queued.
+static bool pin_range (const void *p, size_t bytes, hipStream_t copy_stream)
 {
   std::lock_guard < std::mutex > lk (g_pin_mu);
   const size_t page = 4096;
   char *lo = (char *) ((uintptr_t) p & ~(uintptr_t) (page - 1));
   char *hi = (char *) (((uintptr_t) p + bytes + page - 1) & ~(uintptr_t) (page - 1));
-  int users = by_user ? 1 : 0;
+  int users = 1;
   for (size_t i = 0; i < g_pinned.size (); i++)
     if (lo >= g_pinned[i].base && hi <= g_pinned[i].base + g_pinned[i].bytes)
       {
-        g_pinned[i].last_use = ++g_pin_clock;
-        g_pinned[i].users += users;
+        g_pinned[i].users++;
         return true;
       }
-  // registered ranges that share pages with the new one are replaced by the union of all of them
   for (size_t i = 0; i < g_pinned.size ();)
     if (lo < g_pinned[i].base + g_pinned[i].bytes && g_pinned[i].base < hi)
       {
@@ -1774,28 +1776,29 @@ static bool pin_range (const void *p, size_t bytes, bool by_user, hipStream_t co
   e.base = lo;
   e.bytes = (size_t) (hi - lo);
   e.users = users;
-  e.last_use = ++g_pin_clock;
   g_pinned.push_back (e);
-  for (;;)
-    {
-      int own = 0;
-      size_t victim = g_pinned.size ();
-      for (size_t i = 0; i < g_pinned.size (); i++)
-        if (g_pinned[i].users == 0)
-          {
-            own++;
-            if (victim == g_pinned.size () || g_pinned[i].last_use < g_pinned[victim].last_use)
-              victim = i;
-          }
-      if (own <= 8)
-        break;
-      if (copy_stream)
-        (void) hipStreamSynchronize (copy_stream);
-      (void) hipHostUnregister (g_pinned[victim].base);
-      (void) hipGetLastError ();
-      g_pinned.erase (g_pinned.begin () + victim);
-    }
   return true;
+}
+
+// host copy into a pinned staging buffer, on a few threads when it is large (one core moves ~10 GB/s: 330 MB per million pairs)
+static void par_memcpy (char *dst, const char *src, size_t bytes)
+{
+  const size_t piece = (size_t) 4 << 20;
+  if (bytes < 2 * piece)
+    {
+      memcpy (dst, src, bytes);
+      return;
+    }
+  const int nt = 4;
+  std::thread th[nt];
+  const size_t per = ((bytes / nt) + 63) & ~(size_t) 63;
+  for (int t = 0; t < nt; t++)
+    {
+      const size_t o = per * t, m = o >= bytes ? 0 : (bytes - o < per ? bytes - o : per);
+      th[t] = std::thread ([=] { if (m) memcpy (dst + o, src + o, m); });
+    }
+  for (int t = 0; t < nt; t++)
+    th[t].join ();
 }
 
 extern "C" int pemap_dev_pin_host (pemap_dev * d, const void *host_ptr, uint64_t n_bytes)
@@ -1803,7 +1806,7 @@ extern "C" int pemap_dev_pin_host (pemap_dev * d, const void *host_ptr, uint64_t
   HIPCHK (d, hipSetDevice (d->device));
   if (!host_ptr || !n_bytes)
     return fail (d, "pin_host: empty range");
-  if (!pin_range (host_ptr, (size_t) n_bytes, true, d->stream_h2d))
+  if (!pin_range (host_ptr, (size_t) n_bytes, d->stream_h2d))
     return fail (d, "pin_host: hipHostRegister of %llu bytes failed", (unsigned long long) n_bytes);
   return 0;
 }
@@ -1914,6 +1917,10 @@ static int ring_setup (pemap_dev * d, int n, int stride, std::unique_lock < std:
         hipHostFree (r.h_res);
       r.h_len = nullptr;
       r.h_res = nullptr;
+      if (r.h_rows)
+        hipHostFree (r.h_rows);
+      r.h_rows = nullptr;
+      r.h_rows_bytes = 0;
       HIPCHK (d, hipHostMalloc ((void **) &r.h_len, (size_t) cap * 2 * sizeof (int), hipHostMallocDefault));
       HIPCHK (d, hipHostMalloc ((void **) &r.h_res, (size_t) cap * 3 * sizeof (uint32_t), hipHostMallocDefault));
       if (!r.ev_done)
@@ -1970,12 +1977,23 @@ extern "C" int pemap_dev_submit_batch (pemap_dev * d, const char *reads1, const 
       memcpy (r.h_len + d->ring_cap, len2, (size_t) n * sizeof (int));
       HIPCHK (d, hipMemcpyAsync (d->d_len2 + first, r.h_len + d->ring_cap, (size_t) n * sizeof (int), hipMemcpyHostToDevice, d->stream_h2d));
     }
-  // the rows move by DMA straight out of the caller's buffers: pinned by the caller, or registered here on first sight (a caller
-  // that reuses its batch buffers, as the reference does, pays that once); when registration is refused the copy still works
-  // (staged by the runtime, slower)
-  (void) pin_range (reads1, (size_t) n * stride, false, d->stream_h2d);
-  if (d->paired)
-    (void) pin_range (reads2, (size_t) n * stride, false, d->stream_h2d);
+  // the rows move by DMA straight out of the caller's buffers when the caller pinned them (pemap_dev_pin_host); otherwise they
+  // are copied, slice by slice, into the slot's pinned staging buffer first (the DMA of slice k runs beside the host copy of k + 1)
+  const bool direct1 = pin_lookup (reads1, (size_t) n * stride);
+  const bool direct2 = d->paired ? pin_lookup (reads2, (size_t) n * stride) : true;
+  if (!direct1 || !direct2)
+    {
+      const size_t need = (size_t) d->ring_cap * stride * 2;
+      if (r.h_rows_bytes < need)
+        {
+          if (r.h_rows)
+            hipHostFree (r.h_rows);
+          r.h_rows = nullptr;
+          r.h_rows_bytes = 0;
+          HIPCHK (d, hipHostMalloc ((void **) &r.h_rows, need, hipHostMallocDefault));
+          r.h_rows_bytes = need;
+        }
+    }
   const int slice = d->kn.chunk_pairs > 0 ? d->kn.chunk_pairs : 131072;
   const int n_slices = (n + slice - 1) / slice;
   if (!d->stream2)
@@ -1996,11 +2014,22 @@ extern "C" int pemap_dev_submit_batch (pemap_dev * d, const char *reads1, const 
   for (int k = 0, off = 0; off < n; off += slice, k++)
     {
       const int m = n - off < slice ? n - off : slice;
-      HIPCHK (d, hipMemcpyAsync (d->d_reads1 + (size_t) (first + off) * stride, reads1 + (size_t) off * stride, (size_t) m * stride,
-                                 hipMemcpyHostToDevice, d->stream_h2d));
+      const char *src1 = reads1 + (size_t) off * stride, *src2 = d->paired ? reads2 + (size_t) off * stride : nullptr;
+      if (!direct1)
+        {
+          char *stg = r.h_rows + (size_t) off * stride;
+          par_memcpy (stg, src1, (size_t) m * stride);
+          src1 = stg;
+        }
+      if (d->paired && !direct2)
+        {
+          char *stg = r.h_rows + ((size_t) d->ring_cap + off) * stride;
+          par_memcpy (stg, src2, (size_t) m * stride);
+          src2 = stg;
+        }
+      HIPCHK (d, hipMemcpyAsync (d->d_reads1 + (size_t) (first + off) * stride, src1, (size_t) m * stride, hipMemcpyHostToDevice, d->stream_h2d));
       if (d->paired)
-        HIPCHK (d, hipMemcpyAsync (d->d_reads2 + (size_t) (first + off) * stride, reads2 + (size_t) off * stride, (size_t) m * stride,
-                                   hipMemcpyHostToDevice, d->stream_h2d));
+        HIPCHK (d, hipMemcpyAsync (d->d_reads2 + (size_t) (first + off) * stride, src2, (size_t) m * stride, hipMemcpyHostToDevice, d->stream_h2d));
       HIPCHK (d, hipEventRecord (r.ev_copy[k], d->stream_h2d));
       // whichever stream touches the slice's rows first (the look-ups on the memory stream, the seed kernel on the ALU stream)
       HIPCHK (d, hipStreamWaitEvent (d->stream, r.ev_copy[k], 0));

@@ -242,7 +242,7 @@ def test_batches_in_flight_equal_one_call(dev):
     dev.set_params(paired=True, min_dist=0, max_dist=500, min_align=0.85)
     cuts = [0, 3000, 3001, 9000, 12000, 16500, 20000]
     dev.reset_pileup()
-    dev.pin_host(r1)                   # one buffer pinned by the caller, the other registered by the library on first use
+    dev.pin_host(r1)                   # one buffer pinned by the caller (DMA straight out of it), the other staged by the library
     tickets = []
     for a, b in zip(cuts[:-1], cuts[1:]):
         tickets.append((a, b, dev.submit_batch(r1[a:b], l1[a:b], r2[a:b], l2[a:b])))
