@@ -172,6 +172,7 @@ struct pemap_dev
   uint32_t *d_seed_scratch;
   uint32_t *d_dirbuf;
   size_t dirbuf_dwords;
+  size_t dir_slabs;             // slabs d_dirbuf holds for the staged read length; the last one is the dump slab of task-less lane groups
   uint8_t *d_ins_log;
   unsigned ins_cap;
   int seed_grid, sw_grid;
@@ -971,6 +972,7 @@ static int ensure_work (pemap_dev * d, int n_ends, bool two_sets)
         TRY (dev_alloc (d, &d->d_dirbuf2, need));
       d->dirbuf_dwords = need;
     }
+  d->dir_slabs = d->dirbuf_dwords / slab_dwords_for (d, d->max_len_staged);
   // recorded traceback steps: PM_PATH_WORDS words of 32 two-bit steps per read-end
   const int pwords = PM_PATH_WORDS (d->max_len_staged);
   if (!d->d_path || n_ends > d->path_cap_ends || pwords != d->path_words || (two_sets && !d->d_path2))
@@ -1418,7 +1420,31 @@ static int ensure_pipeline (pemap_dev * d, int chunk_ends)
   return 0;
 }
 
-static int run_slice (pemap_dev * d, int first, int n, int sync)
+// chunk size run_slice cuts a run of n pairs of reads up to L bases into
+static int chunk_pairs_for (const pemap_dev * d, int n, int L, bool split)
+{
+  const int per = d->paired ? 2 : 1;
+  // one direction slab per read-end must fit the budget; the pipeline wants several chunks per run
+  size_t slab_bytes = slab_dwords_for (d, L) * 4;
+  long max_ends = (long) (dir_budget_bytes (d) / slab_bytes);
+  if (max_ends > 20000000)
+    max_ends = 20000000;        // task ids are end * 200 + hit in 32 bits
+  int chunk = (int) (max_ends / per);
+  const int want = d->kn.chunk_pairs;
+  if (split && want > 0 && chunk > want)
+    chunk = want;
+  if (chunk < 1)
+    chunk = 1;
+  if (chunk > n)
+    chunk = n;
+  if ((n + chunk - 1) / chunk > PM_MAX_CHUNKS)
+    chunk = (n + PM_MAX_CHUNKS - 1) / PM_MAX_CHUNKS;
+  return chunk;
+}
+
+// copy_evs (may be NULL): one event per chunk, recorded behind the host-to-device copy of that chunk's rows; the first stream
+// that touches the rows waits for it
+static int run_slice (pemap_dev * d, int first, int n, int sync, const hipEvent_t * copy_evs = nullptr)
 {
   HIPCHK (d, hipSetDevice (d->device));
   if (!d->index_ready)
@@ -1455,21 +1481,7 @@ static int run_slice (pemap_dev * d, int first, int n, int sync)
       for (int i = 0; i < 2; i++)
         HIPCHK (d, hipEventCreateWithFlags (&d->ev_lookup_done[i], hipEventDisableTiming));
     }
-  // chunk: one direction slab per read-end must fit the budget; the two-stream pipeline wants several chunks per run
-  size_t slab_bytes = slab_dwords_for (d, L) * 4;
-  long max_ends = (long) (dir_budget_bytes (d) / slab_bytes);
-  if (max_ends > 20000000)
-    max_ends = 20000000;        // task ids are end * 200 + hit in 32 bits
-  int chunk = (int) (max_ends / per);
-  const int want = d->kn.chunk_pairs;
-  if (split && want > 0 && chunk > want)
-    chunk = want;
-  if (chunk < 1)
-    chunk = 1;
-  if (chunk > n)
-    chunk = n;
-  if ((n + chunk - 1) / chunk > PM_MAX_CHUNKS)
-    chunk = (n + PM_MAX_CHUNKS - 1) / PM_MAX_CHUNKS;
+  const int chunk = chunk_pairs_for (d, n, L, split);
   const int nch = (n + chunk - 1) / chunk;
   // Asynchronous runs queue up behind each other: the chunks of this run continue the pipeline of the pending ones (same
   // slots, same event chain), so that look-ups of this run's first chunk overlap the previous run's last.  The pending runs
@@ -1477,7 +1489,9 @@ static int run_slice (pemap_dev * d, int first, int n, int sync)
   int k0 = 0;
   if (d->run_pending)
     {
-      const bool same = d->run_split == split && d->run_chunk_pairs == chunk && d->run_L == L && split && !d->serial_split;
+      // (a smaller chunk than the pending runs' fits their arrays: the tail of a batch continues the pipeline too)
+      const bool same = d->run_split == split && d->run_L == L && split && !d->serial_split && chunk * per <= d->cap_ends
+        && chunk * per <= d->lists_cap && (size_t) (chunk * per) < d->dir_slabs;
       if (same && d->run_chunks + nch <= PM_MAX_CHUNKS)
         k0 = d->run_chunks;
       else
@@ -1507,7 +1521,8 @@ static int run_slice (pemap_dev * d, int first, int n, int sync)
   c.prm.bisulfite = d->bisulfite;
   c.L = L;
   c.tstride = tstride_for (d, L);
-  c.dump_slab = d->d_dirbuf + (size_t) (chunk * per) * slab_dwords_for (d, L);
+  // (the last slab of the allocation, whatever this run's chunk size: chunks of earlier, larger runs may still be in flight)
+  c.dump_slab = d->d_dirbuf + (d->dir_slabs - 1) * slab_dwords_for (d, L);
   if (k0 == 0)
     {
       memset (&d->last_ctr, 0, sizeof (d->last_ctr));
@@ -1545,6 +1560,8 @@ static int run_slice (pemap_dev * d, int first, int n, int sync)
     RunCtx cl = c;
     batch_of (k, cl.b, f, m);
     const int g = k0 + k, slot = g & 1;
+    if (copy_evs)
+      HIPCHK (d, hipStreamWaitEvent (d->serial_split ? d->stream : d->stream2, copy_evs[k], 0));
     // the slot's lists must have been consumed by the vote of chunk g-2
     if (g >= 2)
       HIPCHK (d, hipStreamWaitEvent (d->serial_split ? d->stream : d->stream2, d->ev_lists_free[slot], 0));
@@ -1578,6 +1595,8 @@ static int run_slice (pemap_dev * d, int first, int n, int sync)
       const int g = k0 + k, slot = g & 1;
       PmChunkCtr *cc = d->d_chunk_ctr + g;
       hipEvent_t *ev = &d->evs[(size_t) g * PM_NEV];
+      if (copy_evs && !(split && !d->serial_split))
+        HIPCHK (d, hipStreamWaitEvent (d->stream, copy_evs[k], 0));
       if (split)
         {
           if (d->serial_split)
@@ -1994,10 +2013,12 @@ extern "C" int pemap_dev_submit_batch (pemap_dev * d, const char *reads1, const 
           r.h_rows_bytes = need;
         }
     }
-  const int slice = d->kn.chunk_pairs > 0 ? d->kn.chunk_pairs : 131072;
-  const int n_slices = (n + slice - 1) / slice;
   if (!d->stream2)
     TRY (ensure_pipeline (d, 0));       // the pipeline's streams must exist before the first copy event is waited on
+  // the copies are cut like the kernels' chunks, one event each: chunk k's look-ups start when its rows have landed
+  const bool split = d->kn.pipeline != 0 && !d->kn.seed_phase;
+  const int slice = chunk_pairs_for (d, n, d->max_len_staged, split);
+  const int n_slices = (n + slice - 1) / slice;
   while ((int) r.ev_copy.size () < n_slices)
     {
       hipEvent_t e;
@@ -2031,12 +2052,8 @@ extern "C" int pemap_dev_submit_batch (pemap_dev * d, const char *reads1, const 
       if (d->paired)
         HIPCHK (d, hipMemcpyAsync (d->d_reads2 + (size_t) (first + off) * stride, src2, (size_t) m * stride, hipMemcpyHostToDevice, d->stream_h2d));
       HIPCHK (d, hipEventRecord (r.ev_copy[k], d->stream_h2d));
-      // whichever stream touches the slice's rows first (the look-ups on the memory stream, the seed kernel on the ALU stream)
-      HIPCHK (d, hipStreamWaitEvent (d->stream, r.ev_copy[k], 0));
-      if (d->stream2)
-        HIPCHK (d, hipStreamWaitEvent (d->stream2, r.ev_copy[k], 0));
-      TRY (run_slice (d, first + off, m, 0));
     }
+  TRY (run_slice (d, first, n, 0, r.ev_copy.data ()));
   // results: behind the batch's last kernel on the ALU stream (every other stream's work for the batch precedes it)
   HIPCHK (d, hipEventRecord (d->ev_batch_alu, d->stream));
   HIPCHK (d, hipStreamWaitEvent (d->stream_d2h, d->ev_batch_alu, 0));
