@@ -91,16 +91,25 @@ def mapper_leg(dev, a, L, B, steps, warmup, rank, world, barrier, allmax, indel_
         out["host_staging_s"] = time.time() - t0
         res = {}
 
+        trace = [] if os.environ.get("BENCH_TRACE") else None
+
         def run(k_from, k_to, depth=2):
             tick = []
             for k in range(k_from, k_to):
                 s = slice(k * B, (k + 1) * B)
+                ta = time.perf_counter()
                 tick.append((k, dev.submit_batch(r1[s], l1[s], r2[s], l2[s])))
+                tb = time.perf_counter()
                 if len(tick) > depth:
                     kk, t = tick.pop(0)
                     res[kk] = dev.wait_batch(t)
+                if trace is not None:
+                    trace.append(("submit %d" % k, round((tb - ta) * 1e3, 2), "then wait", round((time.perf_counter() - tb) * 1e3, 2)))
             for kk, t in tick:
+                ta = time.perf_counter()
                 res[kk] = dev.wait_batch(t)
+                if trace is not None:
+                    trace.append(("wait %d" % kk, round((time.perf_counter() - ta) * 1e3, 2)))
         run(0, warmup)
         dev.sync()                  # the warm-up's kernels are accounted and out of the counters
         barrier()
@@ -108,6 +117,8 @@ def mapper_leg(dev, a, L, B, steps, warmup, rank, world, barrier, allmax, indel_
         run(warmup, n_batches)
         dt = allmax(time.perf_counter() - t0)
         st, tm = dev.run_stats()        # totals over the K timed steps
+        if trace:
+            print("seam trace (ms):", trace, file=sys.stderr)
         out.update(seam_dt=dt, stats=st, times=tm, results=res)
         mapped = sum(int((res[k][0] > 0).sum() + (res[k][1] > 0).sum()) for k in range(warmup, n_batches))
         out["mapped_frac"] = mapped / float(2 * B * steps)

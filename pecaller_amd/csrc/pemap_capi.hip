@@ -74,6 +74,7 @@ struct PmKnobs
   int vote_stream_prio;
   bool vote_stream_prio_set;
   int chunk_pairs;
+  int d2h_stream;               // 1: the results of a submitted batch return on a stream of their own instead of the ALU stream
   int seed_phase, vote_probe;   // always 0 without PEMAP_TIMING_PROBES
 };
 
@@ -98,7 +99,7 @@ static void read_knobs (PmKnobs & k)
   { const char *e = getenv ("PEMAP_DIR_BUDGET_GB"); k.dir_budget_gb = e ? atof (e) : 40.0; if (k.dir_budget_gb < 0.25) k.dir_budget_gb = 0.25; }
   k.lookup_lds_pad_kb = env_int ("PEMAP_LOOKUP_LDS_PAD_KB", 20);
   k.lookup_waves = env_int ("PEMAP_LOOKUP_WAVES", -1);
-  k.lookup_v = env_int ("PEMAP_LOOKUP_V", 1);
+  k.lookup_v = env_int ("PEMAP_LOOKUP_V", 3);
   k.lookup_batch = env_int ("PEMAP_LOOKUP_BATCH", -1);
   k.lookup_prio = env_int ("PEMAP_LOOKUP_PRIO", 0);
   k.vote_prio = env_int ("PEMAP_VOTE_PRIO", 0);
@@ -118,6 +119,7 @@ static void read_knobs (PmKnobs & k)
   k.vote_stream_prio_set = getenv ("PEMAP_VOTE_STREAM_PRIO") != nullptr;
   k.vote_stream_prio = env_int ("PEMAP_VOTE_STREAM_PRIO", 0);
   k.chunk_pairs = env_int ("PEMAP_CHUNK_PAIRS", 131072);
+  k.d2h_stream = env_int ("PEMAP_D2H_STREAM", 0);
   k.seed_phase = k.vote_probe = 0;
 #ifdef PEMAP_TIMING_PROBES
   k.seed_phase = env_int ("PEMAP_SEED_PHASE", 0);
@@ -458,8 +460,11 @@ extern "C" void pemap_dev_destroy (pemap_dev * d)
   if (d->stream_h2d)
     {
       hipStreamDestroy (d->stream_h2d);
-      hipStreamDestroy (d->stream_d2h);
-      hipEventDestroy (d->ev_batch_alu);
+      if (d->stream_d2h)
+        {
+          hipStreamDestroy (d->stream_d2h);
+          hipEventDestroy (d->ev_batch_alu);
+        }
     }
   for (int i = 0; i < 7; i++)
     hipEventDestroy (d->ev[i]);
@@ -1092,7 +1097,13 @@ static int seg_template (int L)
 }
 
 // ---- the memory stream's work for one chunk: look-ups + slice gather into the slot's lists
-static void launch_lookup (pemap_dev * d, const RunCtx & c, int slot, PmChunkCtr * cc, hipEvent_t * ev)
+// is the seed stage of this run the fused kernel (pm_seed3_kernel: look-ups and vote of a read-end in one wave)?
+static bool pm_fused (const pemap_dev * d)
+{
+  return d->n_rep == 8 && d->kn.lookup_v == 3 && d->kn.lookup_waves != 0;
+}
+
+static void launch_lookup (pemap_dev * d, const RunCtx & c, int slot, PmChunkCtr * cc, hipEvent_t * ev, bool split)
 {
   PmLists L = d->lists[slot];
   L.n_big = &cc->n_big;
@@ -1112,7 +1123,7 @@ static void launch_lookup (pemap_dev * d, const RunCtx & c, int slot, PmChunkCtr
   const int lv = d->kn.lookup_v;
   // waves per CU: 6 (with the replicas 4 was the optimum while the SW kernel scored every problem: one per SIMD; since the
   // gapless rule took 78 % of its problems away the two streams balance at 6)
-  const int lw = d->kn.lookup_waves >= 0 ? d->kn.lookup_waves : (c.ix.n_rep == 8) ? (lv == 2 ? 3 : 6) : 6;
+  const int lw = d->kn.lookup_waves >= 0 ? d->kn.lookup_waves : (c.ix.n_rep == 8) ? (lv == 3 ? 5 : lv == 2 ? 3 : 6) : 6;
   int lgrid = lw * d->n_cus;
   if (lgrid > c.b.n_ends)
     lgrid = c.b.n_ends;
@@ -1121,7 +1132,10 @@ static void launch_lookup (pemap_dev * d, const RunCtx & c, int slot, PmChunkCtr
   const int lprio = d->kn.lookup_prio;
 #define PM_LKW(SM, B) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_lookup_wave_kernel < SM, B >), dim3 (lgrid), dim3 (64), 0, st, c.ix, c.b, c.prm, L, lprio)
 #define PM_LKR(SM, B) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_lookup_rep_kernel < SM, B >), dim3 (lgrid), dim3 (64), 0, st, c.ix, c.b, c.prm, L, lprio)
-#define PM_LK(SM) do { if (lw > 0 && c.ix.n_rep == 8 && lv == 2) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_lookup_rep2_kernel < SM >), dim3 (lgrid), dim3 (64), sizeof (PmLookupRep2Shared < SM >), st, c.ix, c.b, c.prm, L, lprio); \
+  const bool set2 = split && slot;
+  const PmHits & H = set2 ? d->hits2 : d->hits;
+#define PM_LK(SM) do { if (lw > 0 && c.ix.n_rep == 8 && lv == 3) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_seed3_kernel < SM >), dim3 (lgrid), dim3 (64), sizeof (PmSeed3Shared < SM >), st, c.ix, c.b, c.prm, H, L, lprio); \
+    else if (lw > 0 && c.ix.n_rep == 8 && lv == 2) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_lookup_rep2_kernel < SM >), dim3 (lgrid), dim3 (64), sizeof (PmLookupRep2Shared < SM >), st, c.ix, c.b, c.prm, L, lprio); \
     else if (lw > 0 && c.ix.n_rep == 8 && lb >= 8) PM_LKR (SM, 10); else if (lw > 0 && c.ix.n_rep == 8) PM_LKR (SM, 5); \
     else if (lw > 0 && lb >= 16) PM_LKW (SM, 16); else if (lw > 0 && lb >= 8) PM_LKW (SM, 8); else if (lw > 0) PM_LKW (SM, 4); \
     else hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_lookup_kernel < SM >), dim3 (c.b.n_ends), dim3 (PM_SEED_THREADS), pad, st, c.ix, c.b, c.prm, L); } while (0)
@@ -1137,6 +1151,12 @@ static void launch_lookup (pemap_dev * d, const RunCtx & c, int slot, PmChunkCtr
 #undef PM_LKW
 #undef PM_LKR
   hipEventRecord (ev[1], st);
+  if (pm_fused (d))
+    {
+      // the vote is part of the kernel: its interval is empty
+      hipEventRecord (ev[2], st);
+      hipEventRecord (ev[3], st);
+    }
 }
 
 // ---- the seed stage after the look-ups, on stream `st`: vote + list-mode remainder on the slot's lists (split), or the
@@ -1245,7 +1265,9 @@ template < int W, int LPA > static void launch_chunk (pemap_dev * d, const RunCt
   uint32_t *dump_slab = dirbuf + (c.dump_slab - d->d_dirbuf);
   const int n_ends = c.b.n_ends;
   PmCounters *ctr = &cc->c;
-  if (!(split && d->vote_on_mem))
+  if (split && pm_fused (d))
+    ;                           // the seed stage ran on the look-up's stream (enqueue_lookup)
+  else if (!(split && d->vote_on_mem))
     launch_vote (d, c, split, slot, cc, ev, d->stream);
   else if (d->vote_stream == 3 && pm_vote_rest_on_alu (d))
     launch_vote (d, c, split, slot, cc, ev, d->stream, 2);
@@ -1468,7 +1490,7 @@ static int run_slice (pemap_dev * d, int first, int n, int sync, const hipEvent_
   // Default: 2 with the look-up replicas (measured 41.5 ms per step against 44.7 with the vote on the ALU stream: with the
   // cheap look-ups and the gapless rule no stream is saturated any more, and the vote of chunk k+1 fills the gaps), 0 without
   // (it was slower beside the look-ups of the reference's layout).
-  { const int vm = d->kn.vote_on_mem >= 0 ? d->kn.vote_on_mem : (d->n_rep == 8 ? 2 : 0);
+  { const int vm = (split && pm_fused (d)) ? 1 : d->kn.vote_on_mem >= 0 ? d->kn.vote_on_mem : (d->n_rep == 8 ? 2 : 0);
     d->vote_on_mem = split && !d->serial_split && vm != 0;
     d->vote_stream = (d->vote_on_mem && vm == 2) ? 3 : 2; }
   if (d->vote_on_mem && d->vote_stream == 3 && !d->stream3)
@@ -1565,7 +1587,19 @@ static int run_slice (pemap_dev * d, int first, int n, int sync, const hipEvent_
     // the slot's lists must have been consumed by the vote of chunk g-2
     if (g >= 2)
       HIPCHK (d, hipStreamWaitEvent (d->serial_split ? d->stream : d->stream2, d->ev_lists_free[slot], 0));
-    launch_lookup (d, cl, slot, d->d_chunk_ctr + g, &d->evs[(size_t) g * PM_NEV]);
+    if (pm_fused (d))
+      {
+        // the fused kernel writes the hit arrays that the SW / walk of chunk g-2 used; the list-mode remainder of the big read-ends
+        // and the emit kernel follow it on the same stream
+        hipStream_t fs = d->serial_split ? d->stream : d->stream2;
+        if (g >= 2 && !d->serial_split)
+          HIPCHK (d, hipStreamWaitEvent (fs, d->ev_walk_done[slot], 0));
+        launch_lookup (d, cl, slot, d->d_chunk_ctr + g, &d->evs[(size_t) g * PM_NEV], true);
+        launch_vote (d, cl, true, slot, d->d_chunk_ctr + g, &d->evs[(size_t) g * PM_NEV], fs, 2);
+        HIPCHK (d, hipEventRecord (d->ev_lists_ready[slot], fs));
+        return 0;
+      }
+    launch_lookup (d, cl, slot, d->d_chunk_ctr + g, &d->evs[(size_t) g * PM_NEV], true);
     if (d->vote_on_mem)
       {
         // the vote fills the array set that the SW / walk of chunk g-2 used
@@ -1908,8 +1942,6 @@ static int ring_setup (pemap_dev * d, int n, int stride, std::unique_lock < std:
   if (!d->stream_h2d)
     {
       HIPCHK (d, hipStreamCreateWithFlags (&d->stream_h2d, hipStreamNonBlocking));
-      HIPCHK (d, hipStreamCreateWithFlags (&d->stream_d2h, hipStreamNonBlocking));
-      HIPCHK (d, hipEventCreateWithFlags (&d->ev_batch_alu, hipEventDisableTiming));
     }
   if (d->ring_cap >= n && d->stride == stride && d->staged_paired == d->paired && (!d->paired || d->d_reads2))
     return 0;
@@ -2054,14 +2086,26 @@ extern "C" int pemap_dev_submit_batch (pemap_dev * d, const char *reads1, const 
       HIPCHK (d, hipEventRecord (r.ev_copy[k], d->stream_h2d));
     }
   TRY (run_slice (d, first, n, 0, r.ev_copy.data ()));
-  // results: behind the batch's last kernel on the ALU stream (every other stream's work for the batch precedes it)
-  HIPCHK (d, hipEventRecord (d->ev_batch_alu, d->stream));
-  HIPCHK (d, hipStreamWaitEvent (d->stream_d2h, d->ev_batch_alu, 0));
-  HIPCHK (d, hipMemcpyAsync (r.h_res, d->d_m1 + first, (size_t) n * 4, hipMemcpyDeviceToHost, d->stream_d2h));
+  // results: on the ALU stream itself, behind the batch's last kernel (every other stream's work for the batch precedes it).
+  // Not on a stream of their own: HIP multiplexes streams onto a few hardware queues, and a copy stream parked on "batch k is
+  // done" held up whichever pipeline stream shared its queue -- 3.5 ms per batch (measured: 45.2 ms per step against 41.7).
+  hipStream_t rs = d->stream;
+  if (d->kn.d2h_stream)
+    {
+      if (!d->stream_d2h)
+        {
+          HIPCHK (d, hipStreamCreateWithFlags (&d->stream_d2h, hipStreamNonBlocking));
+          HIPCHK (d, hipEventCreateWithFlags (&d->ev_batch_alu, hipEventDisableTiming));
+        }
+      rs = d->stream_d2h;
+      HIPCHK (d, hipEventRecord (d->ev_batch_alu, d->stream));
+      HIPCHK (d, hipStreamWaitEvent (rs, d->ev_batch_alu, 0));
+    }
+  HIPCHK (d, hipMemcpyAsync (r.h_res, d->d_m1 + first, (size_t) n * 4, hipMemcpyDeviceToHost, rs));
   if (d->paired)
-    HIPCHK (d, hipMemcpyAsync (r.h_res + d->ring_cap, d->d_m2 + first, (size_t) n * 4, hipMemcpyDeviceToHost, d->stream_d2h));
-  HIPCHK (d, hipMemcpyAsync (r.h_res + 2 * (size_t) d->ring_cap, d->d_mtype + first, (size_t) n * 4, hipMemcpyDeviceToHost, d->stream_d2h));
-  HIPCHK (d, hipEventRecord (r.ev_done, d->stream_d2h));
+    HIPCHK (d, hipMemcpyAsync (r.h_res + d->ring_cap, d->d_m2 + first, (size_t) n * 4, hipMemcpyDeviceToHost, rs));
+  HIPCHK (d, hipMemcpyAsync (r.h_res + 2 * (size_t) d->ring_cap, d->d_mtype + first, (size_t) n * 4, hipMemcpyDeviceToHost, rs));
+  HIPCHK (d, hipEventRecord (r.ev_done, rs));
   *ticket = d->ring_seq++;
   return 0;
 }

@@ -192,4 +192,5 @@ __device__ __forceinline__ void pm_set_prio (int p)
 
 #include "pemap_seed.hip.h"
 #include "pemap_seed2.hip.h"
+#include "pemap_seed3.hip.h"
 #include "pemap_sw.hip.h"

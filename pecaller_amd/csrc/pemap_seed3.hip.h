@@ -1,0 +1,611 @@
+// pemap_seed3.hip.h -- the seed stage of a read-end in ONE kernel: bucket look-ups against the 8 table replicas
+// (fill_mers / get_mers, pemapper.c:1969-2003, 2158-2165; initial_map 1539-1690) and the diagonal vote (find_matches,
+// pemapper.c:2189-2289), ONE WAVE per read-end, persistent, the positions never leaving LDS.
+//
+// Why a third form.  Round 1's split (pm_lookup_rep_kernel -> (key, segment) lists in HBM -> pm_vote_wave_kernel) spent
+// 2,350 + 1,750 wave instructions per read-end, moved the lists through HBM twice (9 bytes per position each way) and left
+// the step's length to how the runtime happened to map three streams onto hardware queues (look-ups and vote on one queue:
+// 47.7 ms per step; on two: 41.7 .. 46; profiles/r02_queue_mapping.txt).  Here
+//   * the look-up half decodes one (strand, segment) per round with lane = neighbour, writes the single-position buckets
+//     straight into the strand's list in LDS (offsets from ballots) and resolves the record buckets from the first one or two
+//     16-byte units of their records -- no per-position binary search, no prefix pass over the 49 buckets of a segment;
+//   * the vote half does not sort.  A histogram of the diagonal bins of both strands finds the few positions that can be
+//     anchors at all (a necessary condition: at least min_match positions in the anchor's three bins), only the positions
+//     next to those are kept, and the exact count of later segments on the anchor's diagonal (tot_found, pemapper.c:2241-2249)
+//     is an all-pairs test among these few.  The walk over the ranked anchors is the reference's state machine unchanged;
+//   * the wave keeps three read-ends in flight: the bytes of end k+2 and the table lines of end k+1 travel while end k is
+//     decoded and voted on, so one exposed trip to HBM per end (the record headers) is left of four.
+// Output: the raw hit lists of pm_vote_wave_kernel (h.n_hits / spot / nn / orient), consumed by pm_emit_kernel.  Ends with
+// more than PM_SEED_CAP positions on a strand, or with more than PM_S3_RCAP positions near candidate anchors (repeats), go
+// to the big-end list and through pm_seed_kernel in list mode, as before.
+#pragma once
+
+#define PM_S3_NH 1024           // histogram cells: hash of (diagonal bin, strand)
+#define PM_S3_RCAP 256          // positions next to candidate anchors, both strands together
+
+template < int SMAX > struct __align__ (16) PmSeed3Shared
+{
+  static constexpr int NSEG = 2 * SMAX;
+  static constexpr int NITEMS = NSEG * 49;
+  uint32_t lines[NSEG * 128];           // 2 x SMAX x 8 lines of 16 entries
+  uint32_t key[2][PM_SEED_CAP];         // diagonal keys m + PM_DIAG_BIAS - offset(segment), per strand
+  uint8_t tag[2][PM_SEED_CAP];          // segment of the position; bit 7: candidate anchor
+  union
+  {
+    struct
+    {
+      uint32_t ent[NITEMS];             // entries that point to a record, (strand, segment)-major
+      uint8_t sg[NITEMS];
+    } m;
+    struct
+    {
+      uint32_t hist[PM_S3_NH];
+      uint32_t candbit[PM_S3_NH / 32];
+      uint2 r[PM_S3_RCAP];              // x = key, y = segment | strand << 5 | candidate << 6
+      uint16_t order[PM_S3_RCAP];
+      uint8_t rtf[PM_S3_RCAP];          // tot_found of a surviving anchor, 0 otherwise
+    } v;
+  } u;
+  uint32_t hits[PM_MAX_HITS];
+  uint16_t hits_off[PM_MAX_HITS];
+  uint8_t hits_or[PM_MAX_HITS];
+  uint32_t kmer[2][NSEG];               // double-buffered: end k (decode) and end k + 1 (line requests)
+  int seg_cnt[NSEG];
+  uint8_t seq[2][320];                  // 2-bit codes of the end whose k-mers are being formed
+};
+
+__device__ __forceinline__ unsigned pm_s3_hash (uint32_t bin, unsigned strand)
+{
+  return ((bin * 2u + strand) * 2654435761u) >> 22;     // 10 bits
+}
+
+__device__ __forceinline__ int pm_lanes_below (unsigned long long m)
+{
+  return (int) __builtin_amdgcn_mbcnt_hi ((unsigned) (m >> 32), __builtin_amdgcn_mbcnt_lo ((unsigned) m, 0u));
+}
+
+__device__ __forceinline__ int pm_wave_min (int v)
+{
+  for (int o = 32; o; o >>= 1)
+    v = min (v, __shfl_xor (v, o));
+  return v;
+}
+
+// LDS is passed as dynamic shared memory (sizeof (PmSeed3Shared < SMAX >)): from a static 30 KB the compiler concludes that two waves
+// per SIMD are all the kernel will ever get and spends 185 VGPRs on it, whatever the launch bounds say -- and a SIMD that hosts such
+// a wave has room for one wave of the fp64 SW kernel (168 VGPRs) instead of two.
+extern __shared__ __align__ (16) uint8_t pm_seed3_lds[];
+
+template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? 3 : 2) void pm_seed3_kernel (PmIndex ix, PmBatch b, PmParams prm, PmHits h, PmLists out, int prio)
+{
+  pm_set_prio (prio);
+  typedef PmSeed3Shared < SMAX > SH;
+  SH & sh = *reinterpret_cast < SH * >(pm_seed3_lds);
+  const int lane = threadIdx.x;
+  const int idepth = ix.idepth;
+  const int max_off = max (2, idepth - 4);
+  const uint32_t span = (uint32_t) (2 * (max_off - 1));
+  const uint32_t multi_base = ix.multi_base;
+  const int n_ends = b.n_ends;
+  const int nb = b.stride < 320 ? b.stride : 320;
+  unsigned long long n_pos = 0;
+  // lane j looks at neighbour j of every segment (fill_mers' order, pm_neighbour): the 2-bit field it replaces, the
+  // alternative's rank, the replica (= 4-bit field) whose line holds the entry
+  const int nb_f = lane > 0 ? (lane - 1) / 3 : 0;
+  const uint32_t nb_a = lane > 0 ? (uint32_t) ((lane - 1) % 3) : 0u;
+  const uint32_t nb_sh = 2u * (uint32_t) (nb_f & 15);
+  const uint32_t nb_keep = lane > 0 ? ~(3u << nb_sh) : 0xFFFFFFFFu;      // lane 0: the k-mer itself
+  const uint32_t nb_alt_on = lane > 0 ? 0xFFFFFFFFu : 0u;
+  const int nb_p = (nb_f >> 1) & 7;
+  const uint32_t nb_p4 = 4u * (uint32_t) nb_p, nb_pw = 16u * (uint32_t) nb_p;
+
+  // ends are handed out through a counter, two values ahead of their use (the first grid-ful by block index)
+  auto next_end = [&] ()->int
+  {
+    return (int) gridDim.x + (int) __builtin_amdgcn_readfirstlane ((int) (lane == 0 ? atomicAdd (out.next_end, 1u) : 0u));
+  };
+  int eQ = blockIdx.x;
+  int eP = next_end ();
+  int eR = next_end ();
+
+  uint8_t rb[5];                // the bytes of the end whose k-mers are formed next
+  int rlen = 0;
+  uint4 ln[SMAX];               // the table lines of the end decoded next: 4 lanes x 16 bytes per line, 16 lines per register
+  auto load_bytes = [&] (int e)
+  {
+    const uint8_t *src = pm_read_ptr (b, e, &rlen);
+#pragma unroll
+    for (int t = 0; t < 5; t++)
+      {
+        const int i = lane + 64 * t;
+        rb[t] = (i < nb) ? src[i] : (uint8_t) 0;
+      }
+  };
+  // read in registers -> 2-bit codes of both strands, N filter (pemapper.c:1552-1559), segment count, the 2 x S k-mers into
+  // kmer[bf], and the 2 x S x 8 line requests into ln[].  -> S, or 0 when the N filter drops the read
+  auto stage_p = [&] (int bf)->int
+  {
+    const int len = rlen;
+    int isn = 0;
+#pragma unroll
+    for (int t = 0; t < 5; t++)
+      {
+        const int i = lane + 64 * t;
+        if (i < len)
+          {
+            // fill_cv_mat / convert_ct (pemapper.c:2375-2383, 2292-2300) of the read and of its reverse complement
+            const uint8_t c = rb[t];
+            sh.seq[0][i] = (uint8_t) pm_code_flat (c, prm.bisulfite);
+            sh.seq[1][len - 1 - i] = (uint8_t) pm_code_flat (pm_rc_flat (c), prm.bisulfite);
+            isn += (c == 'N');
+          }
+      }
+    for (int o = 32; o; o >>= 1)
+      isn += __shfl_xor (isn, o);
+    int cuts = len / idepth;    // pemapper.c:1573-1587
+    if (len % idepth == 0)
+      cuts--;
+    if (cuts > SMAX - 1)
+      cuts = SMAX - 1;
+    const int S = cuts + 1;
+    if (isn >= 1 + len / 10)
+      return 0;
+    pm_wave_sync ();
+    if (lane < 2 * S)
+      {
+        const int strand = lane >= S ? 1 : 0, seg = lane - strand * S;
+        const int off = (seg < cuts || cuts == 0) ? seg * idepth : len - idepth;
+        const uint8_t *p = &sh.seq[strand][off];
+        uint32_t k = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+          k = (k << 2) + p[i];
+        sh.kmer[bf][lane] = k;
+      }
+    pm_wave_sync ();
+    const int n_lines = 2 * S * 8;
+#pragma unroll
+    for (int r = 0; r < SMAX; r++)
+      {
+        const int li = r * 16 + (lane >> 2);
+        ln[r] = make_uint4 (0u, 0u, 0u, 0u);
+        if (li < n_lines)
+          {
+            const int p = li & 7;
+            const uint32_t idx = pm_swap_fields (sh.kmer[bf][li >> 3], p);
+            ln[r] = *(const uint4 *) (ix.rep + ((size_t) p << 32) + (size_t) (idx & ~15u) + (size_t) ((lane & 3) * 4));
+          }
+      }
+    return S;
+  };
+
+  int SQ = 0, lenQ = 0, bufQ = 0;
+  if (eQ < n_ends)
+    {
+      load_bytes (eQ);
+      lenQ = rlen;
+      SQ = stage_p (0);
+    }
+  if (eP < n_ends)
+    load_bytes (eP);
+
+  while (eQ < n_ends)
+    {
+      const int e = eQ, S = SQ, len = lenQ;
+      int cuts = S - 1;
+      const int last_off = len - idepth;
+      int tot = 0;
+      bool big = false;
+      int T0 = 0, T1 = 0, cmin0 = 0, cmin1 = 0;
+      if (S > 0)
+        {
+          // ---- A: the lines of this end (requested one iteration ago) from registers to LDS
+#pragma unroll
+          for (int r = 0; r < SMAX; r++)
+            if (r * 16 < 2 * S * 8)
+              *(uint4 *) (&sh.lines[(r * 16 + (lane >> 2)) * 16 + (lane & 3) * 4]) = ln[r];
+          if (lane < 2 * SMAX)
+            sh.seg_cnt[lane] = 0;
+          pm_wave_sync ();
+          // ---- B: one (strand, segment) per round, lane j = neighbour j.  A segment with a bucket of too_many_spots or more is
+          //      dropped whole (pemapper.c:1602-1606: the entry itself says so); buckets of one position go straight to the
+          //      strand's list; entries that point to a record are collected
+          int n0 = 0, n1 = 0, n_multi = 0;
+#pragma unroll 2
+          for (int sg = 0; sg < 2 * S; sg++)
+            {
+              const uint32_t k = sh.kmer[bufQ][sg];
+              const uint32_t cur = (k >> nb_sh) & 3u;
+              const uint32_t alt = nb_a + (nb_a >= cur ? 1u : 0u);
+              const uint32_t nbk = (k & nb_keep) | ((alt << nb_sh) & nb_alt_on);
+              const uint32_t ent = lane < 49 ? sh.lines[sg * 128 + nb_pw + ((nbk >> nb_p4) & 15u)] : 0xFFFFFFFFu;
+              if (__ballot (ent == 0xFFFFFFFEu) != 0ull)
+                continue;
+              const bool single = ent < multi_base, multi = ent >= multi_base && ent != 0xFFFFFFFFu;
+              const unsigned long long bs = __ballot (single), bm = __ballot (multi);
+              const int strand = sg >= S ? 1 : 0, seg = sg - strand * S;
+              const int off = (seg < cuts || cuts == 0) ? seg * idepth : last_off;
+              if (single)
+                {
+                  const int at = (strand ? n1 : n0) + pm_lanes_below (bs);
+                  sh.key[strand][at] = ent + (uint32_t) (PM_DIAG_BIAS - off);
+                  sh.tag[strand][at] = (uint8_t) seg;
+                }
+              const int ns = (int) __popcll (bs);
+              if (strand)
+                n1 += ns;
+              else
+                n0 += ns;
+              if (lane == 0)
+                sh.seg_cnt[sg] = ns;
+              if (multi)
+                {
+                  const int slot = n_multi + pm_lanes_below (bm);
+                  sh.u.m.ent[slot] = ent;
+                  sh.u.m.sg[slot] = (uint8_t) sg;
+                }
+              n_multi += (int) __popcll (bm);
+            }
+          pm_wave_sync ();
+          // ---- C: the records: {count, positions...} in 16-byte units; the first unit answers for buckets of up to 3 positions,
+          //      the second for up to 7, longer ones are copied by the whole wave.  Two rounds of 64 records in flight.
+          int m0 = 0, m1 = 0;
+#pragma unroll 1
+          for (int i0 = 0; i0 < n_multi; i0 += 128)
+            {
+              uint4 hd[2];
+              int sgv[2];
+              uint32_t unit[2];
+#pragma unroll
+              for (int r = 0; r < 2; r++)
+                {
+                  const int i = i0 + r * 64 + lane;
+                  hd[r] = make_uint4 (0u, 0u, 0u, 0u);
+                  sgv[r] = 0;
+                  unit[r] = 0;
+                  if (i < n_multi)
+                    {
+                      unit[r] = sh.u.m.ent[i] - multi_base;
+                      sgv[r] = sh.u.m.sg[i];
+                      hd[r] = *(const uint4 *) (ix.multi + (size_t) unit[r] * 4);
+                    }
+                }
+#pragma unroll
+              for (int r = 0; r < 2; r++)
+                if (i0 + r * 64 < n_multi)
+                  {
+                    const bool valid = i0 + r * 64 + lane < n_multi;
+                    const uint32_t c = valid ? hd[r].x : 0u;
+                    const int strand = sgv[r] >= S ? 1 : 0, seg = sgv[r] - strand * S;
+                    // both strands' running offsets in one scan: counts are below 100, 64 of them stay below 2^16
+                    const uint32_t packed = strand ? (c << 16) : c;
+                    uint32_t incl = packed;
+                    for (int o = 1; o < 64; o <<= 1)
+                      {
+                        const uint32_t t = __shfl_up (incl, o);
+                        if (lane >= o)
+                          incl += t;
+                      }
+                    const uint32_t excl = incl - packed;
+                    const uint32_t total = __shfl (incl, 63);
+                    const int dst = strand ? n1 + m1 + (int) (excl >> 16) : n0 + m0 + (int) (excl & 0xFFFFu);
+                    m0 += (int) (total & 0xFFFFu);
+                    m1 += (int) (total >> 16);
+                    const bool fits = valid && dst + (int) c <= PM_SEED_CAP;
+                    const int off = (seg < cuts || cuts == 0) ? seg * idepth : last_off;
+                    const uint32_t bias = (uint32_t) (PM_DIAG_BIAS - off);
+                    if (valid)
+                      atomicAdd (&sh.seg_cnt[sgv[r]], (int) c);
+                    if (fits)
+                      {
+                        uint32_t *kk = &sh.key[strand][dst];
+                        uint8_t *tt = &sh.tag[strand][dst];
+                        kk[0] = hd[r].y + bias;
+                        tt[0] = (uint8_t) seg;
+                        kk[1] = hd[r].z + bias;
+                        tt[1] = (uint8_t) seg;
+                        if (c > 2)
+                          {
+                            kk[2] = hd[r].w + bias;
+                            tt[2] = (uint8_t) seg;
+                          }
+                      }
+                    const bool need2 = fits && c > 3;
+                    if (__ballot (need2) != 0ull)
+                      {
+                        uint4 h2 = make_uint4 (0u, 0u, 0u, 0u);
+                        if (need2)
+                          h2 = *(const uint4 *) (ix.multi + (size_t) unit[r] * 4 + 4);
+                        if (need2)
+                          {
+                            uint32_t *kk = &sh.key[strand][dst];
+                            uint8_t *tt = &sh.tag[strand][dst];
+                            kk[3] = h2.x + bias;
+                            tt[3] = (uint8_t) seg;
+                            if (c > 4)
+                              {
+                                kk[4] = h2.y + bias;
+                                tt[4] = (uint8_t) seg;
+                              }
+                            if (c > 5)
+                              {
+                                kk[5] = h2.z + bias;
+                                tt[5] = (uint8_t) seg;
+                              }
+                            if (c > 6)
+                              {
+                                kk[6] = h2.w + bias;
+                                tt[6] = (uint8_t) seg;
+                              }
+                          }
+                      }
+                    unsigned long long bl = __ballot (fits && c > 7);
+                    while (bl)
+                      {
+                        const int l = __ffsll ((long long) bl) - 1;
+                        bl &= bl - 1;
+                        const int cc = (int) __shfl ((int) c, l), dd = __shfl (dst, l), st = __shfl (strand, l), sgl = __shfl (seg, l);
+                        const uint32_t bl_bias = (uint32_t) __shfl ((int) bias, l);
+                        const uint32_t *rec = ix.multi + (size_t) (uint32_t) __shfl ((int) unit[r], l) * 4 + 1;
+                        for (int q = 7 + lane; q < cc; q += 64)
+                          {
+                            sh.key[st][dd + q] = rec[q] + bl_bias;
+                            sh.tag[st][dd + q] = (uint8_t) sgl;
+                          }
+                      }
+                  }
+            }
+          pm_wave_sync ();
+          T0 = n0 + m0;
+          T1 = n1 + m1;
+          big = T0 > PM_SEED_CAP || T1 > PM_SEED_CAP;
+          // pemapper.c:2200-2207: a strand is not searched when every one of its segments holds more than max_hits positions
+          {
+            const int c = lane < 2 * S ? sh.seg_cnt[lane] : 10000;
+            cmin0 = pm_wave_min (lane < S ? c : 10000);
+            cmin1 = pm_wave_min (lane >= S ? c : 10000);
+          }
+        }
+      // ---- P: the next end's k-mers and line requests (its bytes arrived during the previous iteration); R: the bytes of the end after
+      int SP = 0, lenP = 0;
+      if (eP < n_ends)
+        {
+          lenP = rlen;
+          SP = stage_p (bufQ ^ 1);
+        }
+      if (eR < n_ends)
+        load_bytes (eR);
+      // ---- V: find_matches (pemapper.c:2189-2289) on the lists in LDS
+      if (S > 0 && !big)
+        {
+          n_pos += (unsigned long long) (T0 + T1);
+          int min_match = max (1, cuts);        // pemapper.c:1642-1645
+          if (cuts > 4)
+            min_match = (4 * cuts) / 5;
+          min_match = min (min_match, 4);
+          const int mm0 = min_match;
+          const int loop_max0 = 1 + cuts - mm0;
+          const bool use0 = cmin0 <= PM_MAX_HITS, use1 = cmin1 <= PM_MAX_HITS;
+          // histogram of the diagonal bins (16 diagonals wide) of both strands
+#pragma unroll
+          for (int i = 0; i < PM_S3_NH / 256; i++)
+            ((uint4 *) sh.u.v.hist)[lane + 64 * i] = make_uint4 (0u, 0u, 0u, 0u);
+          if (lane < PM_S3_NH / 32)
+            sh.u.v.candbit[lane] = 0u;
+          pm_wave_sync ();
+          for (int st = 0; st < 2; st++)
+            if (st ? use1 : use0)
+              for (int i = lane; i < (st ? T1 : T0); i += 64)
+                atomicAdd (&sh.u.v.hist[pm_s3_hash (sh.key[st][i] >> 4, (unsigned) st)], 1u);
+          pm_wave_sync ();
+          // candidate anchors: positions of a segment the walk can reach with at least min_match positions in their three bins
+          // (everything within max_off - 1 <= 15 diagonals of an anchor lies there)
+          for (int st = 0; st < 2; st++)
+            if (st ? use1 : use0)
+              for (int i = lane; i < (st ? T1 : T0); i += 64)
+                {
+                  const uint32_t bin = sh.key[st][i] >> 4;
+                  const int sa = sh.tag[st][i];
+                  const unsigned hc = pm_s3_hash (bin, (unsigned) st);
+                  const uint32_t c = sh.u.v.hist[pm_s3_hash (bin - 1u, (unsigned) st)] + sh.u.v.hist[hc] + sh.u.v.hist[pm_s3_hash (bin + 1u, (unsigned) st)];
+                  if (sa <= loop_max0 && c >= (uint32_t) mm0)
+                    {
+                      sh.tag[st][i] = (uint8_t) (sa | 0x80);
+                      atomicOr (&sh.u.v.candbit[hc >> 5], 1u << (hc & 31u));
+                    }
+                }
+          pm_wave_sync ();
+          // the positions next to a candidate (same or adjacent bin), both strands, compacted
+          int nR = 0;
+          for (int st = 0; st < 2; st++)
+            if (st ? use1 : use0)
+              for (int i0 = 0; i0 < (st ? T1 : T0); i0 += 64)
+                {
+                  const int i = i0 + lane;
+                  bool rel = false;
+                  uint32_t k = 0, tg = 0;
+                  if (i < (st ? T1 : T0))
+                    {
+                      k = sh.key[st][i];
+                      tg = sh.tag[st][i];
+                      const uint32_t bin = k >> 4;
+                      const unsigned h0 = pm_s3_hash (bin - 1u, (unsigned) st), h1 = pm_s3_hash (bin, (unsigned) st), h2 = pm_s3_hash (bin + 1u, (unsigned) st);
+                      rel = (((sh.u.v.candbit[h0 >> 5] >> (h0 & 31u)) | (sh.u.v.candbit[h1 >> 5] >> (h1 & 31u)) | (sh.u.v.candbit[h2 >> 5] >> (h2 & 31u))) & 1u) != 0u;
+                    }
+                  const unsigned long long br = __ballot (rel);
+                  if (rel)
+                    {
+                      const int at = nR + pm_lanes_below (br);
+                      if (at < PM_S3_RCAP)
+                        sh.u.v.r[at] = make_uint2 (k, (tg & 31u) | ((uint32_t) st << 5) | ((tg & 0x80u) >> 1));
+                    }
+                  nR += (int) __popcll (br);
+                }
+          pm_wave_sync ();
+          if (nR > PM_S3_RCAP)
+            big = true;         // a repeat: left to the monolithic kernel
+          else
+            {
+              // tot_found of every candidate (pemapper.c:2241-2249): 1 + the later segments with a position within max_off of its diagonal
+              for (int i0 = 0; i0 < nR; i0 += 64)
+                {
+                  const int i = i0 + lane;
+                  const uint2 me = i < nR ? sh.u.v.r[i] : make_uint2 (0u, 0u);
+                  const bool cand = (me.y & 0x40u) != 0u;
+                  uint32_t bits = 0;
+                  if (__ballot (cand) != 0ull)
+                    for (int y = 0; y < nR; y++)
+                      {
+                        const uint2 o = sh.u.v.r[y];
+                        const uint32_t dd = o.x - me.x + (uint32_t) (max_off - 1);   // |diag_y - diag_a| < max_off in wrapping arithmetic
+                        if (dd <= span && ((o.y ^ me.y) & 0x20u) == 0u && (o.y & 31u) > (me.y & 31u))
+                          bits |= 1u << (o.y & 31u);
+                      }
+                  const int tf = 1 + __popc (bits);
+                  if (i < nR)
+                    sh.u.v.rtf[i] = (uint8_t) ((cand && tf >= mm0) ? tf : 0);
+                }
+              pm_wave_sync ();
+              bool go_on = true;
+              for (int strand = 0; strand < 2 && go_on; strand++)
+                {
+                  if (!(strand ? use1 : use0))
+                    {
+                      tot = 0;
+                      continue;
+                    }
+                  // ---- walk order of this strand's surviving anchors: segment ascending, position ascending inside a segment
+                  int ns = 0;
+                  for (int i0 = 0; i0 < nR; i0 += 64)
+                    {
+                      const int i = i0 + lane;
+                      const uint2 me = i < nR ? sh.u.v.r[i] : make_uint2 (0u, 0u);
+                      const bool sv = i < nR && sh.u.v.rtf[i] != 0 && (int) ((me.y >> 5) & 1u) == strand;
+                      const unsigned long long bsv = __ballot (sv);
+                      if (bsv != 0ull)
+                        {
+                          const uint64_t ck = ((uint64_t) (me.y & 31u) << 32) | me.x;
+                          int rank = 0;
+                          for (int y = 0; y < nR; y++)
+                            {
+                              const uint2 o = sh.u.v.r[y];
+                              const bool osv = sh.u.v.rtf[y] != 0 && (int) ((o.y >> 5) & 1u) == strand;
+                              rank += (osv && ((((uint64_t) (o.y & 31u)) << 32) | o.x) < ck) ? 1 : 0;
+                            }
+                          if (sv)
+                            sh.u.v.order[rank] = (uint16_t) i;
+                        }
+                      ns += (int) __popcll (bsv);
+                    }
+                  pm_wave_sync ();
+                  // ---- the walk's state machine on the ranked anchors (pemapper.c:2251-2284)
+                  bool more = true, done = false;
+                  int cur_loop = -1;
+                  for (int i0 = 0; i0 < ns && !done; i0 += 64)
+                    {
+                      const int i = i0 + lane;
+                      const bool act = i < ns;
+                      const int ri = act ? (int) sh.u.v.order[i] : 0;
+                      const uint2 a = sh.u.v.r[ri];
+                      const int tf = act ? (int) sh.u.v.rtf[ri] : 0;
+                      const int my_loop = act ? (int) (a.y & 31u) : 0;
+                      const int my_off = (my_loop < cuts || cuts == 0) ? my_loop * idepth : last_off;
+                      const uint32_t my_ml = (act ? a.x : 0u) - (uint32_t) (PM_DIAG_BIAS - my_off);        // the position itself
+                      unsigned long long cnd = __ballot (act && tf >= min_match);
+                      while (cnd)
+                        {
+                          const int l = __ffsll ((long long) cnd) - 1;
+                          cnd &= cnd - 1;
+                          const int tfl = __shfl (tf, l);
+                          const int loop = __shfl (my_loop, l);
+                          if (loop != cur_loop)
+                            {
+                              // the walk's loop bound is tested when a segment is entered, not inside it (pemapper.c:2216)
+                              if (loop > 1 + cuts - min_match)
+                                {
+                                  done = true;
+                                  break;
+                                }
+                              cur_loop = loop;
+                            }
+                          const int off_a = __shfl (my_off, l);
+                          const uint32_t ml = (uint32_t) __shfl ((int) my_ml, l);
+                          if (tfl > min_match)
+                            {
+                              min_match = tfl;
+                              if (lane == 0)
+                                {
+                                  sh.hits[0] = ml;
+                                  sh.hits_off[0] = (uint16_t) off_a;
+                                  sh.hits_or[0] = (uint8_t) strand;
+                                }
+                              tot = 1;
+                              pm_wave_sync ();
+                              cnd &= __ballot (tf >= min_match);     // candidates below the new best would fall through both tests
+                            }
+                          else if (tfl == min_match)
+                            {
+                              if (tot < PM_MAX_HITS)
+                                {
+                                  const uint32_t diag = ml - (uint32_t) off_a;        // unsigned, pemapper.c:2268
+                                  bool dup = false;
+                                  for (int k = lane; k < tot; k += 64)
+                                    if (sh.hits[k] - (uint32_t) sh.hits_off[k] == diag)
+                                      dup = true;
+                                  if (!__any (dup))
+                                    {
+                                      if (lane == 0)
+                                        {
+                                          sh.hits[tot] = ml;
+                                          sh.hits_off[tot] = (uint16_t) off_a;
+                                          sh.hits_or[tot] = (uint8_t) strand;
+                                        }
+                                      tot++;
+                                      pm_wave_sync ();
+                                    }
+                                }
+                              else
+                                {
+                                  more = false; // the reference returns with a full list (pemapper.c:2283-2284)
+                                  done = true;
+                                  break;
+                                }
+                            }
+                        }
+                    }
+                  if (tot >= PM_MAX_HITS)
+                    more = false;
+                  go_on = more;
+                  pm_wave_sync ();
+                }
+            }
+        }
+      if (big)
+        {
+          if (lane == 0)
+            out.big_list[atomicAdd (out.n_big, 1u)] = (uint32_t) e;
+        }
+      else
+        {
+          // ---- raw hits out (pm_seed_emit's format); pm_emit_kernel makes windows and task lists of them
+          if (lane == 0)
+            h.n_hits[e] = tot;
+          for (int t = lane; t < tot; t += 64)
+            {
+              const size_t o = (size_t) e * PM_MAX_HITS + t;
+              h.spot[o] = sh.hits[t];
+              h.nn[o] = (int16_t) sh.hits_off[t];
+              h.orient[o] = sh.hits_or[t];
+            }
+        }
+      pm_wave_sync ();
+      eQ = eP;
+      eP = eR;
+      eR = next_end ();
+      SQ = SP;
+      lenQ = lenP;
+      bufQ ^= 1;
+    }
+  if (lane == 0 && n_pos)
+    atomicAdd (out.positions, n_pos);
+}
