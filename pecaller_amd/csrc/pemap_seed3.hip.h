@@ -19,44 +19,46 @@
 // more than PM_SEED_CAP positions on a strand, or with more than PM_S3_RCAP positions near candidate anchors (repeats), go
 // to the big-end list and through pm_seed_kernel in list mode, as before.
 #pragma once
+#include <type_traits>
 
-#define PM_S3_NH 1024           // histogram cells: hash of (diagonal bin, strand)
+#ifndef PM_S3_NH_LOG2
+#define PM_S3_NH_LOG2 11
+#endif
+#define PM_S3_NH (1 << PM_S3_NH_LOG2)   // cells of the bin table: hash of (diagonal bin, strand)
+#ifndef PM_S3_WAVES_PER_EU
+#define PM_S3_WAVES_PER_EU 3
+#endif
 #define PM_S3_RCAP 256          // positions next to candidate anchors, both strands together
 
 template < int SMAX > struct __align__ (16) PmSeed3Shared
 {
   static constexpr int NSEG = 2 * SMAX;
-  static constexpr int NITEMS = NSEG * 49;
-  uint32_t lines[NSEG * 128];           // 2 x SMAX x 8 lines of 16 entries
-  uint32_t key[2][PM_SEED_CAP];         // diagonal keys m + PM_DIAG_BIAS - offset(segment), per strand
-  uint8_t tag[2][PM_SEED_CAP];          // segment of the position; bit 7: candidate anchor
   union
   {
-    struct
+    uint32_t lines[NSEG * 128];         // 2 x SMAX x 8 lines of 16 entries: needed while the entries are decoded ...
+    struct                              // ... the vote's tables afterwards (the next end's lines wait in registers)
     {
-      uint32_t ent[NITEMS];             // entries that point to a record, (strand, segment)-major
-      uint8_t sg[NITEMS];
-    } m;
-    struct
-    {
-      uint32_t hist[PM_S3_NH];
+      uint32_t segmask[PM_S3_NH];       // bit s: a position of segment s has its diagonal in this bin
       uint32_t candbit[PM_S3_NH / 32];
       uint2 r[PM_S3_RCAP];              // x = key, y = segment | strand << 5 | candidate << 6
+      uint2 sv[PM_S3_RCAP];             // the surviving anchors: x = key, y = segment | tot_found << 8 (strand 0 from the front, 1 from the back)
       uint16_t order[PM_S3_RCAP];
-      uint8_t rtf[PM_S3_RCAP];          // tot_found of a surviving anchor, 0 otherwise
     } v;
-  } u;
+  } a;
+  // diagonal keys m + PM_DIAG_BIAS - offset(segment) per strand, from the front; while the entries are decoded the entries that
+  // point to a record wait at the back (a strand has at most 49 x S <= 931 look-ups, each of them one or the other)
+  uint32_t key[2][PM_SEED_CAP];
+  uint8_t tag[2][PM_SEED_CAP];          // segment of the position; bit 7: candidate anchor
   uint32_t hits[PM_MAX_HITS];
   uint16_t hits_off[PM_MAX_HITS];
   uint8_t hits_or[PM_MAX_HITS];
-  uint32_t kmer[2][NSEG];               // double-buffered: end k (decode) and end k + 1 (line requests)
   int seg_cnt[NSEG];
   uint8_t seq[2][320];                  // 2-bit codes of the end whose k-mers are being formed
 };
 
 __device__ __forceinline__ unsigned pm_s3_hash (uint32_t bin, unsigned strand)
 {
-  return ((bin * 2u + strand) * 2654435761u) >> 22;     // 10 bits
+  return ((bin * 2u + strand) * 2654435761u) >> (32 - PM_S3_NH_LOG2);
 }
 
 __device__ __forceinline__ int pm_lanes_below (unsigned long long m)
@@ -76,7 +78,7 @@ __device__ __forceinline__ int pm_wave_min (int v)
 // a wave has room for one wave of the fp64 SW kernel (168 VGPRs) instead of two.
 extern __shared__ __align__ (16) uint8_t pm_seed3_lds[];
 
-template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? 3 : 2) void pm_seed3_kernel (PmIndex ix, PmBatch b, PmParams prm, PmHits h, PmLists out, int prio)
+template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES_PER_EU : 2) void pm_seed3_kernel (PmIndex ix, PmBatch b, PmParams prm, PmHits h, PmLists out, int prio)
 {
   pm_set_prio (prio);
   typedef PmSeed3Shared < SMAX > SH;
@@ -123,9 +125,12 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? 3 : 2) void
   };
   // read in registers -> 2-bit codes of both strands, N filter (pemapper.c:1552-1559), segment count, the 2 x S k-mers into
   // kmer[bf], and the 2 x S x 8 line requests into ln[].  -> S, or 0 when the N filter drops the read
-  auto stage_p = [&] (int bf)->int
+  // (the length is a per-lane load of one address: told to be wave-uniform here, where it is first needed, so that everything
+  // derived from it -- segment counts, loop bounds, the branches on them -- lives in scalar registers)
+  auto stage_p = [&] (uint32_t & kmer_out, int &len_out)->int
   {
-    const int len = rlen;
+    const int len = __builtin_amdgcn_readfirstlane (rlen);
+    len_out = len;
     int isn = 0;
 #pragma unroll
     for (int t = 0; t < 5; t++)
@@ -147,8 +152,9 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? 3 : 2) void
       cuts--;
     if (cuts > SMAX - 1)
       cuts = SMAX - 1;
+    cuts = __builtin_amdgcn_readfirstlane (cuts);       // (integer division is done by the vector unit)
     const int S = cuts + 1;
-    if (isn >= 1 + len / 10)
+    if (__builtin_amdgcn_readfirstlane (isn) >= __builtin_amdgcn_readfirstlane (1 + len / 10))
       return 0;
     pm_wave_sync ();
     if (lane < 2 * S)
@@ -160,38 +166,39 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? 3 : 2) void
 #pragma unroll
         for (int i = 0; i < 16; i++)
           k = (k << 2) + p[i];
-        sh.kmer[bf][lane] = k;
+        kmer_out = k;
       }
-    pm_wave_sync ();
     const int n_lines = 2 * S * 8;
 #pragma unroll
     for (int r = 0; r < SMAX; r++)
       {
         const int li = r * 16 + (lane >> 2);
         ln[r] = make_uint4 (0u, 0u, 0u, 0u);
+        const uint32_t ksrc = (uint32_t) __shfl ((int) kmer_out, (li >> 3) & 63);        // (every lane takes part in the shuffle)
         if (li < n_lines)
           {
             const int p = li & 7;
-            const uint32_t idx = pm_swap_fields (sh.kmer[bf][li >> 3], p);
+            const uint32_t idx = pm_swap_fields (ksrc, p);
             ln[r] = *(const uint4 *) (ix.rep + ((size_t) p << 32) + (size_t) (idx & ~15u) + (size_t) ((lane & 3) * 4));
           }
       }
     return S;
   };
 
-  int SQ = 0, lenQ = 0, bufQ = 0;
+  int SQ = 0, lenQ = 0;
+  uint32_t kQ = 0;              // lane sg: the k-mer of (strand, segment) sg of the end being decoded
   if (eQ < n_ends)
     {
       load_bytes (eQ);
-      lenQ = rlen;
-      SQ = stage_p (0);
+      SQ = stage_p (kQ, lenQ);
     }
   if (eP < n_ends)
     load_bytes (eP);
 
   while (eQ < n_ends)
     {
-      const int e = eQ, S = SQ, len = lenQ;
+      // (loop-carried and wave-uniform: said so, or the compiler keeps them, and every branch on them, in vector registers)
+      const int e = eQ, S = __builtin_amdgcn_readfirstlane (SQ), len = __builtin_amdgcn_readfirstlane (lenQ);
       int cuts = S - 1;
       const int last_off = len - idepth;
       int tot = 0;
@@ -203,175 +210,184 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? 3 : 2) void
 #pragma unroll
           for (int r = 0; r < SMAX; r++)
             if (r * 16 < 2 * S * 8)
-              *(uint4 *) (&sh.lines[(r * 16 + (lane >> 2)) * 16 + (lane & 3) * 4]) = ln[r];
+              *(uint4 *) (&sh.a.lines[(r * 16 + (lane >> 2)) * 16 + (lane & 3) * 4]) = ln[r];
           if (lane < 2 * SMAX)
             sh.seg_cnt[lane] = 0;
           pm_wave_sync ();
           // ---- B: one (strand, segment) per round, lane j = neighbour j.  A segment with a bucket of too_many_spots or more is
           //      dropped whole (pemapper.c:1602-1606: the entry itself says so); buckets of one position go straight to the
-          //      strand's list; entries that point to a record are collected
-          int n0 = 0, n1 = 0, n_multi = 0;
-#pragma unroll 2
-          for (int sg = 0; sg < 2 * S; sg++)
-            {
-              const uint32_t k = sh.kmer[bufQ][sg];
-              const uint32_t cur = (k >> nb_sh) & 3u;
-              const uint32_t alt = nb_a + (nb_a >= cur ? 1u : 0u);
-              const uint32_t nbk = (k & nb_keep) | ((alt << nb_sh) & nb_alt_on);
-              const uint32_t ent = lane < 49 ? sh.lines[sg * 128 + nb_pw + ((nbk >> nb_p4) & 15u)] : 0xFFFFFFFFu;
-              if (__ballot (ent == 0xFFFFFFFEu) != 0ull)
-                continue;
-              const bool single = ent < multi_base, multi = ent >= multi_base && ent != 0xFFFFFFFFu;
-              const unsigned long long bs = __ballot (single), bm = __ballot (multi);
-              const int strand = sg >= S ? 1 : 0, seg = sg - strand * S;
-              const int off = (seg < cuts || cuts == 0) ? seg * idepth : last_off;
-              if (single)
-                {
-                  const int at = (strand ? n1 : n0) + pm_lanes_below (bs);
-                  sh.key[strand][at] = ent + (uint32_t) (PM_DIAG_BIAS - off);
-                  sh.tag[strand][at] = (uint8_t) seg;
-                }
-              const int ns = (int) __popcll (bs);
-              if (strand)
-                n1 += ns;
-              else
-                n0 += ns;
-              if (lane == 0)
-                sh.seg_cnt[sg] = ns;
-              if (multi)
-                {
-                  const int slot = n_multi + pm_lanes_below (bm);
-                  sh.u.m.ent[slot] = ent;
-                  sh.u.m.sg[slot] = (uint8_t) sg;
-                }
-              n_multi += (int) __popcll (bm);
-            }
+          //      front of the strand's list; entries that point to a record are parked at its back
+          // (the two strands are two instances of the same code: their counters stay in scalar registers)
+          int nf0 = 0, nf1 = 0, nm0 = 0, nm1 = 0;
+          auto decode_strand = [&] (auto ST)
+          {
+            constexpr int strand = decltype (ST)::value;
+            int &nf = strand ? nf1 : nf0, &nm = strand ? nm1 : nm0;
+#pragma unroll 1
+            for (int seg = 0; seg < S; seg++)
+              {
+                const int sg = strand * S + seg;
+                const uint32_t k = (uint32_t) __builtin_amdgcn_readlane ((int) kQ, sg);
+                const uint32_t cur = (k >> nb_sh) & 3u;
+                const uint32_t alt = nb_a + (nb_a >= cur ? 1u : 0u);
+                const uint32_t nbk = (k & nb_keep) | ((alt << nb_sh) & nb_alt_on);
+                const uint32_t ent = lane < 49 ? sh.a.lines[sg * 128 + nb_pw + ((nbk >> nb_p4) & 15u)] : 0xFFFFFFFFu;
+                if (__ballot (ent == 0xFFFFFFFEu) != 0ull)
+                  continue;
+                const bool single = ent < multi_base, multi = ent >= multi_base && ent != 0xFFFFFFFFu;
+                const unsigned long long bs = __ballot (single), bm = __ballot (multi);
+                const int off = (seg < cuts || cuts == 0) ? seg * idepth : last_off;
+                if (single)
+                  {
+                    const int at = nf + pm_lanes_below (bs);
+                    sh.key[strand][at] = ent + (uint32_t) (PM_DIAG_BIAS - off);
+                    sh.tag[strand][at] = (uint8_t) seg;
+                  }
+                if (multi)
+                  {
+                    const int at = PM_SEED_CAP - 1 - (nm + pm_lanes_below (bm));
+                    sh.key[strand][at] = ent - multi_base;      // the record's first 16-byte unit
+                    sh.tag[strand][at] = (uint8_t) seg;
+                  }
+                const int ns = (int) __popcll (bs);
+                nf += ns;
+                nm += (int) __popcll (bm);
+                if (lane == 0)
+                  sh.seg_cnt[sg] = ns;
+              }
+          };
+          decode_strand (std::integral_constant < int, 0 > { });
+          decode_strand (std::integral_constant < int, 1 > { });
           pm_wave_sync ();
           // ---- C: the records: {count, positions...} in 16-byte units; the first unit answers for buckets of up to 3 positions,
-          //      the second for up to 7, longer ones are copied by the whole wave.  Two rounds of 64 records in flight.
-          int m0 = 0, m1 = 0;
+          //      the second for up to 7, longer ones are copied by the whole wave.  Two rounds of 64 records in flight.  The
+          //      positions go to the front of the list whose back still holds the records not yet read: an end whose list would
+          //      reach them is left to the monolithic kernel (only ends close to the capacity anyway).
+          auto records_strand = [&] (auto ST)
+          {
+            constexpr int strand = decltype (ST)::value;
+            int &nf = strand ? nf1 : nf0;
+            const int nm = strand ? nm1 : nm0;
 #pragma unroll 1
-          for (int i0 = 0; i0 < n_multi; i0 += 128)
-            {
-              uint4 hd[2];
-              int sgv[2];
-              uint32_t unit[2];
+            for (int i0 = 0; i0 < nm && !big; i0 += 128)
+              {
+                uint4 hd[2];
+                int sgv[2];
+                uint32_t unit[2];
 #pragma unroll
-              for (int r = 0; r < 2; r++)
-                {
-                  const int i = i0 + r * 64 + lane;
-                  hd[r] = make_uint4 (0u, 0u, 0u, 0u);
-                  sgv[r] = 0;
-                  unit[r] = 0;
-                  if (i < n_multi)
-                    {
-                      unit[r] = sh.u.m.ent[i] - multi_base;
-                      sgv[r] = sh.u.m.sg[i];
-                      hd[r] = *(const uint4 *) (ix.multi + (size_t) unit[r] * 4);
-                    }
-                }
-#pragma unroll
-              for (int r = 0; r < 2; r++)
-                if (i0 + r * 64 < n_multi)
+                for (int r = 0; r < 2; r++)
                   {
-                    const bool valid = i0 + r * 64 + lane < n_multi;
-                    const uint32_t c = valid ? hd[r].x : 0u;
-                    const int strand = sgv[r] >= S ? 1 : 0, seg = sgv[r] - strand * S;
-                    // both strands' running offsets in one scan: counts are below 100, 64 of them stay below 2^16
-                    const uint32_t packed = strand ? (c << 16) : c;
-                    uint32_t incl = packed;
-                    for (int o = 1; o < 64; o <<= 1)
+                    const int i = i0 + r * 64 + lane;
+                    hd[r] = make_uint4 (0u, 0u, 0u, 0u);
+                    sgv[r] = 0;
+                    unit[r] = 0;
+                    if (i < nm)
                       {
-                        const uint32_t t = __shfl_up (incl, o);
-                        if (lane >= o)
-                          incl += t;
-                      }
-                    const uint32_t excl = incl - packed;
-                    const uint32_t total = __shfl (incl, 63);
-                    const int dst = strand ? n1 + m1 + (int) (excl >> 16) : n0 + m0 + (int) (excl & 0xFFFFu);
-                    m0 += (int) (total & 0xFFFFu);
-                    m1 += (int) (total >> 16);
-                    const bool fits = valid && dst + (int) c <= PM_SEED_CAP;
-                    const int off = (seg < cuts || cuts == 0) ? seg * idepth : last_off;
-                    const uint32_t bias = (uint32_t) (PM_DIAG_BIAS - off);
-                    if (valid)
-                      atomicAdd (&sh.seg_cnt[sgv[r]], (int) c);
-                    if (fits)
-                      {
-                        uint32_t *kk = &sh.key[strand][dst];
-                        uint8_t *tt = &sh.tag[strand][dst];
-                        kk[0] = hd[r].y + bias;
-                        tt[0] = (uint8_t) seg;
-                        kk[1] = hd[r].z + bias;
-                        tt[1] = (uint8_t) seg;
-                        if (c > 2)
-                          {
-                            kk[2] = hd[r].w + bias;
-                            tt[2] = (uint8_t) seg;
-                          }
-                      }
-                    const bool need2 = fits && c > 3;
-                    if (__ballot (need2) != 0ull)
-                      {
-                        uint4 h2 = make_uint4 (0u, 0u, 0u, 0u);
-                        if (need2)
-                          h2 = *(const uint4 *) (ix.multi + (size_t) unit[r] * 4 + 4);
-                        if (need2)
-                          {
-                            uint32_t *kk = &sh.key[strand][dst];
-                            uint8_t *tt = &sh.tag[strand][dst];
-                            kk[3] = h2.x + bias;
-                            tt[3] = (uint8_t) seg;
-                            if (c > 4)
-                              {
-                                kk[4] = h2.y + bias;
-                                tt[4] = (uint8_t) seg;
-                              }
-                            if (c > 5)
-                              {
-                                kk[5] = h2.z + bias;
-                                tt[5] = (uint8_t) seg;
-                              }
-                            if (c > 6)
-                              {
-                                kk[6] = h2.w + bias;
-                                tt[6] = (uint8_t) seg;
-                              }
-                          }
-                      }
-                    unsigned long long bl = __ballot (fits && c > 7);
-                    while (bl)
-                      {
-                        const int l = __ffsll ((long long) bl) - 1;
-                        bl &= bl - 1;
-                        const int cc = (int) __shfl ((int) c, l), dd = __shfl (dst, l), st = __shfl (strand, l), sgl = __shfl (seg, l);
-                        const uint32_t bl_bias = (uint32_t) __shfl ((int) bias, l);
-                        const uint32_t *rec = ix.multi + (size_t) (uint32_t) __shfl ((int) unit[r], l) * 4 + 1;
-                        for (int q = 7 + lane; q < cc; q += 64)
-                          {
-                            sh.key[st][dd + q] = rec[q] + bl_bias;
-                            sh.tag[st][dd + q] = (uint8_t) sgl;
-                          }
+                        unit[r] = sh.key[strand][PM_SEED_CAP - 1 - i];
+                        sgv[r] = sh.tag[strand][PM_SEED_CAP - 1 - i];
+                        hd[r] = *(const uint4 *) (ix.multi + (size_t) unit[r] * 4);
                       }
                   }
-            }
+                const int limit = (i0 + 128 < nm) ? PM_SEED_CAP - nm : PM_SEED_CAP;
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+                  if (i0 + r * 64 < nm && !big)
+                    {
+                      const bool valid = i0 + r * 64 + lane < nm;
+                      const uint32_t c = valid ? hd[r].x : 0u;
+                      const int seg = sgv[r];
+                      uint32_t incl = c;
+                      for (int o = 1; o < 64; o <<= 1)
+                        {
+                          const uint32_t t = __shfl_up (incl, o);
+                          if (lane >= o)
+                            incl += t;
+                        }
+                      const int dst = nf + (int) (incl - c);
+                      nf += __builtin_amdgcn_readlane ((int) incl, 63);
+                      if (nf > limit)
+                        big = true;     // (wave-uniform) nothing more is written for this end: it goes to the big-end list
+                      const bool wr = valid && !big;
+                      const int off = (seg < cuts || cuts == 0) ? seg * idepth : last_off;
+                      const uint32_t bias = (uint32_t) (PM_DIAG_BIAS - off);
+                      if (wr)
+                        {
+                          atomicAdd (&sh.seg_cnt[strand * S + seg], (int) c);
+                          uint32_t *kk = &sh.key[strand][dst];
+                          uint8_t *tt = &sh.tag[strand][dst];
+                          kk[0] = hd[r].y + bias;
+                          tt[0] = (uint8_t) seg;
+                          kk[1] = hd[r].z + bias;
+                          tt[1] = (uint8_t) seg;
+                          if (c > 2)
+                            {
+                              kk[2] = hd[r].w + bias;
+                              tt[2] = (uint8_t) seg;
+                            }
+                        }
+                      const bool need2 = wr && c > 3;
+                      if (__ballot (need2) != 0ull)
+                        {
+                          if (need2)
+                            {
+                              const uint4 h2 = *(const uint4 *) (ix.multi + (size_t) unit[r] * 4 + 4);
+                              uint32_t *kk = &sh.key[strand][dst];
+                              uint8_t *tt = &sh.tag[strand][dst];
+                              kk[3] = h2.x + bias;
+                              tt[3] = (uint8_t) seg;
+                              if (c > 4)
+                                {
+                                  kk[4] = h2.y + bias;
+                                  tt[4] = (uint8_t) seg;
+                                }
+                              if (c > 5)
+                                {
+                                  kk[5] = h2.z + bias;
+                                  tt[5] = (uint8_t) seg;
+                                }
+                              if (c > 6)
+                                {
+                                  kk[6] = h2.w + bias;
+                                  tt[6] = (uint8_t) seg;
+                                }
+                            }
+                        }
+                      unsigned long long bl = __ballot (wr && c > 7);
+                      while (bl)
+                        {
+                          const int l = __ffsll ((long long) bl) - 1;
+                          bl &= bl - 1;
+                          const int cc = __builtin_amdgcn_readlane ((int) c, l), dd = __builtin_amdgcn_readlane (dst, l), sgl = __builtin_amdgcn_readlane (seg, l);
+                          const uint32_t bl_bias = (uint32_t) __builtin_amdgcn_readlane ((int) bias, l);
+                          const uint32_t *rec = ix.multi + (size_t) (uint32_t) __builtin_amdgcn_readlane ((int) unit[r], l) * 4 + 1;
+                          for (int q = 7 + lane; q < cc; q += 64)
+                            {
+                              sh.key[strand][dd + q] = rec[q] + bl_bias;
+                              sh.tag[strand][dd + q] = (uint8_t) sgl;
+                            }
+                        }
+                    }
+              }
+          };
+          records_strand (std::integral_constant < int, 0 > { });
+          records_strand (std::integral_constant < int, 1 > { });
           pm_wave_sync ();
-          T0 = n0 + m0;
-          T1 = n1 + m1;
-          big = T0 > PM_SEED_CAP || T1 > PM_SEED_CAP;
+          T0 = nf0;
+          T1 = nf1;
+          big = big || T0 > PM_SEED_CAP || T1 > PM_SEED_CAP;
           // pemapper.c:2200-2207: a strand is not searched when every one of its segments holds more than max_hits positions
           {
             const int c = lane < 2 * S ? sh.seg_cnt[lane] : 10000;
-            cmin0 = pm_wave_min (lane < S ? c : 10000);
-            cmin1 = pm_wave_min (lane >= S ? c : 10000);
+            cmin0 = __builtin_amdgcn_readfirstlane (pm_wave_min (lane < S ? c : 10000));
+            cmin1 = __builtin_amdgcn_readfirstlane (pm_wave_min (lane >= S ? c : 10000));
           }
         }
       // ---- P: the next end's k-mers and line requests (its bytes arrived during the previous iteration); R: the bytes of the end after
       int SP = 0, lenP = 0;
+      uint32_t kP = 0;
       if (eP < n_ends)
         {
-          lenP = rlen;
-          SP = stage_p (bufQ ^ 1);
+          SP = stage_p (kP, lenP);
         }
       if (eR < n_ends)
         load_bytes (eR);
@@ -386,84 +402,145 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? 3 : 2) void
           const int mm0 = min_match;
           const int loop_max0 = 1 + cuts - mm0;
           const bool use0 = cmin0 <= PM_MAX_HITS, use1 = cmin1 <= PM_MAX_HITS;
-          // histogram of the diagonal bins (16 diagonals wide) of both strands
+          // which segments have a position in each diagonal bin (16 diagonals wide), both strands
 #pragma unroll
           for (int i = 0; i < PM_S3_NH / 256; i++)
-            ((uint4 *) sh.u.v.hist)[lane + 64 * i] = make_uint4 (0u, 0u, 0u, 0u);
+            ((uint4 *) sh.a.v.segmask)[lane + 64 * i] = make_uint4 (0u, 0u, 0u, 0u);
           if (lane < PM_S3_NH / 32)
-            sh.u.v.candbit[lane] = 0u;
+            sh.a.v.candbit[lane] = 0u;
           pm_wave_sync ();
+          // (each pass takes the positions four rounds at a time: the LDS reads of a batch are issued together)
           for (int st = 0; st < 2; st++)
             if (st ? use1 : use0)
-              for (int i = lane; i < (st ? T1 : T0); i += 64)
-                atomicAdd (&sh.u.v.hist[pm_s3_hash (sh.key[st][i] >> 4, (unsigned) st)], 1u);
+              {
+                const int T = st ? T1 : T0;
+                for (int i0 = 0; i0 < T; i0 += 256)
+                  {
+                    uint32_t kk[4], tg[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                      {
+                        const int i = i0 + 64 * j + lane;
+                        kk[j] = i < T ? sh.key[st][i] : 0u;
+                        tg[j] = i < T ? (uint32_t) sh.tag[st][i] : 0u;
+                      }
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                      if (i0 + 64 * j + lane < T)
+                        atomicOr (&sh.a.v.segmask[pm_s3_hash (kk[j] >> 4, (unsigned) st)], 1u << tg[j]);
+                  }
+              }
           pm_wave_sync ();
-          // candidate anchors: positions of a segment the walk can reach with at least min_match positions in their three bins
-          // (everything within max_off - 1 <= 15 diagonals of an anchor lies there)
+          // candidate anchors: positions of a segment the walk can reach whose three bins hold at least min_match - 1 LATER segments
+          // (everything within max_off - 1 <= 15 diagonals of an anchor lies in those bins; colliding bins only add candidates)
           for (int st = 0; st < 2; st++)
             if (st ? use1 : use0)
-              for (int i = lane; i < (st ? T1 : T0); i += 64)
-                {
-                  const uint32_t bin = sh.key[st][i] >> 4;
-                  const int sa = sh.tag[st][i];
-                  const unsigned hc = pm_s3_hash (bin, (unsigned) st);
-                  const uint32_t c = sh.u.v.hist[pm_s3_hash (bin - 1u, (unsigned) st)] + sh.u.v.hist[hc] + sh.u.v.hist[pm_s3_hash (bin + 1u, (unsigned) st)];
-                  if (sa <= loop_max0 && c >= (uint32_t) mm0)
-                    {
-                      sh.tag[st][i] = (uint8_t) (sa | 0x80);
-                      atomicOr (&sh.u.v.candbit[hc >> 5], 1u << (hc & 31u));
-                    }
-                }
+              {
+                const int T = st ? T1 : T0;
+                for (int i0 = 0; i0 < T; i0 += 256)
+                  {
+                    uint32_t kk[4], tg[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                      {
+                        const int i = i0 + 64 * j + lane;
+                        kk[j] = i < T ? sh.key[st][i] : 0u;
+                        tg[j] = i < T ? (uint32_t) sh.tag[st][i] : 0u;
+                      }
+                    uint32_t mk[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                      {
+                        const uint32_t bin = kk[j] >> 4;
+                        mk[j] = sh.a.v.segmask[pm_s3_hash (bin - 1u, (unsigned) st)] | sh.a.v.segmask[pm_s3_hash (bin, (unsigned) st)]
+                          | sh.a.v.segmask[pm_s3_hash (bin + 1u, (unsigned) st)];
+                      }
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                      {
+                        const int i = i0 + 64 * j + lane;
+                        const int sa = (int) tg[j];
+                        if (i < T && sa <= loop_max0 && 1 + __popc (mk[j] & ~((2u << sa) - 1u)) >= mm0)
+                          {
+                            const unsigned hc = pm_s3_hash (kk[j] >> 4, (unsigned) st);
+                            sh.tag[st][i] = (uint8_t) (sa | 0x80);
+                            atomicOr (&sh.a.v.candbit[hc >> 5], 1u << (hc & 31u));
+                          }
+                      }
+                  }
+              }
           pm_wave_sync ();
           // the positions next to a candidate (same or adjacent bin), both strands, compacted
           int nR = 0;
           for (int st = 0; st < 2; st++)
             if (st ? use1 : use0)
-              for (int i0 = 0; i0 < (st ? T1 : T0); i0 += 64)
-                {
-                  const int i = i0 + lane;
-                  bool rel = false;
-                  uint32_t k = 0, tg = 0;
-                  if (i < (st ? T1 : T0))
-                    {
-                      k = sh.key[st][i];
-                      tg = sh.tag[st][i];
-                      const uint32_t bin = k >> 4;
-                      const unsigned h0 = pm_s3_hash (bin - 1u, (unsigned) st), h1 = pm_s3_hash (bin, (unsigned) st), h2 = pm_s3_hash (bin + 1u, (unsigned) st);
-                      rel = (((sh.u.v.candbit[h0 >> 5] >> (h0 & 31u)) | (sh.u.v.candbit[h1 >> 5] >> (h1 & 31u)) | (sh.u.v.candbit[h2 >> 5] >> (h2 & 31u))) & 1u) != 0u;
-                    }
-                  const unsigned long long br = __ballot (rel);
-                  if (rel)
-                    {
-                      const int at = nR + pm_lanes_below (br);
-                      if (at < PM_S3_RCAP)
-                        sh.u.v.r[at] = make_uint2 (k, (tg & 31u) | ((uint32_t) st << 5) | ((tg & 0x80u) >> 1));
-                    }
-                  nR += (int) __popcll (br);
-                }
+              {
+                const int T = st ? T1 : T0;
+                for (int i0 = 0; i0 < T; i0 += 256)
+                  {
+                    uint32_t kk[4], tg[4], cb[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                      {
+                        const int i = i0 + 64 * j + lane;
+                        kk[j] = i < T ? sh.key[st][i] : 0u;
+                        tg[j] = i < T ? (uint32_t) sh.tag[st][i] : 0u;
+                      }
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                      {
+                        const uint32_t bin = kk[j] >> 4;
+                        const unsigned h0 = pm_s3_hash (bin - 1u, (unsigned) st), h1 = pm_s3_hash (bin, (unsigned) st), h2 = pm_s3_hash (bin + 1u, (unsigned) st);
+                        cb[j] = ((sh.a.v.candbit[h0 >> 5] >> (h0 & 31u)) | (sh.a.v.candbit[h1 >> 5] >> (h1 & 31u)) | (sh.a.v.candbit[h2 >> 5] >> (h2 & 31u))) & 1u;
+                      }
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                      if (i0 + 64 * j < T)
+                        {
+                          const bool rel = i0 + 64 * j + lane < T && cb[j] != 0u;
+                          const unsigned long long br = __ballot (rel);
+                          if (rel)
+                            {
+                              const int at = nR + pm_lanes_below (br);
+                              if (at < PM_S3_RCAP)
+                                sh.a.v.r[at] = make_uint2 (kk[j], (tg[j] & 31u) | ((uint32_t) st << 5) | ((tg[j] & 0x80u) >> 1));
+                            }
+                          nR += (int) __popcll (br);
+                        }
+                  }
+              }
           pm_wave_sync ();
           if (nR > PM_S3_RCAP)
             big = true;         // a repeat: left to the monolithic kernel
           else
             {
-              // tot_found of every candidate (pemapper.c:2241-2249): 1 + the later segments with a position within max_off of its diagonal
+              // tot_found of every candidate (pemapper.c:2241-2249): 1 + the later segments with a position within max_off of its
+              // diagonal; the anchors that reach min_match, per strand, compacted: sv[] (strand 0 from the front, strand 1 from the back)
+              int ns0 = 0, ns1 = 0;
               for (int i0 = 0; i0 < nR; i0 += 64)
                 {
                   const int i = i0 + lane;
-                  const uint2 me = i < nR ? sh.u.v.r[i] : make_uint2 (0u, 0u);
+                  const uint2 me = i < nR ? sh.a.v.r[i] : make_uint2 (0u, 0u);
                   const bool cand = (me.y & 0x40u) != 0u;
                   uint32_t bits = 0;
                   if (__ballot (cand) != 0ull)
                     for (int y = 0; y < nR; y++)
                       {
-                        const uint2 o = sh.u.v.r[y];
+                        const uint2 o = sh.a.v.r[y];
                         const uint32_t dd = o.x - me.x + (uint32_t) (max_off - 1);   // |diag_y - diag_a| < max_off in wrapping arithmetic
                         if (dd <= span && ((o.y ^ me.y) & 0x20u) == 0u && (o.y & 31u) > (me.y & 31u))
                           bits |= 1u << (o.y & 31u);
                       }
                   const int tf = 1 + __popc (bits);
-                  if (i < nR)
-                    sh.u.v.rtf[i] = (uint8_t) ((cand && tf >= mm0) ? tf : 0);
+                  const bool surv = cand && tf >= mm0;
+                  const bool s1 = surv && (me.y & 0x20u) != 0u, s0 = surv && (me.y & 0x20u) == 0u;
+                  const unsigned long long b0 = __ballot (s0), b1 = __ballot (s1);
+                  if (s0)
+                    sh.a.v.sv[ns0 + pm_lanes_below (b0)] = make_uint2 (me.x, (me.y & 31u) | ((uint32_t) tf << 8));
+                  if (s1)
+                    sh.a.v.sv[PM_S3_RCAP - 1 - (ns1 + pm_lanes_below (b1))] = make_uint2 (me.x, (me.y & 31u) | ((uint32_t) tf << 8));
+                  ns0 += (int) __popcll (b0);
+                  ns1 += (int) __popcll (b1);
                 }
               pm_wave_sync ();
               bool go_on = true;
@@ -475,27 +552,21 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? 3 : 2) void
                       continue;
                     }
                   // ---- walk order of this strand's surviving anchors: segment ascending, position ascending inside a segment
-                  int ns = 0;
-                  for (int i0 = 0; i0 < nR; i0 += 64)
+                  const int ns = strand ? ns1 : ns0;
+                  const uint2 *svp = strand ? &sh.a.v.sv[PM_S3_RCAP - ns1] : &sh.a.v.sv[0];
+                  for (int i0 = 0; i0 < ns; i0 += 64)
                     {
                       const int i = i0 + lane;
-                      const uint2 me = i < nR ? sh.u.v.r[i] : make_uint2 (0u, 0u);
-                      const bool sv = i < nR && sh.u.v.rtf[i] != 0 && (int) ((me.y >> 5) & 1u) == strand;
-                      const unsigned long long bsv = __ballot (sv);
-                      if (bsv != 0ull)
+                      const uint2 me = i < ns ? svp[i] : make_uint2 (0u, 0u);
+                      const uint64_t ck = ((uint64_t) (me.y & 31u) << 32) | me.x;
+                      int rank = 0;
+                      for (int y = 0; y < ns; y++)
                         {
-                          const uint64_t ck = ((uint64_t) (me.y & 31u) << 32) | me.x;
-                          int rank = 0;
-                          for (int y = 0; y < nR; y++)
-                            {
-                              const uint2 o = sh.u.v.r[y];
-                              const bool osv = sh.u.v.rtf[y] != 0 && (int) ((o.y >> 5) & 1u) == strand;
-                              rank += (osv && ((((uint64_t) (o.y & 31u)) << 32) | o.x) < ck) ? 1 : 0;
-                            }
-                          if (sv)
-                            sh.u.v.order[rank] = (uint16_t) i;
+                          const uint2 o = svp[y];
+                          rank += (((((uint64_t) (o.y & 31u)) << 32) | o.x) < ck) ? 1 : 0;
                         }
-                      ns += (int) __popcll (bsv);
+                      if (i < ns)
+                        sh.a.v.order[rank] = (uint16_t) i;
                     }
                   pm_wave_sync ();
                   // ---- the walk's state machine on the ranked anchors (pemapper.c:2251-2284)
@@ -505,9 +576,9 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? 3 : 2) void
                     {
                       const int i = i0 + lane;
                       const bool act = i < ns;
-                      const int ri = act ? (int) sh.u.v.order[i] : 0;
-                      const uint2 a = sh.u.v.r[ri];
-                      const int tf = act ? (int) sh.u.v.rtf[ri] : 0;
+                      const int ri = act ? (int) sh.a.v.order[i] : 0;
+                      const uint2 a = svp[ri];
+                      const int tf = act ? (int) (a.y >> 8) : 0;
                       const int my_loop = act ? (int) (a.y & 31u) : 0;
                       const int my_off = (my_loop < cuts || cuts == 0) ? my_loop * idepth : last_off;
                       const uint32_t my_ml = (act ? a.x : 0u) - (uint32_t) (PM_DIAG_BIAS - my_off);        // the position itself
@@ -516,8 +587,8 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? 3 : 2) void
                         {
                           const int l = __ffsll ((long long) cnd) - 1;
                           cnd &= cnd - 1;
-                          const int tfl = __shfl (tf, l);
-                          const int loop = __shfl (my_loop, l);
+                          const int tfl = __builtin_amdgcn_readlane (tf, l);
+                          const int loop = __builtin_amdgcn_readlane (my_loop, l);
                           if (loop != cur_loop)
                             {
                               // the walk's loop bound is tested when a segment is entered, not inside it (pemapper.c:2216)
@@ -528,8 +599,8 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? 3 : 2) void
                                 }
                               cur_loop = loop;
                             }
-                          const int off_a = __shfl (my_off, l);
-                          const uint32_t ml = (uint32_t) __shfl ((int) my_ml, l);
+                          const int off_a = __builtin_amdgcn_readlane (my_off, l);
+                          const uint32_t ml = (uint32_t) __builtin_amdgcn_readlane ((int) my_ml, l);
                           if (tfl > min_match)
                             {
                               min_match = tfl;
@@ -604,7 +675,7 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? 3 : 2) void
       eR = next_end ();
       SQ = SP;
       lenQ = lenP;
-      bufQ ^= 1;
+      kQ = kP;
     }
   if (lane == 0 && n_pos)
     atomicAdd (out.positions, n_pos);

@@ -4,7 +4,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpemap_hip.so")
+# (PEMAP_LIB: another build of the same library, for A/B runs of compile-time variants -- tools/variants.sh)
+LIB_PATH = os.environ.get("PEMAP_LIB") or os.path.join(HERE, "libpemap_hip.so")
 MAX_HITS = 200
 MIN_READ = 16
 MAX_READ = 278
