@@ -118,7 +118,7 @@ static void read_knobs (PmKnobs & k)
   k.vote_on_mem = env_int ("PEMAP_VOTE_ON_MEM", -1);
   k.vote_stream_prio_set = getenv ("PEMAP_VOTE_STREAM_PRIO") != nullptr;
   k.vote_stream_prio = env_int ("PEMAP_VOTE_STREAM_PRIO", 0);
-  k.chunk_pairs = env_int ("PEMAP_CHUNK_PAIRS", 131072);
+  k.chunk_pairs = env_int ("PEMAP_CHUNK_PAIRS", 262144);
   k.d2h_stream = env_int ("PEMAP_D2H_STREAM", 0);
   k.seed_phase = k.vote_probe = 0;
 #ifdef PEMAP_TIMING_PROBES
@@ -194,6 +194,7 @@ struct pemap_dev
   hipEvent_t ev_lists_ready[2], ev_lists_free[2];
   PmLists lists[2];
   int lists_cap;
+  bool lists_arrays;            // the (key, segment) lists exist (not needed, and not allocated, while the fused seed kernel serves)
   PmChunkCtr *d_chunk_ctr;
   std::vector < hipEvent_t > evs;
   int big_grid, scratch_blocks;
@@ -301,6 +302,7 @@ extern "C" int pemap_dev_create (pemap_dev ** out, int device_id)
   d->stream2 = nullptr;
   memset (d->lists, 0, sizeof (d->lists));
   d->lists_cap = 0;
+  d->lists_arrays = false;
   d->d_chunk_ctr = nullptr;
   d->last_big = 0;
   d->ring_cap = 0;
@@ -1123,7 +1125,7 @@ static void launch_lookup (pemap_dev * d, const RunCtx & c, int slot, PmChunkCtr
   const int lv = d->kn.lookup_v;
   // waves per CU: 6 (with the replicas 4 was the optimum while the SW kernel scored every problem: one per SIMD; since the
   // gapless rule took 78 % of its problems away the two streams balance at 6)
-  const int lw = d->kn.lookup_waves >= 0 ? d->kn.lookup_waves : (c.ix.n_rep == 8) ? (lv == 3 ? 5 : lv == 2 ? 3 : 6) : 6;
+  const int lw = d->kn.lookup_waves >= 0 ? d->kn.lookup_waves : (c.ix.n_rep == 8) ? (lv == 3 ? 7 : lv == 2 ? 3 : 6) : 6;
   int lgrid = lw * d->n_cus;
   if (lgrid > c.b.n_ends)
     lgrid = c.b.n_ends;
@@ -1424,19 +1426,34 @@ static int ensure_pipeline (pemap_dev * d, int chunk_ends)
       for (size_t i = 0; i < d->evs.size (); i++)
         HIPCHK (d, hipEventCreate (&d->evs[i]));
     }
-  if (chunk_ends > d->lists_cap)
+  if (chunk_ends > d->lists_cap || (chunk_ends > 0 && !pm_fused (d) && !d->lists_arrays))
     {
+      if (chunk_ends < d->lists_cap)
+        chunk_ends = d->lists_cap;
+      // (the look-up kernels of a pending run may still be writing the old arrays)
+      if (d->run_pending)
+        {
+          TRY (absorb_run (d));
+          d->run_pending = false;
+        }
       for (int i = 0; i < 2; i++)
         {
           hipFree (d->lists[i].hdr);
           hipFree (d->lists[i].key);
           hipFree (d->lists[i].seg);
           hipFree (d->lists[i].big_list);
-          TRY (dev_alloc (d, &d->lists[i].hdr, (size_t) chunk_ends));
-          TRY (dev_alloc (d, &d->lists[i].key, (size_t) chunk_ends * 2 * PM_SEED_CAP));
-          TRY (dev_alloc (d, &d->lists[i].seg, (size_t) chunk_ends * 2 * PM_SEED_CAP));
+          // (the fused seed kernel keeps the lists in LDS: only the big-end list is needed then)
+          const size_t list_ends = pm_fused (d) ? 0 : (size_t) chunk_ends;
+          d->lists[i].hdr = nullptr;
+          d->lists[i].key = nullptr;
+          d->lists[i].seg = nullptr;
+          d->lists[i].big_list = nullptr;
+          TRY (dev_alloc (d, &d->lists[i].hdr, list_ends));
+          TRY (dev_alloc (d, &d->lists[i].key, list_ends * 2 * PM_SEED_CAP));
+          TRY (dev_alloc (d, &d->lists[i].seg, list_ends * 2 * PM_SEED_CAP));
           TRY (dev_alloc (d, &d->lists[i].big_list, (size_t) chunk_ends));
         }
+      d->lists_arrays = !pm_fused (d);
       d->lists_cap = chunk_ends;
     }
   return 0;

@@ -28,17 +28,21 @@
 #ifndef PM_S3_WAVES_PER_EU
 #define PM_S3_WAVES_PER_EU 3
 #endif
-#define PM_S3_RCAP 256          // positions next to candidate anchors, both strands together
+#ifndef PM_S3_RCAP
+#define PM_S3_RCAP 160          // positions next to candidate anchors, both strands together
+#endif
 
 template < int SMAX > struct __align__ (16) PmSeed3Shared
 {
   static constexpr int NSEG = 2 * SMAX;
   union
   {
-    uint32_t lines[NSEG * 128];         // 2 x SMAX x 8 lines of 16 entries: needed while the entries are decoded ...
-    struct                              // ... the vote's tables afterwards (the next end's lines wait in registers)
+    uint32_t lines[SMAX * 128];         // ONE strand's SMAX x 8 lines of 16 entries (the other strand's wait in registers) ...
+    struct                              // ... the vote's tables afterwards (the next end's lines wait in registers too)
     {
-      uint32_t segmask[PM_S3_NH];       // bit s: a position of segment s has its diagonal in this bin
+      // bit s of cell h: a position of segment s has its diagonal in a bin that hashes to h.  16-bit cells, two to a word, while
+      // the segments fit (reads of up to 256 bases)
+      uint32_t segmask[SMAX <= 16 ? PM_S3_NH / 2 : PM_S3_NH];
       uint32_t candbit[PM_S3_NH / 32];
       uint2 r[PM_S3_RCAP];              // x = key, y = segment | strand << 5 | candidate << 6
       uint2 sv[PM_S3_RCAP];             // the surviving anchors: x = key, y = segment | tot_found << 8 (strand 0 from the front, 1 from the back)
@@ -59,6 +63,22 @@ template < int SMAX > struct __align__ (16) PmSeed3Shared
 __device__ __forceinline__ unsigned pm_s3_hash (uint32_t bin, unsigned strand)
 {
   return ((bin * 2u + strand) * 2654435761u) >> (32 - PM_S3_NH_LOG2);
+}
+
+// the bin table's cells: 16 bits each (two to a word) for up to 16 segments, 32 bits beyond
+template < int SMAX > __device__ __forceinline__ void pm_s3_mask_or (uint32_t * tab, unsigned h, unsigned seg)
+{
+  if (SMAX <= 16)
+    atomicOr (&tab[h >> 1], (1u << seg) << (16u * (h & 1u)));
+  else
+    atomicOr (&tab[h], 1u << seg);
+}
+
+template < int SMAX > __device__ __forceinline__ uint32_t pm_s3_mask_get (const uint32_t * tab, unsigned h)
+{
+  if (SMAX <= 16)
+    return (tab[h >> 1] >> (16u * (h & 1u))) & 0xFFFFu;
+  return tab[h];
 }
 
 __device__ __forceinline__ int pm_lanes_below (unsigned long long m)
@@ -206,11 +226,20 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
       int T0 = 0, T1 = 0, cmin0 = 0, cmin1 = 0;
       if (S > 0)
         {
-          // ---- A: the lines of this end (requested one iteration ago) from registers to LDS
+          // ---- A: the lines of this end (requested one iteration ago) go from registers to LDS one strand at a time (lines
+          //      [strand * S * 8, (strand + 1) * S * 8) of the 2 x S x 8), so that the buffer is half the size
+          auto lines_to_lds = [&] (int strand)
+          {
+            const int first = strand * S * 8, last = first + S * 8;
 #pragma unroll
-          for (int r = 0; r < SMAX; r++)
-            if (r * 16 < 2 * S * 8)
-              *(uint4 *) (&sh.a.lines[(r * 16 + (lane >> 2)) * 16 + (lane & 3) * 4]) = ln[r];
+            for (int r = 0; r < SMAX; r++)
+              {
+                const int li = r * 16 + (lane >> 2);
+                if (li >= first && li < last)
+                  *(uint4 *) (&sh.a.lines[(li - first) * 16 + (lane & 3) * 4]) = ln[r];
+              }
+          };
+          lines_to_lds (0);
           if (lane < 2 * SMAX)
             sh.seg_cnt[lane] = 0;
           pm_wave_sync ();
@@ -223,15 +252,23 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
           {
             constexpr int strand = decltype (ST)::value;
             int &nf = strand ? nf1 : nf0, &nm = strand ? nm1 : nm0;
+            // neighbour `lane` of segment sg: its entry, from the segment's 8 lines
+            auto entry_of = [&] (int sg)->uint32_t
+            {
+              const uint32_t k = (uint32_t) __builtin_amdgcn_readlane ((int) kQ, sg);
+              const uint32_t cur = (k >> nb_sh) & 3u;
+              const uint32_t alt = nb_a + (nb_a >= cur ? 1u : 0u);
+              const uint32_t nbk = (k & nb_keep) | ((alt << nb_sh) & nb_alt_on);
+              return lane < 49 ? sh.a.lines[(sg - strand * S) * 128 + nb_pw + ((nbk >> nb_p4) & 15u)] : 0xFFFFFFFFu;
+            };
+            uint32_t ent_next = entry_of (strand * S);
 #pragma unroll 1
             for (int seg = 0; seg < S; seg++)
               {
                 const int sg = strand * S + seg;
-                const uint32_t k = (uint32_t) __builtin_amdgcn_readlane ((int) kQ, sg);
-                const uint32_t cur = (k >> nb_sh) & 3u;
-                const uint32_t alt = nb_a + (nb_a >= cur ? 1u : 0u);
-                const uint32_t nbk = (k & nb_keep) | ((alt << nb_sh) & nb_alt_on);
-                const uint32_t ent = lane < 49 ? sh.a.lines[sg * 128 + nb_pw + ((nbk >> nb_p4) & 15u)] : 0xFFFFFFFFu;
+                const uint32_t ent = ent_next;
+                if (seg + 1 < S)
+                  ent_next = entry_of (sg + 1);         // (its LDS read flies while this segment is filed)
                 if (__ballot (ent == 0xFFFFFFFEu) != 0ull)
                   continue;
                 const bool single = ent < multi_base, multi = ent >= multi_base && ent != 0xFFFFFFFFu;
@@ -257,6 +294,9 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
               }
           };
           decode_strand (std::integral_constant < int, 0 > { });
+          pm_wave_sync ();
+          lines_to_lds (1);
+          pm_wave_sync ();
           decode_strand (std::integral_constant < int, 1 > { });
           pm_wave_sync ();
           // ---- C: the records: {count, positions...} in 16-byte units; the first unit answers for buckets of up to 3 positions,
@@ -404,7 +444,7 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
           const bool use0 = cmin0 <= PM_MAX_HITS, use1 = cmin1 <= PM_MAX_HITS;
           // which segments have a position in each diagonal bin (16 diagonals wide), both strands
 #pragma unroll
-          for (int i = 0; i < PM_S3_NH / 256; i++)
+          for (int i = 0; i < (int) (sizeof (sh.a.v.segmask) / 1024); i++)
             ((uint4 *) sh.a.v.segmask)[lane + 64 * i] = make_uint4 (0u, 0u, 0u, 0u);
           if (lane < PM_S3_NH / 32)
             sh.a.v.candbit[lane] = 0u;
@@ -427,10 +467,11 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
 #pragma unroll
                     for (int j = 0; j < 4; j++)
                       if (i0 + 64 * j + lane < T)
-                        atomicOr (&sh.a.v.segmask[pm_s3_hash (kk[j] >> 4, (unsigned) st)], 1u << tg[j]);
+                        pm_s3_mask_or < SMAX > (sh.a.v.segmask, pm_s3_hash (kk[j] >> 4, (unsigned) st), tg[j]);
                   }
               }
           pm_wave_sync ();
+          unsigned long long any_cand = 0ull;
           // candidate anchors: positions of a segment the walk can reach whose three bins hold at least min_match - 1 LATER segments
           // (everything within max_off - 1 <= 15 diagonals of an anchor lies in those bins; colliding bins only add candidates)
           for (int st = 0; st < 2; st++)
@@ -452,15 +493,17 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
                     for (int j = 0; j < 4; j++)
                       {
                         const uint32_t bin = kk[j] >> 4;
-                        mk[j] = sh.a.v.segmask[pm_s3_hash (bin - 1u, (unsigned) st)] | sh.a.v.segmask[pm_s3_hash (bin, (unsigned) st)]
-                          | sh.a.v.segmask[pm_s3_hash (bin + 1u, (unsigned) st)];
+                        mk[j] = pm_s3_mask_get < SMAX > (sh.a.v.segmask, pm_s3_hash (bin - 1u, (unsigned) st)) | pm_s3_mask_get < SMAX > (sh.a.v.segmask, pm_s3_hash (bin, (unsigned) st))
+                          | pm_s3_mask_get < SMAX > (sh.a.v.segmask, pm_s3_hash (bin + 1u, (unsigned) st));
                       }
 #pragma unroll
                     for (int j = 0; j < 4; j++)
                       {
                         const int i = i0 + 64 * j + lane;
                         const int sa = (int) tg[j];
-                        if (i < T && sa <= loop_max0 && 1 + __popc (mk[j] & ~((2u << sa) - 1u)) >= mm0)
+                        const bool is_cand = i < T && sa <= loop_max0 && 1 + __popc (mk[j] & ~((2u << sa) - 1u)) >= mm0;
+                        any_cand |= __ballot (is_cand);
+                        if (is_cand)
                           {
                             const unsigned hc = pm_s3_hash (kk[j] >> 4, (unsigned) st);
                             sh.tag[st][i] = (uint8_t) (sa | 0x80);
@@ -472,7 +515,7 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
           pm_wave_sync ();
           // the positions next to a candidate (same or adjacent bin), both strands, compacted
           int nR = 0;
-          for (int st = 0; st < 2; st++)
+          for (int st = 0; st < 2 && any_cand != 0ull; st++)      // (most ends that do not map have no candidate at all)
             if (st ? use1 : use0)
               {
                 const int T = st ? T1 : T0;
@@ -524,12 +567,18 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
                   const bool cand = (me.y & 0x40u) != 0u;
                   uint32_t bits = 0;
                   if (__ballot (cand) != 0ull)
-                    for (int y = 0; y < nR; y++)
+                    for (int c0 = 0; c0 < nR; c0 += 64)
                       {
-                        const uint2 o = sh.a.v.r[y];
-                        const uint32_t dd = o.x - me.x + (uint32_t) (max_off - 1);   // |diag_y - diag_a| < max_off in wrapping arithmetic
-                        if (dd <= span && ((o.y ^ me.y) & 0x20u) == 0u && (o.y & 31u) > (me.y & 31u))
-                          bits |= 1u << (o.y & 31u);
+                        // the others, 64 at a time in registers: handed round by readlane, no LDS trip per pair
+                        const uint2 oth = c0 + lane < nR ? sh.a.v.r[c0 + lane] : make_uint2 (0u, 0u);
+                        const int ny = min (64, nR - c0);
+                        for (int y = 0; y < ny; y++)
+                          {
+                            const uint32_t ox = (uint32_t) __builtin_amdgcn_readlane ((int) oth.x, y), oy = (uint32_t) __builtin_amdgcn_readlane ((int) oth.y, y);
+                            const uint32_t dd = ox - me.x + (uint32_t) (max_off - 1);   // |diag_y - diag_a| < max_off in wrapping arithmetic
+                            if (dd <= span && ((oy ^ me.y) & 0x20u) == 0u && (oy & 31u) > (me.y & 31u))
+                              bits |= 1u << (oy & 31u);
+                          }
                       }
                   const int tf = 1 + __popc (bits);
                   const bool surv = cand && tf >= mm0;
@@ -560,10 +609,15 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
                       const uint2 me = i < ns ? svp[i] : make_uint2 (0u, 0u);
                       const uint64_t ck = ((uint64_t) (me.y & 31u) << 32) | me.x;
                       int rank = 0;
-                      for (int y = 0; y < ns; y++)
+                      for (int c0 = 0; c0 < ns; c0 += 64)
                         {
-                          const uint2 o = svp[y];
-                          rank += (((((uint64_t) (o.y & 31u)) << 32) | o.x) < ck) ? 1 : 0;
+                          const uint2 oth = c0 + lane < ns ? svp[c0 + lane] : make_uint2 (0u, 0u);
+                          const int ny = min (64, ns - c0);
+                          for (int y = 0; y < ny; y++)
+                            {
+                              const uint32_t ox = (uint32_t) __builtin_amdgcn_readlane ((int) oth.x, y), oy = (uint32_t) __builtin_amdgcn_readlane ((int) oth.y, y);
+                              rank += (((((uint64_t) (oy & 31u)) << 32) | ox) < ck) ? 1 : 0;
+                            }
                         }
                       if (i < ns)
                         sh.a.v.order[rank] = (uint16_t) i;
