@@ -56,14 +56,12 @@ def sw_geometry(L):
 
 
 def lookup_kernel_name(n_rep):
-    if os.environ.get("PEMAP_LOOKUP_WAVES", "6") == "0":
+    """the kernel that serves the look-ups (with the 8 table replicas, by default, the fused look-up + vote kernel)"""
+    if os.environ.get("PEMAP_LOOKUP_WAVES", "7") == "0":
         return "pm_lookup_kernel"
     if not n_rep:
         return "pm_lookup_wave_kernel"
-    return {"2": "pm_lookup_rep2_kernel", "3": "pm_lookup_rep3_kernel"}.get(os.environ.get("PEMAP_LOOKUP_V", ""), None) or DEFAULT_LOOKUP
-
-
-DEFAULT_LOOKUP = "pm_lookup_rep_kernel"
+    return {"1": "pm_lookup_rep_kernel", "2": "pm_lookup_rep2_kernel", "3": "pm_seed3_kernel"}[os.environ.get("PEMAP_LOOKUP_V", "3")]
 
 
 def mapper_leg(dev, a, L, B, steps, warmup, rank, world, barrier, allmax, indel_read_frac=0.0, seed_off=7, seam=True):
@@ -393,7 +391,7 @@ def pmc_traffic(kernel, gsize, B, L):
     MI355X_MICROARCH.md applies to coalesced streams)."""
     if not (gsize == 3100000000 and B == 1000000 and L == 150):
         return None, None
-    for name in ("r02_bench_pmc.json", "r01_bench_pmc_final3.json"):
+    for name in ("r02_bench_pmc.json",):
         path = os.path.join(ROOT, "profiles", name)
         try:
             pm = json.load(open(path))
@@ -404,8 +402,8 @@ def pmc_traffic(kernel, gsize, B, L):
                         if k.startswith("pm_"):       # the mapping path's kernels (not the index build or the generators)
                             tot += v["mean_KB_per_launch"] * v["launches"] / pm.get("steps", 3)
                 return round(tot * 1024.0), "profiles/" + name
-            if name.startswith("r01") and kernel != "pm_vote_wave_kernel" and kernel != "pm_lookup_rep_kernel":
-                continue
+            if name.startswith("r01"):
+                continue            # round 1's kernels are not this pipeline's
             f = [v for k, v in pm["FETCH_SIZE"].items() if k.startswith(kernel)][0]["mean_KB_per_launch"]
             w = [v for k, v in pm["WRITE_SIZE"].items() if k.startswith(kernel)][0]["mean_KB_per_launch"]
             return round((f + w) * 1024.0), "profiles/" + name

@@ -35,6 +35,14 @@
 template < int SMAX > struct __align__ (16) PmSeed3Shared
 {
   static constexpr int NSEG = 2 * SMAX;
+  // positions a strand's list holds: 1,024 for reads of up to 160 bases (10 segments x 49 look-ups, most of them empty or single);
+  // twice that for longer reads, whose 13..19 segments gather in proportion (2 x 250 bp: 5 % of the ends passed 1,024 and took the slow
+  // monolithic kernel, half of that configuration's seed time)
+  static constexpr int CAP = SMAX <= 10 ? PM_SEED_CAP : 2 * PM_SEED_CAP;
+  // cells of the bin table and positions kept next to candidate anchors: more of both for the longer reads' fuller lists
+  static constexpr int NH_LOG2 = SMAX <= 10 ? PM_S3_NH_LOG2 : PM_S3_NH_LOG2 + 1;
+  static constexpr int NH = 1 << NH_LOG2;
+  static constexpr int RCAP = SMAX <= 10 ? PM_S3_RCAP : 256;
   union
   {
     uint32_t lines[SMAX * 128];         // ONE strand's SMAX x 8 lines of 16 entries (the other strand's wait in registers) ...
@@ -42,17 +50,17 @@ template < int SMAX > struct __align__ (16) PmSeed3Shared
     {
       // bit s of cell h: a position of segment s has its diagonal in a bin that hashes to h.  16-bit cells, two to a word, while
       // the segments fit (reads of up to 256 bases)
-      uint32_t segmask[SMAX <= 16 ? PM_S3_NH / 2 : PM_S3_NH];
-      uint32_t candbit[PM_S3_NH / 32];
-      uint2 r[PM_S3_RCAP];              // x = key, y = segment | strand << 5 | candidate << 6
-      uint2 sv[PM_S3_RCAP];             // the surviving anchors: x = key, y = segment | tot_found << 8 (strand 0 from the front, 1 from the back)
-      uint16_t order[PM_S3_RCAP];
+      uint32_t segmask[SMAX <= 16 ? NH / 2 : NH];
+      uint32_t candbit[NH / 32];
+      uint2 r[RCAP];                    // x = key, y = segment | strand << 5 | candidate << 6
+      uint2 sv[RCAP];                   // the surviving anchors: x = key, y = segment | tot_found << 8 (strand 0 from the front, 1 from the back)
+      uint16_t order[RCAP];
     } v;
   } a;
   // diagonal keys m + PM_DIAG_BIAS - offset(segment) per strand, from the front; while the entries are decoded the entries that
   // point to a record wait at the back (a strand has at most 49 x S <= 931 look-ups, each of them one or the other)
-  uint32_t key[2][PM_SEED_CAP];
-  uint8_t tag[2][PM_SEED_CAP];          // segment of the position; bit 7: candidate anchor
+  uint32_t key[2][CAP];
+  uint8_t tag[2][CAP];                  // segment of the position; bit 7: candidate anchor
   uint32_t hits[PM_MAX_HITS];
   uint16_t hits_off[PM_MAX_HITS];
   uint8_t hits_or[PM_MAX_HITS];
@@ -60,9 +68,9 @@ template < int SMAX > struct __align__ (16) PmSeed3Shared
   uint8_t seq[2][320];                  // 2-bit codes of the end whose k-mers are being formed
 };
 
-__device__ __forceinline__ unsigned pm_s3_hash (uint32_t bin, unsigned strand)
+template < int NH_LOG2 > __device__ __forceinline__ unsigned pm_s3_hash_t (uint32_t bin, unsigned strand)
 {
-  return ((bin * 2u + strand) * 2654435761u) >> (32 - PM_S3_NH_LOG2);
+  return ((bin * 2u + strand) * 2654435761u) >> (32 - NH_LOG2);
 }
 
 // the bin table's cells: 16 bits each (two to a word) for up to 16 segments, 32 bits beyond
@@ -282,7 +290,7 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
                   }
                 if (multi)
                   {
-                    const int at = PM_SEED_CAP - 1 - (nm + pm_lanes_below (bm));
+                    const int at = SH::CAP - 1 - (nm + pm_lanes_below (bm));
                     sh.key[strand][at] = ent - multi_base;      // the record's first 16-byte unit
                     sh.tag[strand][at] = (uint8_t) seg;
                   }
@@ -323,12 +331,12 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
                     unit[r] = 0;
                     if (i < nm)
                       {
-                        unit[r] = sh.key[strand][PM_SEED_CAP - 1 - i];
-                        sgv[r] = sh.tag[strand][PM_SEED_CAP - 1 - i];
+                        unit[r] = sh.key[strand][SH::CAP - 1 - i];
+                        sgv[r] = sh.tag[strand][SH::CAP - 1 - i];
                         hd[r] = *(const uint4 *) (ix.multi + (size_t) unit[r] * 4);
                       }
                   }
-                const int limit = (i0 + 128 < nm) ? PM_SEED_CAP - nm : PM_SEED_CAP;
+                const int limit = (i0 + 128 < nm) ? SH::CAP - nm : SH::CAP;
 #pragma unroll
                 for (int r = 0; r < 2; r++)
                   if (i0 + r * 64 < nm && !big)
@@ -414,7 +422,7 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
           pm_wave_sync ();
           T0 = nf0;
           T1 = nf1;
-          big = big || T0 > PM_SEED_CAP || T1 > PM_SEED_CAP;
+          big = big || T0 > SH::CAP || T1 > SH::CAP;
           // pemapper.c:2200-2207: a strand is not searched when every one of its segments holds more than max_hits positions
           {
             const int c = lane < 2 * S ? sh.seg_cnt[lane] : 10000;
@@ -446,8 +454,8 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
 #pragma unroll
           for (int i = 0; i < (int) (sizeof (sh.a.v.segmask) / 1024); i++)
             ((uint4 *) sh.a.v.segmask)[lane + 64 * i] = make_uint4 (0u, 0u, 0u, 0u);
-          if (lane < PM_S3_NH / 32)
-            sh.a.v.candbit[lane] = 0u;
+          for (int i = lane; i < SH::NH / 32; i += 64)
+            sh.a.v.candbit[i] = 0u;
           pm_wave_sync ();
           // (each pass takes the positions four rounds at a time: the LDS reads of a batch are issued together)
           for (int st = 0; st < 2; st++)
@@ -467,7 +475,7 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
 #pragma unroll
                     for (int j = 0; j < 4; j++)
                       if (i0 + 64 * j + lane < T)
-                        pm_s3_mask_or < SMAX > (sh.a.v.segmask, pm_s3_hash (kk[j] >> 4, (unsigned) st), tg[j]);
+                        pm_s3_mask_or < SMAX > (sh.a.v.segmask, pm_s3_hash_t < SH::NH_LOG2 > (kk[j] >> 4, (unsigned) st), tg[j]);
                   }
               }
           pm_wave_sync ();
@@ -493,8 +501,8 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
                     for (int j = 0; j < 4; j++)
                       {
                         const uint32_t bin = kk[j] >> 4;
-                        mk[j] = pm_s3_mask_get < SMAX > (sh.a.v.segmask, pm_s3_hash (bin - 1u, (unsigned) st)) | pm_s3_mask_get < SMAX > (sh.a.v.segmask, pm_s3_hash (bin, (unsigned) st))
-                          | pm_s3_mask_get < SMAX > (sh.a.v.segmask, pm_s3_hash (bin + 1u, (unsigned) st));
+                        mk[j] = pm_s3_mask_get < SMAX > (sh.a.v.segmask, pm_s3_hash_t < SH::NH_LOG2 > (bin - 1u, (unsigned) st)) | pm_s3_mask_get < SMAX > (sh.a.v.segmask, pm_s3_hash_t < SH::NH_LOG2 > (bin, (unsigned) st))
+                          | pm_s3_mask_get < SMAX > (sh.a.v.segmask, pm_s3_hash_t < SH::NH_LOG2 > (bin + 1u, (unsigned) st));
                       }
 #pragma unroll
                     for (int j = 0; j < 4; j++)
@@ -505,7 +513,7 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
                         any_cand |= __ballot (is_cand);
                         if (is_cand)
                           {
-                            const unsigned hc = pm_s3_hash (kk[j] >> 4, (unsigned) st);
+                            const unsigned hc = pm_s3_hash_t < SH::NH_LOG2 > (kk[j] >> 4, (unsigned) st);
                             sh.tag[st][i] = (uint8_t) (sa | 0x80);
                             atomicOr (&sh.a.v.candbit[hc >> 5], 1u << (hc & 31u));
                           }
@@ -533,7 +541,7 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
                     for (int j = 0; j < 4; j++)
                       {
                         const uint32_t bin = kk[j] >> 4;
-                        const unsigned h0 = pm_s3_hash (bin - 1u, (unsigned) st), h1 = pm_s3_hash (bin, (unsigned) st), h2 = pm_s3_hash (bin + 1u, (unsigned) st);
+                        const unsigned h0 = pm_s3_hash_t < SH::NH_LOG2 > (bin - 1u, (unsigned) st), h1 = pm_s3_hash_t < SH::NH_LOG2 > (bin, (unsigned) st), h2 = pm_s3_hash_t < SH::NH_LOG2 > (bin + 1u, (unsigned) st);
                         cb[j] = ((sh.a.v.candbit[h0 >> 5] >> (h0 & 31u)) | (sh.a.v.candbit[h1 >> 5] >> (h1 & 31u)) | (sh.a.v.candbit[h2 >> 5] >> (h2 & 31u))) & 1u;
                       }
 #pragma unroll
@@ -545,7 +553,7 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
                           if (rel)
                             {
                               const int at = nR + pm_lanes_below (br);
-                              if (at < PM_S3_RCAP)
+                              if (at < SH::RCAP)
                                 sh.a.v.r[at] = make_uint2 (kk[j], (tg[j] & 31u) | ((uint32_t) st << 5) | ((tg[j] & 0x80u) >> 1));
                             }
                           nR += (int) __popcll (br);
@@ -553,7 +561,7 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
                   }
               }
           pm_wave_sync ();
-          if (nR > PM_S3_RCAP)
+          if (nR > SH::RCAP)
             big = true;         // a repeat: left to the monolithic kernel
           else
             {
@@ -587,7 +595,7 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
                   if (s0)
                     sh.a.v.sv[ns0 + pm_lanes_below (b0)] = make_uint2 (me.x, (me.y & 31u) | ((uint32_t) tf << 8));
                   if (s1)
-                    sh.a.v.sv[PM_S3_RCAP - 1 - (ns1 + pm_lanes_below (b1))] = make_uint2 (me.x, (me.y & 31u) | ((uint32_t) tf << 8));
+                    sh.a.v.sv[SH::RCAP - 1 - (ns1 + pm_lanes_below (b1))] = make_uint2 (me.x, (me.y & 31u) | ((uint32_t) tf << 8));
                   ns0 += (int) __popcll (b0);
                   ns1 += (int) __popcll (b1);
                 }
@@ -602,7 +610,7 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
                     }
                   // ---- walk order of this strand's surviving anchors: segment ascending, position ascending inside a segment
                   const int ns = strand ? ns1 : ns0;
-                  const uint2 *svp = strand ? &sh.a.v.sv[PM_S3_RCAP - ns1] : &sh.a.v.sv[0];
+                  const uint2 *svp = strand ? &sh.a.v.sv[SH::RCAP - ns1] : &sh.a.v.sv[0];
                   for (int i0 = 0; i0 < ns; i0 += 64)
                     {
                       const int i = i0 + lane;
