@@ -43,6 +43,8 @@ struct pecall_dev
   long staged_sites;
   int staged_indiv;
   hipEvent_t ev_site[2];
+  unsigned long long *d_next_site;      // work counter of the per-site kernel; the word after it counts the listed columns
+  unsigned *d_slow;             // columns left to the beam search
 };
 
 static int pc_fail (pecall_dev * d, const char *fmt, ...)
@@ -147,6 +149,13 @@ extern "C" void pecall_dev_destroy (pecall_dev * d)
   hipFree (d->d_ped);
   hipFree (d->d_dyad);
   hipFree (d->d_trio);
+  hipFree (d->d_slow);
+  hipFree (d->d_next_site);
+  if (d->ev_site[0])
+    {
+      hipEventDestroy (d->ev_site[0]);
+      hipEventDestroy (d->ev_site[1]);
+    }
   hipStreamDestroy (d->stream);
   free (d);
 }
@@ -302,7 +311,8 @@ static int pcs_ensure (pecall_dev * d, long n_sites, int indiv)
   if (n_sites > d->cap_ssites || items > d->cap_sitems)
     {
       hipFree (d->d_sreads); hipFree (d->d_dom); hipFree (d->d_chromy); hipFree (d->d_call); hipFree (d->d_type);
-      hipFree (d->d_npass); hipFree (d->d_post); hipFree (d->d_ac); hipFree (d->d_den);
+      hipFree (d->d_npass); hipFree (d->d_post); hipFree (d->d_ac); hipFree (d->d_den); hipFree (d->d_slow);
+      PCCHK (d, hipMalloc ((void **) &d->d_slow, n_sites * sizeof (unsigned)));
       PCCHK (d, hipMalloc ((void **) &d->d_sreads, items * PCS_NA * sizeof (uint16_t)));
       PCCHK (d, hipMalloc ((void **) &d->d_dom, n_sites));
       PCCHK (d, hipMalloc ((void **) &d->d_chromy, n_sites));
@@ -502,9 +512,22 @@ extern "C" int pecall_dev_sites_run (pecall_dev * d, int haploid, double thresho
       PCCHK (d, hipEventCreate (&d->ev_site[0]));
       PCCHK (d, hipEventCreate (&d->ev_site[1]));
     }
+  if (!d->d_next_site)
+    {
+      PCCHK (d, hipMalloc ((void **) &d->d_next_site, 2 * sizeof (unsigned long long)));
+      PCCHK (d, hipFuncSetAttribute ((const void *) pcs_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PCS_FAST_LDS_BYTES));
+    }
+  PCCHK (d, hipMemsetAsync (d->d_next_site, 0, 2 * sizeof (unsigned long long), d->stream));
   PCCHK (d, hipEventRecord (d->ev_site[0], d->stream));
+  // the columns every sample agrees on are settled by pcs_fast_kernel; the rest, listed by it, go through the beam search
+  unsigned *n_slow = (unsigned *) (d->d_next_site + 1);
+  long fgrid = (n_sites + PCS_FAST_BLOCK / 64 - 1) / (PCS_FAST_BLOCK / 64);
+  if (fgrid > d->grid / 2)
+    fgrid = d->grid / 2;        // one workgroup per CU: the ln n! table takes half its LDS
+  hipLaunchKernelGGL (pcs_fast_kernel, dim3 ((unsigned) fgrid), dim3 (PCS_FAST_BLOCK), PCS_FAST_LDS_BYTES, d->stream, P, d->d_sreads, d->d_dom, d->d_chromy,
+                      n_sites, d->d_call, d->d_post, d->d_type, d->d_ac, d->d_npass, d->d_den, d->d_slow, n_slow);
   hipLaunchKernelGGL (pcs_call_kernel, dim3 ((unsigned) grid), dim3 (64), 0, d->stream, P, d->d_sreads, d->d_dom, d->d_chromy, n_sites, d->d_call,
-                      d->d_post, d->d_type, d->d_ac, d->d_npass, d->d_den, d->d_scratch);
+                      d->d_post, d->d_type, d->d_ac, d->d_npass, d->d_den, d->d_scratch, d->d_next_site, d->d_slow, n_slow);
   PCCHK (d, hipGetLastError ());
   PCCHK (d, hipEventRecord (d->ev_site[1], d->stream));
   PCCHK (d, hipStreamSynchronize (d->stream));

@@ -169,6 +169,46 @@ __device__ __forceinline__ int pcs_order (int ref, int jj, int haploid)
   return pcs_order_tab[haploid ? 1 : 0][ref][jj];
 }
 
+// fill_alpha_prior, pecaller.c:3043-3139: the integer Dirichlet pseudo-counts of genotype row g for reference base dom
+// (normal_factor 300: hom = 300, het = 150)
+__device__ __forceinline__ void pcs_alpha_prior_row (int g, int dom, int (&row)[PCS_NA])
+{
+  const int normal_factor = 300;
+  const int hom = normal_factor, het = normal_factor / 2;
+  const int hom_err = max (1, hom / 300), err = max (1, (2 * het) / 300);
+  for (int k = 0; k < PCS_NA; k++)
+    row[k] = err;
+  if (g < 4)
+    for (int k = 0; k < PCS_NA; k++)
+      row[k] = (g == k) ? hom : hom_err;
+  else if (g == 4 || g == 5)
+    {
+      for (int k = 0; k < 4; k++)
+        row[k] = (k == dom) ? (g == 4 ? hom / 5 : hom) : err;
+      row[4] = g == 4 ? (4 * hom) / 5 : err;
+      row[5] = g == 4 ? err : (4 * hom) / 5;
+    }
+  else if (g < 12)
+    {
+      int a, b;
+      pcs_het (g, a, b, dom);
+      if (a == dom || b == dom)
+        {
+          for (int k = 0; k < PCS_NA; k++)
+            row[k] = (k == dom) ? (51 * het) / 50 : (k == (a == dom ? b : a)) ? (49 * het) / 50 : (k == 4) ? max (1, het / 20) : err;
+        }
+      else
+        for (int k = 0; k < PCS_NA; k++)
+          row[k] = (k == a || k == b) ? het : err;
+    }
+  else if (g == 12)
+    for (int k = 0; k < PCS_NA; k++)
+      row[k] = (k == 4) ? (4 * het) / 5 : (k == dom) ? (6 * het) / 5 : err;
+  else
+    for (int k = 0; k < PCS_NA; k++)
+      row[k] = (k == 5) ? (2 * het) / 5 : (k == dom) ? (8 * het) / 5 : err;
+}
+
 // config_alloc, pecaller.c:2987-3027, into slot s: every sample above the depth floor called homozygous `dom`
 __device__ __forceinline__ void pcs_cfg_init (const PcsPool & p, int s, int dom, unsigned long long deep, int haploid, int lane)
 {
@@ -517,7 +557,8 @@ __device__ int pcs_expand (const PcsPool & cur, PcsPool & nw, const PcsPool & bi
 // Allele_Counts, passes.
 __global__ __launch_bounds__ (64) void pcs_call_kernel (PcsParams P, const uint16_t * reads, const uint8_t * dom_of, const uint8_t * chrom_of,
                                                       long n_sites, int8_t * call, double *post_out, int8_t * type_out,
-                                                      int32_t * allele_count, int8_t * n_pass, int32_t * denovo_out, char *scratch)
+                                                      int32_t * allele_count, int8_t * n_pass, int32_t * denovo_out, char *scratch,
+                                                      unsigned long long *next_site, const unsigned *site_list, const unsigned *n_list)
 {
   __shared__ PcsShared sh;
   const int lane = threadIdx.x;
@@ -527,8 +568,13 @@ __global__ __launch_bounds__ (64) void pcs_call_kernel (PcsParams P, const uint1
   pcs_pool_big (bigp[0], my);
   pcs_pool_big (bigp[1], my + PCS_BIG_BYTES);
   uint8_t *big_dup = (uint8_t *) (my + 2 * PCS_BIG_BYTES);
-  for (long site = blockIdx.x; site < n_sites; site += gridDim.x)
+  // columns are handed out through a counter (the first grid-ful by block index): a column that needs the whole beam search
+  // takes ~50 times as long as one settled by the shortcut below, so a fixed stride would leave most waves waiting for a few
+  // (site_list: only the listed columns -- the ones pcs_fast_kernel could not settle)
+  const long n_iter = site_list ? (long) *n_list : n_sites;
+  for (long it = blockIdx.x; it < n_iter; it = (long) gridDim.x + (long) __shfl ((long long) (lane == 0 ? atomicAdd (next_site, 1ull) : 0ull), 0))
     {
+      const long site = site_list ? (long) site_list[it] : it;
       const int dom = dom_of[site];
       const int chrom = chrom_of[site] & 3;
       // bit 4: HAPLOID forced for this column (BED guide mode on chrY / chrMT, pecaller.c:955-957): only the initial allele
@@ -595,42 +641,10 @@ __global__ __launch_bounds__ (64) void pcs_call_kernel (PcsParams P, const uint1
           // ---- fill_alpha_prior (pecaller.c:3043-3139): lane = genotype row
           if (lane < G)
             {
-              const int hom = normal_factor, het = normal_factor / 2, g = lane;
-              const int hom_err = max (1, hom / 300), err = max (1, (2 * het) / 300);
               int row[PCS_NA];
+              pcs_alpha_prior_row (lane, dom, row);
               for (int k = 0; k < PCS_NA; k++)
-                row[k] = err;
-              if (g < 4)
-                for (int k = 0; k < PCS_NA; k++)
-                  row[k] = (g == k) ? hom : hom_err;
-              else if (g == 4 || g == 5)
-                {
-                  for (int k = 0; k < 4; k++)
-                    row[k] = (k == dom) ? (g == 4 ? hom / 5 : hom) : err;
-                  row[4] = g == 4 ? (4 * hom) / 5 : err;
-                  row[5] = g == 4 ? err : (4 * hom) / 5;
-                }
-              else if (g < 12)
-                {
-                  int a, b;
-                  pcs_het (g, a, b, dom);
-                  if (a == dom || b == dom)
-                    {
-                      for (int k = 0; k < PCS_NA; k++)
-                        row[k] = (k == dom) ? (51 * het) / 50 : (k == (a == dom ? b : a)) ? (49 * het) / 50 : (k == 4) ? max (1, het / 20) : err;
-                    }
-                  else
-                    for (int k = 0; k < PCS_NA; k++)
-                      row[k] = (k == a || k == b) ? het : err;
-                }
-              else if (g == 12)
-                for (int k = 0; k < PCS_NA; k++)
-                  row[k] = (k == 4) ? (4 * het) / 5 : (k == dom) ? (6 * het) / 5 : err;
-              else
-                for (int k = 0; k < PCS_NA; k++)
-                  row[k] = (k == 5) ? (2 * het) / 5 : (k == dom) ? (8 * het) / 5 : err;
-              for (int k = 0; k < PCS_NA; k++)
-                sh.al[g][k] = row[k];
+                sh.al[lane][k] = row[k];
             }
         }
       pcs_sync ();
@@ -695,6 +709,26 @@ __global__ __launch_bounds__ (64) void pcs_call_kernel (PcsParams P, const uint1
                     const double dlt = mx - sh.like[lane][g];
                     initial_p = (dlt < initial_p) ? dlt : initial_p;
                   }
+            }
+          // ---- shortcut for the column every sample agrees on (the overwhelming majority).  If, in the first pass, every sample
+          //      above the depth floor has the reference homozygote as its best genotype with a margin of more than 2.31 nats, the beam
+          //      never holds more than the all-reference configuration: for each sample in turn the candidate "reference homozygote"
+          //      comes first (genotype_order starts with it) and is kept; every other candidate j has
+          //      templ = (L - l_ref) + l_j <= L - 2.31 + rounding, which fails both acceptance tests of pecaller.c:2628 / 2750
+          //      (templ + 2.3 > best_post, templ + 0.01 > best_like; best_post = best_like = L for a configuration with one allele,
+          //      whose prior is 0) whatever its prior is -- unsupported indel genotypes (2622-2625) only sink further.  The list
+          //      stays one configuration through clean_config_probs (it is homozygous), its posterior normalises to exactly 1, each
+          //      sample's call is the reference base with final_p = 1, nothing changed, and the pass loop ends after pass 1
+          //      (pecaller.c:1454-1471).  The 0.01 nat between 2.3 and 2.31 is ~10^10 times the rounding of the sums involved.
+          if (pass == 1)
+            {
+              const bool ok = !(lane < N && tot > md) || (initial_call == dom && initial_p > 2.31);
+              if (__all (ok))
+                {
+                  final_call = (lane < N && tot > md) ? dom : PCS_NG;
+                  final_p = 1.0;
+                  break;
+                }
             }
           // samples by margin, descending, stable (sort_compare_sample_pointer)
           {
@@ -1032,5 +1066,142 @@ __global__ __launch_bounds__ (64) void pcs_call_kernel (PcsParams P, const uint1
           denovo_out[site] = dcount;
         }
       pcs_sync ();
+    }
+}
+
+// ---- the columns every sample agrees on, without the beam.  One wave per column (lane = sample), eight columns per
+// workgroup round, the ln n! table (80 KB) and the four first-pass Dirichlet mean tables in the workgroup's LDS.  Per column:
+// the set-up and site filters of pecaller.c:1230-1304, the first pass of fill_sample_like (2448-2507), and the test of the
+// shortcut argued in pcs_call_kernel: every sample above the depth floor has the reference homozygote as its best genotype
+// by more than 2.31 nats.  Then the column's result is known -- every such sample is called the reference base with
+// posterior 1 after one pass, site type REF -- and is written here; so are the columns the site filters drop (every call N,
+// zero passes) and the ones whose reference base is not A/C/G/T.  Everything else goes to slow_list for pcs_call_kernel.
+#define PCS_FAST_BLOCK 512
+#define PCS_FAST_LDS_BYTES ((PC_TABLE + 1 + 4 * PCS_NG * PCS_NA) * 8)
+
+__global__ __launch_bounds__ (PCS_FAST_BLOCK) void pcs_fast_kernel (PcsParams P, const uint16_t * reads, const uint8_t * dom_of, const uint8_t * chrom_of,
+                                                                    long n_sites, int8_t * call, double *post_out, int8_t * type_out,
+                                                                    int32_t * allele_count, int8_t * n_pass, int32_t * denovo_out,
+                                                                    unsigned *slow_list, unsigned *n_slow)
+{
+  extern __shared__ double pcs_fast_lds[];
+  double *tab = pcs_fast_lds;
+  double *mean = pcs_fast_lds + PC_TABLE + 1;           // [4][PCS_NG][PCS_NA]
+  for (int i = threadIdx.x; i < PC_TABLE; i += PCS_FAST_BLOCK)
+    tab[i] = P.tab[i];
+  const int N = P.indiv, G = P.max_gen, md = P.min_depth;
+  if ((int) threadIdx.x < 4 * G)
+    {
+      // d_alpha_mean of pass 1 (pecaller.c:1354-1364) for each of the four reference bases
+      const int dom = threadIdx.x / G, g = threadIdx.x - dom * G;
+      int row[PCS_NA], myt = 0;
+      pcs_alpha_prior_row (g, dom, row);
+      for (int a = 0; a < PCS_NA; a++)
+        myt += row[a];
+      for (int a = 0; a < PCS_NA; a++)
+        mean[(dom * PCS_NG + g) * PCS_NA + a] = (double) row[a] / (double) myt;
+    }
+  __syncthreads ();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long stride = (long) gridDim.x * (PCS_FAST_BLOCK / 64);
+  for (long site = (long) blockIdx.x * (PCS_FAST_BLOCK / 64) + wave; site < n_sites; site += stride)
+    {
+      const int dom = dom_of[site];
+      const int chrom = chrom_of[site] & 3;
+      int decided = 1;          // 1: written here, 0: left to the beam
+      int my_call = PCS_NG, npass = 0, ac_dom = 0, type = 0;
+      if (dom > 3)
+        type = -1;              // the reference skips the column (pecaller.c:1208, 1718)
+      else
+        {
+          int r[PCS_NA], tot = 0;
+#pragma unroll
+          for (int a = 0; a < PCS_NA; a++)
+            r[a] = lane < N ? (int) reads[(site * N + lane) * PCS_NA + a] : 0;
+          tot = r[0] + r[1] + r[2] + r[3] + r[4];
+          double coef = pc_factln (tab, tot);
+#pragma unroll
+          for (int a = 0; a < PCS_NA; a++)
+            coef -= pc_factln (tab, r[a]);
+          int tsum = tot;
+          for (int o = 32; o; o >>= 1)
+            tsum += __shfl_xor (tsum, o);
+          const double average_depth = (double) tsum / (double) N;
+          bool bad_base = average_depth < 8;
+          const int sample_count = __popcll (__ballot (lane < N && tot >= 8));
+          if (sample_count < (double) 0.5 * N && chrom != 2)
+            bad_base = true;
+          if (!bad_base)
+            {
+              const bool deep = lane < N && tot > md;
+              bool ok = true;
+              if (deep)
+                {
+                  const double sc0 = (double) min (tot, 100);   // norm of pass 1 is 1
+                  const double sc1 = (10 > sc0) ? 10 : sc0;
+                  const double scale = (1000 < sc1) ? 1000 : sc1;
+                  const double *mrow = mean + dom * PCS_NG * PCS_NA;
+                  double mx = -1e100, lk_dom = 0.0, second = -1e100;
+                  int best = PCS_NG;
+                  for (int g = 0; g < G; g++)
+                    {
+                      int tot_a = 0, tot_tot = 0;
+                      double cf = coef, lk = 0.0;
+#pragma unroll
+                      for (int a = 0; a < PCS_NA; a++)
+                        {
+                          const double cv = ceil (scale * mrow[g * PCS_NA + a]);
+                          const int ta = (int) ((1 > cv) ? 1 : cv);
+                          tot_a += ta;
+                          tot_tot += ta + r[a];
+                          cf -= pc_factln (tab, ta - 1);
+                          lk += pc_factln (tab, ta + r[a] - 1);
+                        }
+                      cf += pc_factln (tab, tot_a - 1);
+                      lk += cf;
+                      lk -= pc_factln (tab, tot_tot - 1);
+                      if (g == dom)
+                        lk_dom = lk;
+                      else
+                        second = (lk > second) ? lk : second;
+                      if (lk > mx)
+                        {
+                          best = g;
+                          mx = lk;
+                        }
+                    }
+                  // best genotype the reference homozygote, and its margin over every other one (initial_p) above 2.31
+                  ok = best == dom && (lk_dom - second) > 2.31;
+                  my_call = dom;
+                }
+              if (__all (ok))
+                {
+                  npass = 1;
+                  // Allele_Counts of the row (pecaller.c:1575-1597): every confident call adds its alleles; the posterior is 1
+                  if (1.0 >= P.threshold)
+                    ac_dom = (int) __popcll (__ballot (deep)) * (P.haploid ? 1 : 2);
+                }
+              else
+                decided = 0;
+            }
+        }
+      if (decided)
+        {
+          if (lane < N)
+            {
+              call[site * N + lane] = (int8_t) my_call;
+              post_out[site * N + lane] = 1.0;
+            }
+          if (lane < PCS_NA)
+            allele_count[site * PCS_NA + lane] = (type == 0 && lane == dom) ? ac_dom : 0;
+          if (lane == 0)
+            {
+              type_out[site] = (int8_t) type;
+              n_pass[site] = (int8_t) npass;
+              denovo_out[site] = 0;
+            }
+        }
+      else if (lane == 0)
+        slow_list[atomicAdd (n_slow, 1u)] = (unsigned) site;
     }
 }
