@@ -11,22 +11,25 @@ import oracle_py
 MISS = np.frombuffer(np.array([0xBFD5555555555555], dtype=np.uint64).tobytes(), dtype=np.float64)[0]   # the reference's -1/3
 
 
-def match(r, q):
-    """init_bonus_matrices as a predicate (pemapper.c:2006-2035), the form pm_match takes without bisulfite"""
+def match(r, q, bis=False):
+    """init_bonus_matrices as a predicate (pemapper.c:2006-2035), the form pm_match takes; bisulfite mode (2024-2035) lets a
+    reference C (either case) pair with a read T (either case)"""
     m = (r == q) | (q == ord("N")) | (q == ord("n"))
     m |= (r == ord("N")) & (q >= ord("N"))
     m |= (r == ord("n")) & (q >= ord("n"))
+    if bis:
+        m |= ((r == ord("C")) | (r == ord("c"))) & ((q == ord("T")) | (q == ord("t")))
     return m
 
 
-def gapless_rule(ref, read, max_x=2):
+def gapless_rule(ref, read, max_x=2, bis=False):
     """-> None (left to the DP) or (score, row of the start cell)"""
     nn, mm = len(ref), len(read)
     nd = nn - mm + 1
     if nd <= 0:
         return None
     idx = np.arange(nd)[:, None] + np.arange(mm)[None, :]
-    eq = match(ref[idx], read[None, :])
+    eq = match(ref[idx], read[None, :], bis)
     x = (~eq).sum(axis=1)
     if (x <= 1).any():
         cand = np.nonzero(x <= 1)[0]
@@ -107,3 +110,75 @@ def test_rule_agrees_with_the_full_dp():
             decided[2] += 1
     # both cases and the deferral all occurred in numbers
     assert decided[1] > 10000 and decided[2] > 1500 and deferred > 4000, (decided, deferred)
+
+
+def edge_windows(seed, n, bis):
+    """the geometry and the letters where pm_match and the number of diagonals leave the common case: windows clipped at a contig
+    end (1 .. 21 diagonals instead of 22), reference N / IUPAC / lower-case letters inside the window, lower-case and N in the
+    read, and -- in bisulfite mode -- reads whose C's were converted to T"""
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    odd_ref = np.frombuffer(b"NNRYKMSWacgtn", np.uint8)
+    for k in range(n):
+        mm = int(rng.integers(16, 48))
+        slack = int(rng.integers(0, 21)) if k % 4 else int(rng.integers(0, 4))      # nn - mm = 0 .. 20: a clipped window
+        alpha = acgt if k % 3 else acgt[:2]
+        ref = alpha[rng.integers(0, len(alpha), mm + slack)].copy()
+        if k % 7 == 0:
+            per = int(rng.integers(1, 5))
+            ref = np.tile(ref[:per], len(ref) // per + 1)[:len(ref)].copy()
+        d = int(rng.integers(0, slack + 1))
+        kind = k % 8
+        if kind == 6 and slack - d >= 1:
+            b = int(rng.integers(1, slack - d + 1))
+            p = int(rng.integers(1, mm))
+            read = np.concatenate([ref[d:d + p], ref[d + p + b:d + mm + b]]).copy()
+        elif kind == 7:
+            p = int(rng.integers(1, mm - 1))
+            read = np.concatenate([ref[d:d + p], acgt[rng.integers(0, 4, 1)], ref[d + p:d + mm - 1]]).copy()
+        else:
+            read = ref[d:d + mm].copy()
+        for q in rng.choice(mm, size=(0, 1, 2, 2, 3, 1, 0, 1)[kind], replace=False):
+            read[q] = acgt[(int(rng.integers(1, 4)) + int(np.searchsorted(acgt, read[q]))) % 4]
+        if bis:
+            conv = (read == ord("C")) & (rng.random(mm) < 0.9)           # bisulfite conversion of the read's C's
+            read[conv] = ord("T")
+        # odd letters: in the reference window (after the read was drawn from it) and in the read
+        for _ in range(int(rng.integers(0, 4))):
+            ref[int(rng.integers(0, len(ref)))] = odd_ref[int(rng.integers(0, len(odd_ref)))]
+        if k % 5 == 0:
+            q = int(rng.integers(0, mm))
+            read[q] = (ord("N"), ord("n"), read[q] | 0x20)[k % 3]
+        yield ref, read
+
+
+def _check(windows_iter, bis):
+    decided = deferred = narrow = odd = 0
+    for ref, read in windows_iter:
+        r2 = gapless_rule(ref, read, max_x=2, bis=bis)
+        if r2 is None:
+            deferred += 1
+            continue
+        score, st, pl = oracle_py.sw(ref, read, bisulfite=bis, planes=True)
+        mm = len(read)
+        assert np.float64(score).view(np.uint64) == np.float64(r2[0]).view(np.uint64), (ref.tobytes(), read.tobytes(), score, r2)
+        assert (int(st[0]), int(st[1]), int(st[2])) == (0, r2[1], mm), (ref.tobytes(), read.tobytes(), st, r2)
+        i = r2[1]
+        for j in range(mm, 1, -1):
+            a, b, c = pl[0, i - 1, j - 1], pl[1, i - 1, j - 1], pl[2, i - 1, j - 1]
+            assert not (b > a) and not (c > max(a, b)), (ref.tobytes(), read.tobytes(), i, j)
+            i -= 1
+        decided += 1
+        narrow += len(ref) - mm < 21
+        odd += bool(np.isin(ref, np.frombuffer(b"NRYKMSWacgtn", np.uint8)).any())
+    return decided, deferred, narrow, odd
+
+
+def test_rule_on_clipped_windows_and_odd_letters():
+    decided, deferred, narrow, odd = _check(edge_windows(77, 20000, False), False)
+    assert decided > 8000 and deferred > 2000 and narrow > 7000 and odd > 4000, (decided, deferred, narrow, odd)
+
+
+def test_rule_in_bisulfite_mode():
+    decided, deferred, narrow, odd = _check(edge_windows(78, 20000, True), True)
+    assert decided > 8000 and deferred > 2000 and narrow > 7000 and odd > 4000, (decided, deferred, narrow, odd)

@@ -305,3 +305,102 @@ def test_big_ends_take_the_spill_path(env, monkeypatch):
             many += k >= 90
     assert many > n // 4, many              # the family's ends really had ~95 or ~190 candidate hits each
     assert (m1 > 0).sum() > n // 2
+
+
+def _edge_genome(seed):
+    """12 short contigs (so that a good share of the reads lies at a contig end and gets a clipped SW window), with N runs,
+    IUPAC letters and single N's sprinkled inside the sequence (.seq holds upper-case letters: lower case cannot occur)"""
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    odd = np.frombuffer(b"NRYKMSW", np.uint8)
+    contigs = []
+    for c in range(12):
+        n = int(rng.integers(2500, 6000))
+        g = acgt[rng.integers(0, 4, n)].copy()
+        for _ in range(n // 300):                       # an odd letter every ~300 bases
+            g[int(rng.integers(0, n))] = odd[int(rng.integers(0, len(odd)))]
+        s = int(rng.integers(300, n - 400))
+        g[s:s + int(rng.integers(3, 30))] = ord("N")    # an N run
+        contigs.append(g)
+    return contigs
+
+
+def _edge_reads(contigs, seed, n, L, bis):
+    """half of the fragments touch a contig end: the read starts within 0..12 bases of the first base or ends within 0..12 of
+    the last one, so that the window (spot - 10 .. spot + L + 10, clipped to the contig: pemapper.c:1047-1081) has 1..21
+    diagonals; exact numbers of substitutions around the rule's case boundaries; C -> T conversion in bisulfite mode"""
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    r1, r2 = [], []
+    for k in range(n):
+        c = contigs[int(rng.integers(0, len(contigs)))]
+        fl = int(rng.integers(L + 10, min(len(c), L + 380)))
+        if k % 2 == 0:
+            s = int(rng.integers(0, 13)) if k % 4 == 0 else len(c) - fl - int(rng.integers(0, 13))
+        else:
+            s = int(rng.integers(0, len(c) - fl))
+        s = max(0, min(s, len(c) - fl))
+        ends = []
+        for which in (0, 1):
+            lo = s if which == 0 else s + fl - L
+            x = c[lo:lo + L].copy()
+            for q in rng.choice(L, size=(0, 1, 2, 2, 3, 1, 0, 4)[int(rng.integers(0, 8))], replace=False):
+                x[q] = acgt[int(rng.integers(0, 4))]
+            if which == 1:
+                x = COMP[x][::-1].copy()
+            if bis:
+                conv = (x == ord("C")) & (rng.random(L) < 0.95)
+                x[conv] = ord("T")
+            ends.append(x)
+        a, b = ends
+        if rng.random() < 0.5:
+            a, b = b, a
+        r1.append(a.tobytes())
+        r2.append(b.tobytes())
+    return refio.pack_reads(r1) + refio.pack_reads(r2)
+
+
+@pytest.mark.parametrize("bis", [False, True])
+def test_gapless_rule_at_contig_ends_and_on_odd_letters(bis):
+    """The three places where the gapless rule's inputs leave the common case -- windows clipped at a contig end (fewer than
+    22 diagonals), reference N / IUPAC letters inside the window (pm_match's asymmetric N row), bisulfite mode -- on the
+    device against the oracle's full DP: coordinates, classes, pileup, insertions, and per hit the score BITS, the start
+    cell and the window geometry."""
+    from pecaller_amd import PemapDev
+    contigs = _edge_genome(31)
+    mers, ukmer, ustart, cs = refio.kmer_index(contigs, bisulfite=bis)
+    ix = dict(mers=mers, ukmer=ukmer, ustart=ustart, genome=np.concatenate(contigs), contig_starts=cs,
+              contig_len=np.array([len(c) for c in contigs], dtype=np.uint32))
+    n, L = 5000, 120
+    b1, l1, b2, l2 = _edge_reads(contigs, 9 + int(bis), n, L, bis)
+    dev = PemapDev(0)
+    dev.build_index(ix["genome"], ix["contig_len"], bisulfite=bis)
+    dev.set_params(paired=True, min_dist=0, max_dist=500, min_align=0.85, bisulfite=bis)
+    m1, m2, mt = dev.map_batch(b1, l1, b2, l2)
+    stats, _ = dev.run_stats()
+    dbg = dev.debug_hits(2 * n)
+    counts, ins = dev.fetch_pileup()
+    dev.close()
+    o = oracle_py.Oracle(ix, paired=True, min_dist=0, max_dist=500, min_align=0.85, bisulfite=bis)
+    om1, om2, omt, d1, d2 = o.map_batch(b1, l1, b2, l2, debug=True, threads=8)
+    assert np.array_equal(m1, om1), np.nonzero(m1 != om1)[0][:10]
+    assert np.array_equal(m2, om2), np.nonzero(m2 != om2)[0][:10]
+    assert np.array_equal(mt, omt)
+    assert np.array_equal(counts, o.counts())
+    assert sorted(ins) == sorted(o.insertions())
+    clipped = 0
+    for which, od in ((0, d1), (1, d2)):
+        nh = dbg["n_hits"][which::2]
+        assert np.array_equal(nh, od["n_hits"])
+        for i in np.nonzero(nh)[0]:
+            k = nh[i]
+            e = 2 * i + which
+            assert np.array_equal(dbg["win_start"][e, :k].astype(np.int32), od["win_start"][i, :k])
+            assert np.array_equal(dbg["win_len"][e, :k], od["win_len"][i, :k])
+            assert np.array_equal(dbg["score"][e, :k].view(np.uint64), od["score"][i, :k].view(np.uint64)), (e, k)
+            assert np.array_equal(dbg["start_k"][e, :k], od["start"][i, :k, 0]), e
+            assert np.array_equal(dbg["start_i"][e, :k], od["start"][i, :k, 1]), e
+            clipped += int((od["win_len"][i, :k] < L + 21).sum())
+    # clipped windows occurred in numbers, the rule decided a good share, and mapping still works
+    # (in bisulfite mode only the end that reads the converted strand forward maps: every C of both ends was turned into T)
+    assert clipped > n // 6 and stats["gapless"] > n // 3 and (m1 > 0).sum() > 2 * n // 5, (clipped, stats, int((m1 > 0).sum()))
