@@ -29,6 +29,7 @@
 #include <math.h>
 #include <zlib.h>
 #include "../../include/pemap_hip.h"
+#include "host_io.h"
 
 #define NA 6
 #define MAX_DIST 501            /* pecaller.c:222 */
@@ -76,7 +77,7 @@ find_chrom (const unsigned int *pos, int first, int last, int try, unsigned this
 
 typedef struct
 {
-  gzFile f;
+  zreader f;                    /* the stream is inflated by a thread of its own (host_io.h) */
   unsigned int cur;             /* position of the pending record, 0 = exhausted (pecaller.c:840-849) */
   unsigned short data[NA];
   char name[256];
@@ -89,17 +90,9 @@ typedef struct
 static void
 advance (sample_t * s, int *running)
 {
-  if (!gzeof (s->f))
-    {
-      int n = gzread (s->f, &s->cur, sizeof (unsigned int));
-      if (n != 0)
-        gzread (s->f, s->data, sizeof (unsigned short) * NA);
-      else
-        {
-          s->cur = 0;
-          (*running)--;
-        }
-    }
+  /* (gzeof / gzread of 4 then 12 bytes in the reference: the end of the stream is a read of nothing) */
+  if (zr_read (&s->f, &s->cur, sizeof (unsigned int)) != 0)
+    zr_read (&s->f, s->data, sizeof (unsigned short) * NA);
   else
     {
       s->cur = 0;
@@ -298,9 +291,8 @@ main (int argc, char *argv[])
             found++;
             break;
           }
-        if (!(sm[found].f = gzopen (de->d_name, "rb")))
+        if (zr_open (&sm[found].f, de->d_name))
           die ("\n Can not open file %s which should contain pileup information", de->d_name);
-        gzbuffer (sm[found].f, 1 << 20);
         strncpy (ss, de->d_name, sizeof ss - 1);
         char *tok = strtok (ss, "\n.\t ");
         strncpy (sm[found].name, tok ? tok : "", sizeof sm[found].name - 1);
@@ -377,9 +369,8 @@ main (int argc, char *argv[])
   int running = no_files;
   for (int i = 0; i < no_files; i++)
     {
-      int n = gzread (sm[i].f, &sm[i].cur, sizeof (unsigned int));
-      if (n != 0)
-        gzread (sm[i].f, sm[i].data, sizeof (unsigned short) * NA);
+      if (zr_read (&sm[i].f, &sm[i].cur, sizeof (unsigned int)) != 0)
+        zr_read (&sm[i].f, sm[i].data, sizeof (unsigned short) * NA);
       else
         sm[i].cur = 0;
       if (sm[i].cur == 0)
@@ -613,7 +604,7 @@ main (int argc, char *argv[])
   gzclose (outfile);
   gzclose (pilefile);
   for (int i = 0; i < no_files; i++)
-    gzclose (sm[i].f);
+    zr_close (&sm[i].f);
   pecall_dev_destroy (pc);
   return 0;
 }

@@ -10,8 +10,9 @@
  * Outputs: <out>.pileup.gz (16-byte records), <out>.indel.txt.gz, <out>.summary.txt, <fastq>.mfile -- the reference's
  * formats (pemapper.c:775-781, 819-900).
  *
- * Differences from the reference, all outside the hot path: `threads` is validated but unused (the batch goes to the
- * GPU); the index arrays are rebuilt on the GPU from <sdx>.seq instead of inflating the 16 GiB <sdx>.idx (the device
+ * Differences from the reference, all outside the hot path: `threads` bounds the host threads that deflate the pileup (the
+ * batch itself goes to the GPU); batches are handed over with pemap_dev_submit_batch, so the next one is parsed while the
+ * GPU maps; <out>.pileup.gz is a sequence of gzip members (it inflates to the reference's bytes); the index arrays are rebuilt on the GPU from <sdx>.seq instead of inflating the 16 GiB <sdx>.idx (the device
  * builder is verified to produce the reference builder's arrays; set PEMAP_INDEX_FROM_FILES=1 to load .idx/.mdx);
  * reads longer than PEMAP_MAX_READ or shorter than PEMAP_MIN_READ are an error instead of undefined behaviour.
  */
@@ -22,7 +23,9 @@
 #include <stdint.h>
 #include <zlib.h>
 #include <pthread.h>
+#include <unistd.h>
 #include "../../include/pemap_hip.h"
+#include "host_io.h"
 
 #define MAX_FILES 2000
 #define BATCH_PAIRS (1 << 20)
@@ -253,6 +256,7 @@ typedef struct
   char **contig_names;
   int n_contigs;
   int paired;
+  int io_threads;
   char mate_names[9][80];
 } ctx_t;
 
@@ -278,10 +282,9 @@ dump_output (ctx_t * c, const char *basename, long tot_pairs)
   if (!summaryfile)
     die ("\n Can not open file %s for writing", path);
   snprintf (path, sizeof path, "%s.pileup.gz", basename);
-  gzFile pileupfile = gzopen (path, "wb");
-  if (!pileupfile)
+  pgz pileupfile;
+  if (pgz_open (&pileupfile, path, c->io_threads))
     die ("\n Can not open file %s for writing", path);
-  gzbuffer (pileupfile, 33554432);
   snprintf (path, sizeof path, "%s.indel.txt.gz", basename);
   gzFile indelfile = gzopen (path, "w");
   if (!indelfile)
@@ -303,7 +306,7 @@ dump_output (ctx_t * c, const char *basename, long tot_pairs)
           fprintf (summaryfile, "\n%s\t%ld\t%g", c->mate_names[i], mate_counts[i], (double) mate_counts[i] / (double) tot_pairs);
       fprintf (summaryfile, "\n");
       fclose (summaryfile);
-      gzclose (pileupfile);
+      pgz_close (&pileupfile);
       gzclose (indelfile);
       return;
     }
@@ -329,8 +332,8 @@ dump_output (ctx_t * c, const char *basename, long tot_pairs)
     {
       uint64_t cnt = c->gsize - first < chunk ? c->gsize - first : chunk, n = 0;
       ck (c->dev, pemap_dev_fetch_records (c->dev, first, cnt, recs, chunk, &n));
-      if (n)
-        gzwrite (pileupfile, recs, (unsigned) (n * sizeof (pile_rec)));
+      if (n && pgz_write (&pileupfile, recs, (size_t) n * sizeof (pile_rec)))
+        die ("\n Can not write %s", "the pileup");
       for (uint64_t r = 0; r < n; r++)
         if (recs[r].c[5] > 0)
           {
@@ -352,7 +355,8 @@ dump_output (ctx_t * c, const char *basename, long tot_pairs)
           }
     }
   free (recs);
-  gzclose (pileupfile);
+  if (pgz_close (&pileupfile))
+    die ("\n Can not write %s", "the pileup");
   gzclose (indelfile);
   double avg_reads = (double) total_bases / (double) c->gsize;
   fprintf (summaryfile, "\n================================================================");
@@ -539,6 +543,14 @@ main (int argc, char *argv[])
       exit (1);
     }
   c.dev = dev;
+  {
+    long ncpu = sysconf (_SC_NPROCESSORS_ONLN);
+    c.io_threads = max_threads - 1;     /* one of the reference's threads is its reader (pemapper.c:360-365) */
+    if (ncpu > 0 && c.io_threads > (int) ncpu)
+      c.io_threads = (int) ncpu;
+    if (c.io_threads > 32)
+      c.io_threads = 32;
+  }
   printf ("\n About to read kmers index \n\n");
   const char *from_files = getenv ("PEMAP_INDEX_FROM_FILES");
   if (from_files && atoi (from_files))
@@ -595,9 +607,25 @@ main (int argc, char *argv[])
   char basename[1024];
   strncpy (basename, argv[1], 1000);
   basename[1000] = 0;
-  char *r1 = (char *) malloc ((size_t) BATCH_PAIRS * ROW_STRIDE), *r2 = paired ? (char *) malloc ((size_t) BATCH_PAIRS * ROW_STRIDE) : NULL;
-  int *l1 = (int *) malloc (sizeof (int) * BATCH_PAIRS), *l2 = (int *) malloc (sizeof (int) * BATCH_PAIRS);
-  int *mt = (int *) malloc (sizeof (int) * BATCH_PAIRS);
+  /* two sets of batch buffers: one is filled from the fastq streams while the GPU maps the other (the reference's reader thread
+     fills a free PTHREAD_DATA_NODE while its workers map the others, pemapper.c:663-703).  Pinned once, like pd_node_alloc. */
+  char *r1s[2], *r2s[2];
+  int *l1s[2], *l2s[2], *mts[2];
+  for (int k = 0; k < 2; k++)
+    {
+      r1s[k] = (char *) malloc ((size_t) BATCH_PAIRS * ROW_STRIDE);
+      r2s[k] = paired ? (char *) malloc ((size_t) BATCH_PAIRS * ROW_STRIDE) : NULL;
+      l1s[k] = (int *) malloc (sizeof (int) * BATCH_PAIRS);
+      l2s[k] = (int *) malloc (sizeof (int) * BATCH_PAIRS);
+      mts[k] = (int *) malloc (sizeof (int) * BATCH_PAIRS);
+      (void) pemap_dev_pin_host (dev, r1s[k], (uint64_t) BATCH_PAIRS * ROW_STRIDE);     /* (a refusal only means staged copies) */
+      if (paired)
+        (void) pemap_dev_pin_host (dev, r2s[k], (uint64_t) BATCH_PAIRS * ROW_STRIDE);
+    }
+  int cur_set = 0, have_pending = 0;
+  uint64_t pending = 0;
+  char *r1 = r1s[0], *r2 = r2s[0];
+  int *l1 = l1s[0], *l2 = l2s[0], *mt = mts[0];
   printf ("\n About to start mapping everything \n\n");
   long tot_pairs = 0;
   for (int iter = 0; iter < file_num; iter++)
@@ -703,6 +731,10 @@ main (int argc, char *argv[])
             {
               if (current_read > cap)
                 {
+                  /* the batch in flight writes into the arrays about to move */
+                  if (have_pending)
+                    ck (dev, pemap_dev_wait_batch (dev, pending));
+                  have_pending = 0;
                   size_t ncap = cap;
                   while (ncap < current_read)
                     ncap *= 2;
@@ -711,12 +743,27 @@ main (int argc, char *argv[])
                     maps2 = (uint32_t *) realloc (maps2, ncap * sizeof (uint32_t));
                   cap = ncap;
                 }
-              ck (dev, pemap_dev_map_batch (dev, r1, l1, r2, l2, nb, ROW_STRIDE, maps1 + (current_read - (size_t) nb),
-                                            paired ? maps2 + (current_read - (size_t) nb) : NULL, mt));
+              uint64_t ticket = 0;
+              ck (dev, pemap_dev_submit_batch (dev, r1, l1, r2, l2, nb, ROW_STRIDE, maps1 + (current_read - (size_t) nb),
+                                               paired ? maps2 + (current_read - (size_t) nb) : NULL, mt, &ticket));
+              /* the other set's batch must be back before that set is filled again */
+              if (have_pending)
+                ck (dev, pemap_dev_wait_batch (dev, pending));
+              pending = ticket;
+              have_pending = 1;
+              cur_set ^= 1;
+              r1 = r1s[cur_set];
+              r2 = r2s[cur_set];
+              l1 = l1s[cur_set];
+              l2 = l2s[cur_set];
+              mt = mts[cur_set];
               printf ("\n We have read %ld reads \n\n", (long) current_read);
               nb = 0;
             }
         }
+      if (have_pending)
+        ck (dev, pemap_dev_wait_batch (dev, pending));
+      have_pending = 0;
       if (nb > 0)               /* loop left through the length test */
         {
           if (current_read > cap)
