@@ -32,4 +32,4 @@ for ctr, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
 if len(sys.argv) > 2:
     out["steps"] = int(sys.argv[2])     # steps of the main configuration the profiled command ran (for per-step totals)
 json.dump(out, open(os.path.join(d, "pmc.json"), "w"), indent=1)
-print("wrote", os.path.join(d, "pmc.json"), {k: len(v) for k, v in out.items()})
+print("wrote", os.path.join(d, "pmc.json"), {k: len(v) for k, v in out.items() if isinstance(v, dict)})
