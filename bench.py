@@ -154,6 +154,7 @@ def roofline_of(leg, dt, steps, L, n_rep, gs, B):
     S = L // 16 + (0 if L % 16 == 0 else 1)
     n_single = (agg["sw_dirs"] - agg["redo"]) / ends      # single-hit problems the DP scored, with nibbles (the rest: gapless rule)
     n_multi = (agg["sw_score"] - (agg["sw_dirs"] - agg["redo"]) - agg.get("gapless", 0)) / ends
+    n_band = agg.get("banded", 0) / ends
     lanes, W = sw_geometry(L)
     slab = lanes * ((L + 21 + lanes + 15) // 16 * 16) * ((W * 4 + 31) // 32) * 4
     per_end = {
@@ -161,7 +162,8 @@ def roofline_of(leg, dt, steps, L, n_rep, gs, B):
         # ... + the (key, segment) lists written for the vote; with the look-up replicas an entry is 4 bytes, not a pair
         "lookup": S * 49 * 2 * (4 if n_rep else 8) + 4.0 * P_e + L + 5.0 * P_e,
         "vote": 5.0 * P_e + H_e * 16,
-        "sw_single": n_single * (L + 21 + L + slab),                # window + read in, direction nibbles out
+        # window + read in, direction nibbles out (a banded problem writes 16 bytes per read column, not the whole slab)
+        "sw_single": (n_single - n_band) * (L + 21 + L + slab) + n_band * (L + 21 + L + 16 * (L + 1)),
         "sw_multi": n_multi * (L + 21 + L),
         "select": H_e * 16 + 12,
         "sw_redo": (agg["redo"] / ends) * (L + 21 + L + slab),
@@ -196,7 +198,7 @@ def roofline_of(leg, dt, steps, L, n_rep, gs, B):
             "path_frac": round(total_b * ends / steps / (dt / steps) / 1e9 / HBM_PEAK_GBS, 5),
             "step_traffic_bytes": step_traffic,
             "step_traffic_over_algorithmic": (round(step_traffic / (total_b * ends / steps), 2) if step_traffic else None),
-            "cells_per_s": round((agg["cells_score"] + agg["cells_dirs"]) / dt, 0)}
+            "cells_per_s": round((agg["cells_score"] + agg["cells_dirs"] + agg.get("cells_band", 0)) / dt, 0)}
     if dom != "lookup" and split:
         # the path's HBM-heavy kernel beside the dominant one: same accounting
         lk_name = lookup_kernel_name(n_rep)
@@ -229,7 +231,7 @@ def main():
     ap.add_argument("--config", default="hg38_150", choices=["hg38_150", "tsw250"],
                     help="tsw250: only BASELINE config 3's leg is run and printed as the record's headline fields (profiling)")
     ap.add_argument("--secondary-steps", type=int, default=3)
-    ap.add_argument("--pecall-sites", type=int, default=1000000,
+    ap.add_argument("--pecall-sites", type=int, default=2000000,
                     help="columns per launch of the PECaller leg (a launch ends with its slowest column: the few hundred-configuration "
                          "variant columns take ~50-90 ms each on one wave, so short launches measure that tail, not the rate)")
     ap.add_argument("--pecall-cpu-seconds", type=float, default=10.0)

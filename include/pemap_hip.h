@@ -177,11 +177,13 @@ int pemap_dev_summary (pemap_dev * dev, long *out13);
  * [11] = chunks the run was cut into (= launches of every kernel),
  * [12] = problems decided without the DP (a diagonal with at most one mismatch; with PEMAP_GAPLESS=0 none):
  *        [3], [5] count the DP's share only.
+ * [13] = problems scored by the DP restricted to a band of 32 diagonals (exact for them: pemap_band.hip.h), part of [2] and,
+ *        for the single-hit ends, of [3]; [14] = band cells computed (not part of [4], [5]); [15] reserved.
  * times_ms[0..7] = seed stage (look-up + vote), SW single-hit (with nibbles), SW multi-hit, select, SW re-score,
  * walk+pileup, look-up kernel alone, vote kernel alone (the list-mode remainder of the big read-ends and the emit kernel count
  * towards [0] only): kernel durations from HIP events on the object's streams, summed over the run's chunks (the streams of
  * the pipeline overlap in time, so their sum exceeds the wall time). */
-int pemap_dev_run_stats (pemap_dev * dev, uint64_t * stats13, float *times_ms8);
+int pemap_dev_run_stats (pemap_dev * dev, uint64_t * stats16, float *times_ms8);
 
 /* Debug/parity taps: per read-end hit lists and per-hit SW results of the last run.
  * n_hits[n_ends]; the other arrays are [n_ends][PEMAP_MAX_HITS]. Any pointer may be NULL. end = 2*pair + mate in paired mode. */

@@ -33,7 +33,8 @@
 
 #define NA 6
 #define MAX_DIST 501            /* pecaller.c:222 */
-#define TILE (1 << 18)          /* columns per device call */
+#define TILE (1 << 21)          /* columns per device call: a call ends with its slowest column (the beam of a few variant columns
+                                   runs 50-90 ms on one wave), so tiles are large enough for that tail to be a small share */
 
 static void
 die (const char *fmt, const char *arg)

@@ -75,6 +75,7 @@ struct PmKnobs
   bool vote_stream_prio_set;
   int chunk_pairs;
   int d2h_stream;               // 1: the results of a submitted batch return on a stream of their own instead of the ALU stream
+  int band, band_waves_per_cu;  // the banded DP (pm_band_kernel) for the problems it is exact for; its waves per CU
   int seed_phase, vote_probe;   // always 0 without PEMAP_TIMING_PROBES
 };
 
@@ -120,6 +121,9 @@ static void read_knobs (PmKnobs & k)
   k.vote_stream_prio = env_int ("PEMAP_VOTE_STREAM_PRIO", 0);
   k.chunk_pairs = env_int ("PEMAP_CHUNK_PAIRS", 262144);
   k.d2h_stream = env_int ("PEMAP_D2H_STREAM", 0);
+  k.band = env_int ("PEMAP_BAND", 1);
+  k.band_waves_per_cu = env_int ("PEMAP_BAND_WAVES_PER_CU", 12);
+  if (k.band_waves_per_cu < 1) k.band_waves_per_cu = 1;
   k.seed_phase = k.vote_probe = 0;
 #ifdef PEMAP_TIMING_PROBES
   k.seed_phase = env_int ("PEMAP_SEED_PHASE", 0);
@@ -139,7 +143,7 @@ struct pemap_dev
   uint32_t multi_base;
   int n_rep, rep_want;          // rep_want: -1 = when the memory is there (default), 0 = never, 8 = required
   uint64_t multi_units;
-  uint8_t *d_genome;
+  uint8_t *d_genome, *d_genome_alloc;   // the letters, and the allocation they sit in (padded in front)
   uint32_t *d_contig_starts;
   uint64_t n_mers, gsize;
   int n_contigs, idepth;
@@ -257,7 +261,7 @@ extern "C" int pemap_dev_create (pemap_dev ** out, int device_id)
   d->n_rep = 0;
   d->rep_want = -1;
   d->multi_units = 0;
-  d->d_genome = nullptr;
+  d->d_genome = d->d_genome_alloc = nullptr;
   d->d_contig_starts = nullptr;
   d->d_counts = nullptr;
   d->n_mers = d->gsize = 0;
@@ -376,7 +380,8 @@ static void free_index (pemap_dev * d)
   hipFree (d->d_multi);         // d_rep is kept for the next index (pemap_dev_destroy frees it)
   d->d_multi = nullptr;
   d->n_rep = 0;
-  hipFree (d->d_genome);
+  hipFree (d->d_genome_alloc);
+  d->d_genome_alloc = nullptr;
   hipFree (d->d_contig_starts);
   hipFree (d->d_counts);
   d->d_pos_index = d->d_mers = nullptr;
@@ -522,7 +527,11 @@ extern "C" int pemap_dev_index_alloc (pemap_dev * d, uint64_t n_mers, uint64_t g
   d->idepth = idepth;
   TRY (dev_alloc (d, &d->d_pos_index, POS_INDEX_N));
   TRY (dev_alloc (d, &d->d_mers, n_mers + 128));
-  TRY (dev_alloc (d, &d->d_genome, genome_size + 512));
+  // (256 bytes in front, 512 behind: pm_band_kernel's window loads start a few bytes before a window and the kernels' 8-byte loads
+  // end a few bytes behind one; d_genome points at the first letter)
+  TRY (dev_alloc (d, &d->d_genome_alloc, genome_size + 768));
+  HIPCHK (d, hipMemset (d->d_genome_alloc, 0, 256));
+  d->d_genome = d->d_genome_alloc + 256;
   TRY (dev_alloc (d, &d->d_contig_starts, (size_t) n_contigs + 2));
   TRY (dev_alloc (d, &d->d_counts, genome_size * 6 + 6));
   HIPCHK (d, hipMemset (d->d_genome + genome_size, 0, 512));
@@ -957,11 +966,11 @@ static int ensure_work (pemap_dev * d, int n_ends, bool two_sets)
         {
           TRY (alloc_hits (d, d->hits2, n_ends));
           TRY (dev_alloc (d, &d->d_wins2, (size_t) n_ends));
-          TRY (dev_alloc (d, &d->d_tasks_s2, (size_t) n_ends * 2));       // second half: the problems left to the DP
-          TRY (dev_alloc (d, &d->d_tasks_m2, nh * 2));    // second half: the problems left to the DP
+          TRY (dev_alloc (d, &d->d_tasks_s2, (size_t) n_ends * 3));       // second third: the problems left to the DP, last third: to the banded DP
+          TRY (dev_alloc (d, &d->d_tasks_m2, nh * 3));
         }
-      TRY (dev_alloc (d, &d->d_tasks_s, (size_t) n_ends * 2));
-      TRY (dev_alloc (d, &d->d_tasks_m, nh * 2));
+      TRY (dev_alloc (d, &d->d_tasks_s, (size_t) n_ends * 3));
+      TRY (dev_alloc (d, &d->d_tasks_m, nh * 3));
       TRY (dev_alloc (d, &d->d_redo, (size_t) n_ends));
       d->cap_ends = n_ends;
     }
@@ -1276,11 +1285,22 @@ template < int W, int LPA > static void launch_chunk (pemap_dev * d, const RunCt
   if (pm_gapless_on (d))
     {
       uint32_t *tasks_dp = tasks_s + d->cap_ends;
+      uint32_t *tasks_band = d->kn.band ? tasks_s + 2 * (size_t) d->cap_ends : nullptr;
       int ggrid = (n_ends + 7) / 8;
       if (ggrid > d->n_cus * 16)
         ggrid = d->n_cus * 16;
       hipLaunchKernelGGL (pm_gapless_kernel, dim3 (ggrid), dim3 (256), 0, d->stream, c.ix, c.b, c.prm, H, tasks_s, &ctr->n_tasks_s, tasks_dp,
-                          &ctr->n_tasks_dp, pm_gapless_max_x (d));
+                          &ctr->n_tasks_dp, pm_gapless_max_x (d), tasks_band, &ctr->n_band[0]);
+      if (tasks_band)
+        {
+          // the problems the rule left open whose best diagonal has few mismatches: the DP restricted to a band of 32 diagonals,
+          // one lane per problem (pemap_band.hip.h); what is left for pm_sw_kernel are mostly the reads with a real indel
+          int bgrid = (n_ends + 63) / 64;
+          if (bgrid > d->n_cus * d->kn.band_waves_per_cu)
+            bgrid = d->n_cus * d->kn.band_waves_per_cu;
+          hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_band_kernel < true >), dim3 (bgrid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, H, tasks_band,
+                              &ctr->n_band[0], ctr, dirbuf, slab_dwords_for (d, c.L), &ctr->band_next[0]);
+        }
       hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, LPA, true >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, H,
                           tasks_dp, &ctr->n_tasks_dp, ctr, dirbuf, dump_slab, c.tstride, c.L, swprio, &ctr->sw_next[0]);
     }
@@ -1293,8 +1313,12 @@ template < int W, int LPA > static void launch_chunk (pemap_dev * d, const RunCt
       // the same rule on the problems of the multi-hit ends (scores only; a winner it decided is not scored again);
       // sw_next[3] counts what is left to the DP
       uint32_t *tasks_mdp = tasks_m + (size_t) d->cap_ends * PM_MAX_HITS;
+      uint32_t *tasks_mband = d->kn.band ? tasks_m + 2 * (size_t) d->cap_ends * PM_MAX_HITS : nullptr;
       hipLaunchKernelGGL (pm_gapless_kernel, dim3 (d->n_cus * 16), dim3 (256), 0, d->stream, c.ix, c.b, c.prm, H, tasks_m, &ctr->n_tasks_m, tasks_mdp,
-                          &ctr->sw_next[3], pm_gapless_max_x (d));
+                          &ctr->sw_next[3], pm_gapless_max_x (d), tasks_mband, &ctr->n_band[1]);
+      if (tasks_mband)
+        hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_band_kernel < false >), dim3 (d->n_cus * d->kn.band_waves_per_cu), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, H,
+                            tasks_mband, &ctr->n_band[1], ctr, dirbuf, slab_dwords_for (d, c.L), &ctr->band_next[1]);
       hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, LPA, false >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, H,
                           tasks_mdp, &ctr->sw_next[3], ctr, dirbuf, dump_slab, c.tstride, c.L, swprio, &ctr->sw_next[1]);
     }
@@ -1360,6 +1384,9 @@ static int absorb_run (pemap_dev * d)
       t.n_tasks_m += c.n_tasks_m;
       t.n_tasks_dp += pm_gapless_on (d) ? c.n_tasks_dp : c.n_tasks_s;
       t.sw_next[3] += pm_gapless_on (d) ? c.sw_next[3] : c.n_tasks_m;
+      t.n_band[0] += c.n_band[0];
+      t.n_band[1] += c.n_band[1];
+      t.cells_band += c.cells_band;
       t.n_slots += c.n_slots;
       t.n_redo += c.n_redo;
       t.n_wins += c.n_wins;
@@ -2175,7 +2202,7 @@ extern "C" int pemap_dev_run_stats (pemap_dev * d, uint64_t * s, float *t)
       s[0] = d->run_ends;
       s[1] = c.positions;
       s[2] = (uint64_t) c.n_tasks_s + c.n_tasks_m;
-      s[3] = (uint64_t) c.n_tasks_dp + c.n_redo;
+      s[3] = (uint64_t) c.n_tasks_dp + c.n_band[0] + c.n_redo;
       s[4] = c.cells_score;
       s[5] = c.cells_dirs;
       s[6] = c.pile_incs;
@@ -2184,7 +2211,10 @@ extern "C" int pemap_dev_run_stats (pemap_dev * d, uint64_t * s, float *t)
       s[9] = c.n_redo;
       s[10] = d->last_big;
       s[11] = (uint64_t) d->run_chunks;
-      s[12] = ((uint64_t) c.n_tasks_s - c.n_tasks_dp) + ((uint64_t) c.n_tasks_m - c.sw_next[3]);
+      s[12] = ((uint64_t) c.n_tasks_s - c.n_tasks_dp - c.n_band[0]) + ((uint64_t) c.n_tasks_m - c.sw_next[3] - c.n_band[1]);
+      s[13] = (uint64_t) c.n_band[0] + c.n_band[1];
+      s[14] = c.cells_band;
+      s[15] = 0;
     }
   if (t)
     memcpy (t, d->last_ms, sizeof (d->last_ms));

@@ -52,6 +52,9 @@ struct PmCounters
   unsigned long long pile_incs;
   unsigned long long n_ins;
   unsigned int sw_next[4];         // work counters of the three SW launches of a chunk (single-hit, multi-hit, redo)
+  unsigned int n_band[2];          // problems left to the banded DP (pm_band_kernel): single-hit ends, multi-hit ends
+  unsigned int band_next[2];       // their work counters
+  unsigned long long cells_band;   // band cells computed
 };
 
 // insertion log cursor: survives runs until the host drains the log
@@ -194,3 +197,4 @@ __device__ __forceinline__ void pm_set_prio (int p)
 #include "pemap_seed2.hip.h"
 #include "pemap_seed3.hip.h"
 #include "pemap_sw.hip.h"
+#include "pemap_band.hip.h"

@@ -404,8 +404,12 @@ __device__ __forceinline__ void pm_sw_forward (const PmSwTask & tk, int bis, int
 // ============================================================================================================
 #define PM_GAPLESS 4            // flag in PmHits::stk beside the plane number
 
+// problems the rule leaves open go to tasks_band (pm_band_kernel, pemap_band.hip.h) when the best diagonal has at most
+// PM_BAND_MAXX_ mismatches -- the condition under which the banded DP is exact -- and to tasks_dp (the full DP) otherwise
+#define PM_BAND_MAXX_ 6
 __global__ __launch_bounds__ (256) void pm_gapless_kernel (PmIndex ix, PmBatch b, PmParams prm, PmHits h, const uint32_t * tasks,
-                                                          const unsigned *n_tasks_p, uint32_t * tasks_dp, unsigned *n_tasks_dp, int max_x)
+                                                          const unsigned *n_tasks_p, uint32_t * tasks_dp, unsigned *n_tasks_dp, int max_x,
+                                                          uint32_t * tasks_band, unsigned *n_tasks_band)
 {
   __shared__ __align__ (8) uint8_t rd[8][320];
   const int lane = threadIdx.x & 63, l = lane & 31, half = lane & 32;
@@ -436,12 +440,12 @@ __global__ __launch_bounds__ (256) void pm_gapless_kernel (PmIndex ix, PmBatch b
       const int ndiag = valid ? nn - mm + 1 : 0;         // diagonals on which the whole read lies inside the window
       const bool mine = l < ndiag;
       const uint8_t *rp = ref + l;
-      // forward: mismatches up to the third, the positions of the first two
-      int mism = 3, m1 = mm, m2 = mm;
+      // forward: mismatches up to the seventh (three decide the rule, PM_BAND_MAXX_ the banded DP), the positions of the first two
+      int mism = 99, m1 = mm, m2 = mm;
       if (mine)
         {
           mism = 0;
-          for (int j = 0; j < mm && mism < 3; j += 8)
+          for (int j = 0; j < mm && mism <= PM_BAND_MAXX_; j += 8)
             {
               const uint64_t q = *(const uint64_t *) &rd[slot][j];
               const uint64_t r = *(const pm_u64_unaligned *) (rp + j);      // (the genome buffer is padded: reading past the window is safe)
@@ -529,8 +533,16 @@ __global__ __launch_bounds__ (256) void pm_gapless_kernel (PmIndex ix, PmBatch b
         {
           if (cmask == 0u)
             {
+              int xmin = mism;
+              for (int s = 16; s; s >>= 1)
+                xmin = min (xmin, __shfl_xor (xmin, s));      // (within the half-wave)
               if (l == 0)
-                tasks_dp[atomicAdd (n_tasks_dp, 1u)] = (uint32_t) o;
+                {
+                  if (tasks_band && xmin <= PM_BAND_MAXX_)
+                    tasks_band[atomicAdd (n_tasks_band, 1u)] = (uint32_t) o;
+                  else
+                    tasks_dp[atomicAdd (n_tasks_dp, 1u)] = (uint32_t) o;
+                }
             }
           else
             {
@@ -883,6 +895,9 @@ template < int W, int PM_LPA > __global__ __launch_bounds__ (256) void pm_walk_k
       const uint32_t *slab = dirbuf + (size_t) h.slot[end] * slab_dwords;
       const int pad = PM_LPA * W - mm;
       int k = h.stk[o], i = h.sti[o], j = mm;
+      const bool banded = (k & 8) != 0;          // PM_BANDED: the slab holds pm_band_kernel's column-major nibbles
+      if (banded)
+        k &= 3;
       int i1 = 0, ins_len = 0;
       unsigned long long *pw = path + (size_t) w * path_words;
       if (k & PM_GAPLESS)
@@ -907,10 +922,19 @@ template < int W, int PM_LPA > __global__ __launch_bounds__ (256) void pm_walk_k
           int maxk = 0;
           if (ci >= 1 && cj >= 1)
             {
-              const int J = cj - 1 + pad, gg = J / W, c = J - gg * W;
-              const uint32_t wv = slab[((size_t) gg * tstride + (ci + gg - 1)) * DW + (c >> 3)];
-              const int nd = (W - (c >> 3) * 8) < 8 ? (W - (c >> 3) * 8) : 8;      // cells in this dword
-              const uint32_t nib = (wv >> (4 * (nd - 1 - (c & 7)))) & 0xFu;
+              uint32_t nib;
+              if (banded)
+                {
+                  const int bb = ci - cj + 5;   // diagonal + PM_BAND_K: the optimal path stays inside the band (pemap_band.hip.h)
+                  nib = (slab[(size_t) cj * 4 + (bb >> 3)] >> (4 * (7 - (bb & 7)))) & 0xFu;
+                }
+              else
+                {
+                  const int J = cj - 1 + pad, gg = J / W, c = J - gg * W;
+                  const uint32_t wv = slab[((size_t) gg * tstride + (ci + gg - 1)) * DW + (c >> 3)];
+                  const int nd = (W - (c >> 3) * 8) < 8 ? (W - (c >> 3) * 8) : 8;      // cells in this dword
+                  nib = (wv >> (4 * (nd - 1 - (c & 7)))) & 0xFu;
+                }
               if (k == 0)
                 maxk = (nib & 2u) ? 2 : ((nib & 1u) ? 1 : 0);
               else if (k == 2)

@@ -295,10 +295,10 @@ class PemapDev:
         return out
 
     def run_stats(self):
-        s = np.zeros(13, np.uint64)
+        s = np.zeros(16, np.uint64)
         t = np.zeros(8, np.float32)
         self._ck(self.L.pemap_dev_run_stats(self.h, _p(s), _p(t)))
-        keys = ["ends", "positions", "sw_score", "sw_dirs", "cells_score", "cells_dirs", "pile_incs", "n_ins", "walks", "redo", "big_ends", "chunks", "gapless"]
+        keys = ["ends", "positions", "sw_score", "sw_dirs", "cells_score", "cells_dirs", "pile_incs", "n_ins", "walks", "redo", "big_ends", "chunks", "gapless", "banded", "cells_band", "reserved"]
         tk = ["seed", "sw_single", "sw_multi", "select", "sw_redo", "walk", "lookup", "vote"]
         return dict(zip(keys, (int(x) for x in s))), dict(zip(tk, (float(x) for x in t)))
 
