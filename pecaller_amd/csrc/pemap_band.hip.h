@@ -35,12 +35,13 @@
 // bytes per column, written column-major into the end's direction slab: slab[4 j + b / 8], first cell in the highest nibble.
 #pragma once
 
-#define PM_BAND_K 5
-#define PM_BAND_W 32            // 21 + 2 K + 1 diagonals
-#define PM_BAND_MAXX 6          // K + 3 + K/36 = 8.139 > 4 x / 3 for x <= 6
+// PM_BAND_K, PM_BAND_W = 21 + 2 K + 1 and the mismatch bound PM_BAND_MAXX_ are defined beside pm_gapless_kernel (pemap_sw.hip.h)
 #define PM_BANDED 8             // flag in PmHits::stk beside the plane number: the direction slab has the band's layout
 
-template < bool DIRS > __global__ __launch_bounds__ (64, 2) void pm_band_kernel (PmIndex ix, PmBatch b, PmParams prm, PmHits h, const uint32_t * tasks,
+#ifndef PM_BAND_WAVES_PER_EU
+#define PM_BAND_WAVES_PER_EU 2
+#endif
+template < bool DIRS > __global__ __launch_bounds__ (64, PM_BAND_WAVES_PER_EU) void pm_band_kernel (PmIndex ix, PmBatch b, PmParams prm, PmHits h, const uint32_t * tasks,
                                                                                const unsigned *n_tasks_p, PmCounters * ctr, uint32_t * dirbuf,
                                                                                size_t slab_dwords, unsigned *next_task)
 {
@@ -96,11 +97,11 @@ template < bool DIRS > __global__ __launch_bounds__ (64, 2) void pm_band_kernel 
           // the address starts up to K + 1 bytes before the window, in the last ones it ends behind it: the genome buffer is padded
           // on both sides, pemap_dev_index_alloc; what is computed from those bytes is never used, see below.)
           const int w0 = j - K - 1;           // window byte of diagonal 0
-          uint32_t wnd[BW / 4] = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u };
+          uint32_t wnd[8] = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u };      // 32 bytes are loaded, the first BW are used
           if (act)
             {
 #pragma unroll
-              for (int k = 0; k < BW / 8; k++)
+              for (int k = 0; k < 4; k++)
                 {
                   const uint64_t v = *(const pm_u64_unaligned *) (ref + w0 + 8 * k);
                   wnd[2 * k] = (uint32_t) v;
@@ -111,7 +112,7 @@ template < bool DIRS > __global__ __launch_bounds__ (64, 2) void pm_band_kernel 
               // says what pm_match says: byte = q where the letters match, ~q where they do not.
               uint32_t has_n = 0;
 #pragma unroll
-              for (int k = 0; k < BW / 4; k++)
+              for (int k = 0; k < (BW + 3) / 4; k++)
                 {
                   const uint32_t v = wnd[k] ^ 0x4E4E4E4Eu;
                   has_n |= (v - 0x01010101u) & ~v & 0x80808080u;
@@ -120,7 +121,7 @@ template < bool DIRS > __global__ __launch_bounds__ (64, 2) void pm_band_kernel 
               if (!q_plain || bis || has_n)
                 {
 #pragma unroll
-                  for (int k = 0; k < BW / 4; k++)
+                  for (int k = 0; k < (BW + 3) / 4; k++)
                     {
                       uint32_t w = 0;
 #pragma unroll
@@ -168,7 +169,12 @@ template < bool DIRS > __global__ __launch_bounds__ (64, 2) void pm_band_kernel 
                   M3[bb] = top ? bj : M3[bb];
                   U = top ? bj_u : U;
                 }
+              // (keeps the scheduler from starting many cells' independent halves at once: their doubles in flight cost more registers
+              // than the band itself)
+              __builtin_amdgcn_sched_barrier (0);
             }
+          if constexpr ((BW & 7) != 0)
+            dw[(BW >> 3) & 3] <<= 4 * (8 - (BW & 7));        // the last dword's first cell in its highest nibble, like the others
           if (any_last)
             {
               // The scan of the last column (pemapper.c:1724-1741: rows ascending, planes 0, 1, 2, strict '>').  A cell takes the

@@ -67,6 +67,7 @@ struct PmKnobs
   double dir_budget_gb;
   int lookup_lds_pad_kb, lookup_waves /* -1 unset */, lookup_v, lookup_batch /* -1 unset */;
   int lookup_prio, vote_prio, sw_prio;
+  int rest_stream3;
   int vote_rest_on_alu, vote_waves, vote_persist /* -1 unset */;
   int walk_blocks_per_cu, pile_blocks_per_cu;
   int mem_cus, mem_prio;
@@ -88,7 +89,7 @@ static int env_int (const char *name, int dflt)
 static void read_knobs (PmKnobs & k)
 {
   k.seed_blocks_per_cu = env_int ("PEMAP_SEED_BLOCKS_PER_CU", 8);
-  k.big_blocks_per_cu = env_int ("PEMAP_BIG_BLOCKS_PER_CU", 4);
+  k.big_blocks_per_cu = env_int ("PEMAP_BIG_BLOCKS_PER_CU", 8);
   k.sw_waves_per_cu = env_int ("PEMAP_SW_WAVES_PER_CU", 16);
   // a grid of zero or fewer blocks is not a setting
   if (k.seed_blocks_per_cu < 1) k.seed_blocks_per_cu = 1;
@@ -106,6 +107,7 @@ static void read_knobs (PmKnobs & k)
   k.vote_prio = env_int ("PEMAP_VOTE_PRIO", 0);
   k.sw_prio = env_int ("PEMAP_SW_PRIO", 0);
   k.vote_rest_on_alu = env_int ("PEMAP_VOTE_REST_ON_ALU", 0);
+  k.rest_stream3 = env_int ("PEMAP_REST_STREAM3", 0);
   k.vote_waves = env_int ("PEMAP_VOTE_WAVES", 1024);
   k.vote_persist = env_int ("PEMAP_VOTE_PERSIST", -1);
   k.walk_blocks_per_cu = env_int ("PEMAP_WALK_BLOCKS_PER_CU", 4);
@@ -1277,7 +1279,12 @@ template < int W, int LPA > static void launch_chunk (pemap_dev * d, const RunCt
   const int n_ends = c.b.n_ends;
   PmCounters *ctr = &cc->c;
   if (split && pm_fused (d))
-    ;                           // the seed stage ran on the look-up's stream (enqueue_lookup)
+    {
+      // the seed stage ran on the look-up's stream (enqueue_lookup); PEMAP_VOTE_REST_ON_ALU=1 leaves the big read-ends' remainder
+      // and the emit kernel to this stream
+      if (pm_vote_rest_on_alu (d) && !d->serial_split)
+        launch_vote (d, c, split, slot, cc, ev, d->stream, 2);
+    }
   else if (!(split && d->vote_on_mem))
     launch_vote (d, c, split, slot, cc, ev, d->stream);
   else if (d->vote_stream == 3 && pm_vote_rest_on_alu (d))
@@ -1537,7 +1544,8 @@ static int run_slice (pemap_dev * d, int first, int n, int sync, const hipEvent_
   { const int vm = (split && pm_fused (d)) ? 1 : d->kn.vote_on_mem >= 0 ? d->kn.vote_on_mem : (d->n_rep == 8 ? 2 : 0);
     d->vote_on_mem = split && !d->serial_split && vm != 0;
     d->vote_stream = (d->vote_on_mem && vm == 2) ? 3 : 2; }
-  if (d->vote_on_mem && d->vote_stream == 3 && !d->stream3)
+  const bool rest3 = split && pm_fused (d) && !d->serial_split && d->kn.rest_stream3 != 0;
+  if (((d->vote_on_mem && d->vote_stream == 3) || rest3) && !d->stream3)
     {
       // PEMAP_VOTE_STREAM_PRIO: queue priority of the vote's stream (-1 high, 0 normal, 1 low)
       if (d->kn.vote_stream_prio_set)
@@ -1639,7 +1647,18 @@ static int run_slice (pemap_dev * d, int first, int n, int sync, const hipEvent_
         if (g >= 2 && !d->serial_split)
           HIPCHK (d, hipStreamWaitEvent (fs, d->ev_walk_done[slot], 0));
         launch_lookup (d, cl, slot, d->d_chunk_ctr + g, &d->evs[(size_t) g * PM_NEV], true);
-        launch_vote (d, cl, true, slot, d->d_chunk_ctr + g, &d->evs[(size_t) g * PM_NEV], fs, 2);
+        if (rest3)
+          {
+            // PEMAP_REST_STREAM3=1: the big read-ends' remainder and the emit kernel on a stream of their own, so that the next
+            // chunk's fused kernel follows this one without them in between
+            HIPCHK (d, hipEventRecord (d->ev_lookup_done[slot], fs));
+            HIPCHK (d, hipStreamWaitEvent (d->stream3, d->ev_lookup_done[slot], 0));
+            launch_vote (d, cl, true, slot, d->d_chunk_ctr + g, &d->evs[(size_t) g * PM_NEV], d->stream3, 2);
+            HIPCHK (d, hipEventRecord (d->ev_lists_ready[slot], d->stream3));
+            return 0;
+          }
+        if (!(pm_vote_rest_on_alu (d) && !d->serial_split))
+          launch_vote (d, cl, true, slot, d->d_chunk_ctr + g, &d->evs[(size_t) g * PM_NEV], fs, 2);
         HIPCHK (d, hipEventRecord (d->ev_lists_ready[slot], fs));
         return 0;
       }

@@ -406,7 +406,14 @@ __device__ __forceinline__ void pm_sw_forward (const PmSwTask & tk, int bis, int
 
 // problems the rule leaves open go to tasks_band (pm_band_kernel, pemap_band.hip.h) when the best diagonal has at most
 // PM_BAND_MAXX_ mismatches -- the condition under which the banded DP is exact -- and to tasks_dp (the full DP) otherwise
-#define PM_BAND_MAXX_ 6
+// (the band's half-width K, its PM_BAND_W = 21 + 2 K + 1 diagonals and the mismatch bound are derived in pemap_band.hip.h:
+// K + 3 + K/36 > 4 x / 3  <=>  x <= 6, 5, 4, 3 for K = 5, 4, 3, 2)
+#ifndef PM_BAND_K
+#define PM_BAND_K 5
+#endif
+#define PM_BAND_W (22 + 2 * PM_BAND_K)
+#define PM_BAND_MAXX_ (PM_BAND_K >= 5 ? 6 : PM_BAND_K + 1)
+static_assert (PM_BAND_K >= 2 && PM_BAND_K <= 5, "the band holds at most 32 diagonals");
 __global__ __launch_bounds__ (256) void pm_gapless_kernel (PmIndex ix, PmBatch b, PmParams prm, PmHits h, const uint32_t * tasks,
                                                           const unsigned *n_tasks_p, uint32_t * tasks_dp, unsigned *n_tasks_dp, int max_x,
                                                           uint32_t * tasks_band, unsigned *n_tasks_band)
@@ -925,7 +932,7 @@ template < int W, int PM_LPA > __global__ __launch_bounds__ (256) void pm_walk_k
               uint32_t nib;
               if (banded)
                 {
-                  const int bb = ci - cj + 5;   // diagonal + PM_BAND_K: the optimal path stays inside the band (pemap_band.hip.h)
+                  const int bb = ci - cj + PM_BAND_K;   // diagonal + K: the optimal path stays inside the band (pemap_band.hip.h)
                   nib = (slab[(size_t) cj * 4 + (bb >> 3)] >> (4 * (7 - (bb & 7)))) & 0xFu;
                 }
               else

@@ -210,6 +210,94 @@ def test_gapless_rule_on_repeats_and_competing_gaps(L):
     dev.close()
 
 
+def _band_reads(contigs, seed, n, L):
+    """reads for the banded DP's corner: the best ungapped placement has 0..8 mismatches (the kernel takes <= 6) while the best
+    alignment may hold a gap -- an indel a few bases from either end of the read (its tail then counts as a handful of
+    mismatches), of any length up to the window's slop, with substitutions, Ns and tandem repeats around it"""
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    r1, r2 = [], []
+    for k in range(n):
+        c = contigs[int(rng.integers(0, len(contigs)))]
+        fl = int(rng.integers(L + 20, L + 380))
+        s = int(rng.integers(1500, int(len(c) * 0.4))) if k % 3 == 0 else int(rng.integers(0, len(c) - fl - 60))
+        ends = []
+        for which in (0, 1):
+            lo = s if which == 0 else s + fl - L
+            kind = int(rng.integers(0, 6))
+            tail = int(rng.integers(1, 13))                    # bases between the indel and the nearer end
+            p = tail if rng.random() < 0.5 else L - tail
+            if kind in (0, 1):      # the read skips b reference bases near an end
+                b = int(rng.integers(1, 22))
+                x = np.concatenate([c[lo:lo + p], c[lo + p + b:lo + L + b]]).copy()
+            elif kind in (2, 3):    # inserted bases near an end (up to beyond the band's K = 5)
+                a = int(rng.integers(1, 9))
+                x = np.concatenate([c[lo:lo + p], acgt[rng.integers(0, 4, a)], c[lo + p:lo + L - a]]).copy()
+            else:
+                x = c[lo:lo + L].copy()
+            nsub = int(rng.integers(0, 9)) if kind >= 4 else int(rng.integers(0, 4))    # 6 | 7 is the kernel's boundary
+            for q in rng.choice(L, size=nsub, replace=False):
+                other = acgt[acgt != x[q]]            # (x[q] may be one of the planted reference Ns)
+                x[q] = other[int(rng.integers(0, len(other)))]
+            if rng.random() < 0.1:
+                x[int(rng.integers(0, L))] = ord("N")
+            if which == 1:
+                x = COMP[x][::-1].copy()
+            ends.append(x)
+        a, b = ends
+        if rng.random() < 0.5:
+            a, b = b, a
+        r1.append(a.tobytes())
+        r2.append(b.tobytes())
+    return refio.pack_reads(r1) + refio.pack_reads(r2)
+
+
+@pytest.mark.parametrize("L", [150, 64, 250])
+def test_banded_dp_on_indels_near_read_ends(L):
+    """pm_band_kernel against the oracle's full DP where a band is most exposed: its problems are those with few mismatches on
+    the best diagonal, which includes reads whose best alignment has a gap a few bases from an end (the ungapped tail costs
+    less than 6 mismatches) -- deletions up to the window's slop, insertions beyond the band's half-width, 0..8 substitutions
+    (6 | 7 is where problems stop going to the band), reference Ns in the window (contigs are N-free here; the read's N is
+    the letter with its own rule).  Per hit the fp64 score bits and the traceback's start cell; coordinates, classes, pileup
+    and insertions."""
+    from pecaller_amd import PemapDev
+    contigs = _adversarial_genome(78)
+    for c in contigs[:3]:          # a few reference Ns: a window with one takes the rewritten-letters form of a column
+        c[np.random.default_rng(len(c)).integers(0, len(c), 300)] = ord("N")
+    mers, ukmer, ustart, cs = refio.kmer_index(contigs)
+    ix = dict(mers=mers, ukmer=ukmer, ustart=ustart, genome=np.concatenate(contigs), contig_starts=cs,
+              contig_len=np.array([len(c) for c in contigs], dtype=np.uint32))
+    n = 5000
+    b1, l1, b2, l2 = _band_reads(contigs, 9 + L, n, L)
+    dev = PemapDev(0)
+    dev.build_index(ix["genome"], ix["contig_len"])
+    dev.set_params(paired=True, min_dist=0, max_dist=500, min_align=0.85)
+    m1, m2, mt = dev.map_batch(b1, l1, b2, l2)
+    stats, _ = dev.run_stats()
+    dbg = dev.debug_hits(2 * n)
+    counts, ins = dev.fetch_pileup()
+    o = oracle_py.Oracle(ix, paired=True, min_dist=0, max_dist=500, min_align=0.85)
+    om1, om2, omt, d1, d2 = o.map_batch(b1, l1, b2, l2, debug=True, threads=8)
+    assert np.array_equal(m1, om1), np.nonzero(m1 != om1)[0][:10]
+    assert np.array_equal(m2, om2), np.nonzero(m2 != om2)[0][:10]
+    assert np.array_equal(mt, omt)
+    assert np.array_equal(counts, o.counts())
+    assert sorted(ins) == sorted(o.insertions())
+    for which, od in ((0, d1), (1, d2)):
+        nh = dbg["n_hits"][which::2]
+        assert np.array_equal(nh, od["n_hits"])
+        for i in np.nonzero(nh)[0]:
+            k = nh[i]
+            e = 2 * i + which
+            assert np.array_equal(dbg["score"][e, :k].view(np.uint64), od["score"][i, :k].view(np.uint64)), (e, k)
+            assert np.array_equal(dbg["start_k"][e, :k], od["start"][i, :k, 0]), e
+            assert np.array_equal(dbg["start_i"][e, :k], od["start"][i, :k, 1]), e
+    # the band took a good share, the full DP still had work (more than 6 mismatches), and gaps were found
+    # ("banded" counts both passes of a multi-hit end; cells_dirs are the full DP's cells: > n // 50 problems of L x (L + 21))
+    assert stats["banded"] > n // 4 and stats["cells_dirs"] > (n // 50) * L * (L + 21) and len(ins) > n // 50, stats
+    dev.close()
+
+
 def _repeat_family_genome(seed):
     """10 contigs of unique sequence with one repeat family planted in them: 95 exact copies of a 260-base tile and 95 copies of a
     variant that differs from it in every 16th base.  Every 16-mer of a read from the family then has a bucket of 95 positions
