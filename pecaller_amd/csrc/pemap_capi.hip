@@ -106,7 +106,7 @@ static void read_knobs (PmKnobs & k)
   k.lookup_prio = env_int ("PEMAP_LOOKUP_PRIO", 0);
   k.vote_prio = env_int ("PEMAP_VOTE_PRIO", 0);
   k.sw_prio = env_int ("PEMAP_SW_PRIO", 0);
-  k.vote_rest_on_alu = env_int ("PEMAP_VOTE_REST_ON_ALU", 0);
+  k.vote_rest_on_alu = env_int ("PEMAP_VOTE_REST_ON_ALU", -1);       // -1 unset: 1 with the fused seed kernel, else 0
   k.rest_stream3 = env_int ("PEMAP_REST_STREAM3", 0);
   k.vote_waves = env_int ("PEMAP_VOTE_WAVES", 1024);
   k.vote_persist = env_int ("PEMAP_VOTE_PERSIST", -1);
@@ -1136,7 +1136,7 @@ static void launch_lookup (pemap_dev * d, const RunCtx & c, int slot, PmChunkCtr
   const int lv = d->kn.lookup_v;
   // waves per CU: 6 (with the replicas 4 was the optimum while the SW kernel scored every problem: one per SIMD; since the
   // gapless rule took 78 % of its problems away the two streams balance at 6)
-  const int lw = d->kn.lookup_waves >= 0 ? d->kn.lookup_waves : (c.ix.n_rep == 8) ? (lv == 3 ? 7 : lv == 2 ? 3 : 6) : 6;
+  const int lw = d->kn.lookup_waves >= 0 ? d->kn.lookup_waves : (c.ix.n_rep == 8) ? (lv == 3 ? 5 : lv == 2 ? 3 : 6) : 6;
   int lgrid = lw * d->n_cus;
   if (lgrid > c.b.n_ends)
     lgrid = c.b.n_ends;
@@ -1178,9 +1178,10 @@ static void launch_lookup (pemap_dev * d, const RunCtx & c, int slot, PmChunkCtr
 // of the big read-ends and the emit kernel (part 2) go to the ALU stream in front of the chunk's SW, so that the next chunk's
 // vote starts 0.5 ms earlier.  Measured 43.3 ms per step against 41.7 (the vote kernel itself slows down by as much as it
 // gains: 4.95 ms per launch against 4.5), so it is off by default.
+static bool pm_fused (const pemap_dev * d);
 static bool pm_vote_rest_on_alu (const pemap_dev * d)
 {
-  return d->kn.vote_rest_on_alu != 0;
+  return d->kn.vote_rest_on_alu >= 0 ? d->kn.vote_rest_on_alu != 0 : pm_fused (d);
 }
 
 // part 0: the whole stage; 1: the vote kernel only; 2: what follows it
@@ -1380,6 +1381,27 @@ static int absorb_run (pemap_dev * d)
     HIPCHK (d, hipStreamSynchronize (d->stream3));
   HIPCHK (d, hipStreamSynchronize (d->stream));
   const int nch = d->run_chunks;
+#ifdef PEMAP_TIMING_PROBES
+  {
+    // the fused seed kernel's phase probes (pemap_seed3.hip.h): cycles summed over waves, printed per run
+    unsigned long long pr[16], z[16] = { 0ull };
+    if (hipMemcpyFromSymbol (pr, HIP_SYMBOL (pm_s3_probe), sizeof pr) == hipSuccess)
+      {
+        unsigned long long tot = 0;
+        for (int i = 0; i < 16; i++)
+          tot += pr[i];
+        if (tot)
+          {
+            static const char *nm[16] = { "lines0+wait", "decode0", "lines1", "decode1", "records-rest", "stage next", "segmask", "candidates", "relevant", "pairs", "rank+walk", "out", "rec:headers", "rec:scan+3", "rec:unit2", "rec:tails" };
+            fprintf (stderr, "[pm_s3_probe]");
+            for (int i = 0; i < 16; i++)
+              fprintf (stderr, " %s %.1f%%", nm[i], 100.0 * (double) pr[i] / (double) tot);
+            fprintf (stderr, " | total %.3f G wave-cycles\n", (double) tot / 1e9);
+          }
+        (void) hipMemcpyToSymbol (HIP_SYMBOL (pm_s3_probe), z, sizeof z);
+      }
+  }
+#endif
   std::vector < PmChunkCtr > hc (nch);
   HIPCHK (d, hipMemcpy (hc.data (), d->d_chunk_ctr, sizeof (PmChunkCtr) * nch, hipMemcpyDeviceToHost));
   HIPCHK (d, hipMemcpy (&d->last_cur, d->d_cur, sizeof (PmInsCursor), hipMemcpyDeviceToHost));

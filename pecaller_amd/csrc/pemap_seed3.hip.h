@@ -56,6 +56,13 @@ template < int SMAX > struct __align__ (16) PmSeed3Shared
       uint2 sv[RCAP];                   // the surviving anchors: x = key, y = segment | tot_found << 8 (strand 0 from the front, 1 from the back)
       uint16_t order[RCAP];
     } v;
+    struct                              // ... and in between, while the records are read: the work list of their tails
+    {
+      uint32_t src[128];                // per record (64 of strand 0, 64 of strand 1) with more than 3 positions: word in `multi` ...
+      int32_t dst[128];                 // ... and slot in its strand's list of its 4th position, both minus the record's place in the flattened tail
+      uint8_t sg[128];                  // segment | strand << 7
+      uint8_t mark[2 * CAP];            // flattened tail: record number + 1 at the record's first element, 0 elsewhere
+    } x;
   } a;
   // diagonal keys m + PM_DIAG_BIAS - offset(segment) per strand, from the front; while the entries are decoded the entries that
   // point to a record wait at the back (a strand has at most 49 x S <= 931 look-ups, each of them one or the other)
@@ -94,17 +101,61 @@ __device__ __forceinline__ int pm_lanes_below (unsigned long long m)
   return (int) __builtin_amdgcn_mbcnt_hi ((unsigned) (m >> 32), __builtin_amdgcn_mbcnt_lo ((unsigned) m, 0u));
 }
 
-__device__ __forceinline__ int pm_wave_min (int v)
+// Wave-wide scan / reduction on the DPP path (row shifts inside the 16-lane rows, then the row broadcasts of gfx9): six VALU
+// instructions, against six round trips through the LDS crossbar (~100 cycles each, queued behind the wave's other LDS traffic)
+// for the __shfl forms.  Lanes without a source lane take `ident`.
+template < int CTRL, int ROW_MASK > __device__ __forceinline__ int pm_dpp_or (int ident, int v)
 {
-  for (int o = 32; o; o >>= 1)
-    v = min (v, __shfl_xor (v, o));
+  return __builtin_amdgcn_update_dpp (ident, v, CTRL, ROW_MASK, 0xF, false);
+}
+
+__device__ __forceinline__ uint32_t pm_wave_incl_sum (uint32_t v)       // inclusive prefix sum over the lanes; lane 63 = the total
+{
+  v += (uint32_t) pm_dpp_or < 0x111, 0xF > (0, (int) v);        // row_shr:1
+  v += (uint32_t) pm_dpp_or < 0x112, 0xF > (0, (int) v);        // row_shr:2
+  v += (uint32_t) pm_dpp_or < 0x114, 0xF > (0, (int) v);        // row_shr:4
+  v += (uint32_t) pm_dpp_or < 0x118, 0xF > (0, (int) v);        // row_shr:8
+  v += (uint32_t) pm_dpp_or < 0x142, 0xA > (0, (int) v);        // row_bcast:15 into rows 1 and 3
+  v += (uint32_t) pm_dpp_or < 0x143, 0xC > (0, (int) v);        // row_bcast:31 into rows 2 and 3
   return v;
+}
+
+__device__ __forceinline__ int pm_wave_incl_max (int v)       // inclusive prefix maximum of non-negative values
+{
+  v = max (v, pm_dpp_or < 0x111, 0xF > (0, v));
+  v = max (v, pm_dpp_or < 0x112, 0xF > (0, v));
+  v = max (v, pm_dpp_or < 0x114, 0xF > (0, v));
+  v = max (v, pm_dpp_or < 0x118, 0xF > (0, v));
+  v = max (v, pm_dpp_or < 0x142, 0xA > (0, v));
+  v = max (v, pm_dpp_or < 0x143, 0xC > (0, v));
+  return v;
+}
+
+__device__ __forceinline__ int pm_wave_min (int v)      // the minimum over the wave (uniform)
+{
+  const int big = 0x7FFFFFFF;
+  v = min (v, pm_dpp_or < 0x111, 0xF > (big, v));
+  v = min (v, pm_dpp_or < 0x112, 0xF > (big, v));
+  v = min (v, pm_dpp_or < 0x114, 0xF > (big, v));
+  v = min (v, pm_dpp_or < 0x118, 0xF > (big, v));
+  v = min (v, pm_dpp_or < 0x142, 0xA > (big, v));
+  v = min (v, pm_dpp_or < 0x143, 0xC > (big, v));
+  return __builtin_amdgcn_readlane (v, 63);
 }
 
 // LDS is passed as dynamic shared memory (sizeof (PmSeed3Shared < SMAX >)): from a static 30 KB the compiler concludes that two waves
 // per SIMD are all the kernel will ever get and spends 185 VGPRs on it, whatever the launch bounds say -- and a SIMD that hosts such
 // a wave has room for one wave of the fp64 SW kernel (168 VGPRs) instead of two.
 extern __shared__ __align__ (16) uint8_t pm_seed3_lds[];
+
+// Cycle probes of the kernel's phases (a library built with -DPEMAP_TIMING_PROBES only): per wave the core-clock cycles between
+// the marks below, summed over the grid into pm_s3_probe[]; pemap_capi.hip prints and clears them after every run.
+#ifdef PEMAP_TIMING_PROBES
+__device__ unsigned long long pm_s3_probe[16];
+#define PM_S3_T(i) do { const unsigned long long t_ = __builtin_readcyclecounter (); pacc[i] += t_ - plast; plast = t_; } while (0)
+#else
+#define PM_S3_T(i) do { } while (0)
+#endif
 
 template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES_PER_EU : 2) void pm_seed3_kernel (PmIndex ix, PmBatch b, PmParams prm, PmHits h, PmLists out, int prio)
 {
@@ -130,9 +181,12 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
   const uint32_t nb_p4 = 4u * (uint32_t) nb_p, nb_pw = 16u * (uint32_t) nb_p;
 
   // ends are handed out through a counter, two values ahead of their use (the first grid-ful by block index)
+  // (the grid size is read from the dispatch packet with a vector load: brought to a scalar register here, before the loop, or the
+  // loop's first use of it carries a "wait for every outstanding load" into every iteration)
+  const int grid_n = __builtin_amdgcn_readfirstlane ((int) gridDim.x);
   auto next_end = [&] ()->int
   {
-    return (int) gridDim.x + (int) __builtin_amdgcn_readfirstlane ((int) (lane == 0 ? atomicAdd (out.next_end, 1u) : 0u));
+    return grid_n + (int) __builtin_amdgcn_readfirstlane ((int) (lane == 0 ? atomicAdd (out.next_end, 1u) : 0u));
   };
   int eQ = blockIdx.x;
   int eP = next_end ();
@@ -155,26 +209,27 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
   // kmer[bf], and the 2 x S x 8 line requests into ln[].  -> S, or 0 when the N filter drops the read
   // (the length is a per-lane load of one address: told to be wave-uniform here, where it is first needed, so that everything
   // derived from it -- segment counts, loop bounds, the branches on them -- lives in scalar registers)
-  auto stage_p = [&] (uint32_t & kmer_out, int &len_out)->int
+  // (`between` runs after the read's bytes have been consumed and before the line requests are issued: the memory counter is in
+  // order, so whatever is issued BEFORE the point that waits for the bytes is waited for as well, and the compiler cannot count
+  // conditional stores -- the loop puts the previous end's output and the work counter's atomic there)
+  auto stage_p = [&] (uint32_t & kmer_out, int &len_out, auto between)->int
   {
     const int len = __builtin_amdgcn_readfirstlane (rlen);
     len_out = len;
-    int isn = 0;
+    int isn = 0;                // (counted with ballots: scalar)
 #pragma unroll
     for (int t = 0; t < 5; t++)
       {
         const int i = lane + 64 * t;
+        const uint8_t c = rb[t];
         if (i < len)
           {
             // fill_cv_mat / convert_ct (pemapper.c:2375-2383, 2292-2300) of the read and of its reverse complement
-            const uint8_t c = rb[t];
             sh.seq[0][i] = (uint8_t) pm_code_flat (c, prm.bisulfite);
             sh.seq[1][len - 1 - i] = (uint8_t) pm_code_flat (pm_rc_flat (c), prm.bisulfite);
-            isn += (c == 'N');
           }
+        isn += (int) __popcll (__ballot (i < len && c == 'N'));
       }
-    for (int o = 32; o; o >>= 1)
-      isn += __shfl_xor (isn, o);
     int cuts = len / idepth;    // pemapper.c:1573-1587
     if (len % idepth == 0)
       cuts--;
@@ -182,9 +237,10 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
       cuts = SMAX - 1;
     cuts = __builtin_amdgcn_readfirstlane (cuts);       // (integer division is done by the vector unit)
     const int S = cuts + 1;
-    if (__builtin_amdgcn_readfirstlane (isn) >= __builtin_amdgcn_readfirstlane (1 + len / 10))
-      return 0;
     pm_wave_sync ();
+    between ();
+    if (isn >= __builtin_amdgcn_readfirstlane (1 + len / 10))
+      return 0;
     if (lane < 2 * S)
       {
         const int strand = lane >= S ? 1 : 0, seg = lane - strand * S;
@@ -202,7 +258,9 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
       {
         const int li = r * 16 + (lane >> 2);
         ln[r] = make_uint4 (0u, 0u, 0u, 0u);
-        const uint32_t ksrc = (uint32_t) __shfl ((int) kmer_out, (li >> 3) & 63);        // (every lane takes part in the shuffle)
+        // (li >> 3 = 2 r + (lane >> 5): the two k-mers a register's lines belong to come over the scalar side)
+        const uint32_t k_lo = (uint32_t) __builtin_amdgcn_readlane ((int) kmer_out, (2 * r) & 63), k_hi = (uint32_t) __builtin_amdgcn_readlane ((int) kmer_out, (2 * r + 1) & 63);
+        const uint32_t ksrc = lane < 32 ? k_lo : k_hi;
         if (li < n_lines)
           {
             const int p = li & 7;
@@ -218,11 +276,42 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
   if (eQ < n_ends)
     {
       load_bytes (eQ);
-      SQ = stage_p (kQ, lenQ);
+      SQ = stage_p (kQ, lenQ, [] () { });
     }
   if (eP < n_ends)
     load_bytes (eP);
 
+  // the end whose hits are still in LDS (written out one iteration later, see O below)
+  int e_out = -1, tot_out = 0;
+  bool big_out = false;
+  auto flush_out = [&] ()
+  {
+    if (e_out < 0)
+      return;
+    if (big_out)
+      {
+        if (lane == 0)
+          out.big_list[atomicAdd (out.n_big, 1u)] = (uint32_t) e_out;
+      }
+    else
+      {
+        // ---- raw hits out (pm_seed_emit's format); pm_emit_kernel makes windows and task lists of them
+        if (lane == 0)
+          h.n_hits[e_out] = tot_out;
+        for (int t = lane; t < tot_out; t += 64)
+          {
+            const size_t o = (size_t) e_out * PM_MAX_HITS + t;
+            h.spot[o] = sh.hits[t];
+            h.nn[o] = (int16_t) sh.hits_off[t];
+            h.orient[o] = sh.hits_or[t];
+          }
+      }
+    e_out = -1;
+  };
+#ifdef PEMAP_TIMING_PROBES
+  unsigned long long pacc[16] = { 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull };
+  unsigned long long plast = __builtin_readcyclecounter ();
+#endif
   while (eQ < n_ends)
     {
       // (loop-carried and wave-uniform: said so, or the compiler keeps them, and every branch on them, in vector registers)
@@ -251,6 +340,7 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
           if (lane < 2 * SMAX)
             sh.seg_cnt[lane] = 0;
           pm_wave_sync ();
+          PM_S3_T (0);
           // ---- B: one (strand, segment) per round, lane j = neighbour j.  A segment with a bucket of too_many_spots or more is
           //      dropped whole (pemapper.c:1602-1606: the entry itself says so); buckets of one position go straight to the
           //      front of the strand's list; entries that point to a record are parked at its back
@@ -303,21 +393,106 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
           };
           decode_strand (std::integral_constant < int, 0 > { });
           pm_wave_sync ();
+          PM_S3_T (1);
           lines_to_lds (1);
           pm_wave_sync ();
+          PM_S3_T (2);
           decode_strand (std::integral_constant < int, 1 > { });
           pm_wave_sync ();
+          PM_S3_T (3);
           // ---- C: the records: {count, positions...} in 16-byte units; the first unit answers for buckets of up to 3 positions,
-          //      the second for up to 7, longer ones are copied by the whole wave.  Two rounds of 64 records in flight.  The
-          //      positions go to the front of the list whose back still holds the records not yet read: an end whose list would
-          //      reach them is left to the monolithic kernel (only ends close to the capacity anyway).
-          auto records_strand = [&] (auto ST)
+          //      the second for up to 7, longer ones are copied by the whole wave.  The first 64 records of BOTH strands are
+          //      requested before either strand is filed (one exposed HBM latency instead of two); what a strand has beyond them
+          //      follows in rounds of 2 x 64.  The positions go to the front of the list whose back still holds the records not
+          //      yet read: an end whose list would reach them is left to the monolithic kernel (only ends close to the capacity
+          //      anyway).
+          // one round: lane = record (count in hdr.x, its first three positions behind it), `limit` = where this strand's front
+          // must stop
+          auto rec_round = [&] (auto ST, const uint4 & hdr, const int seg, const uint32_t unit_, const bool valid, const int limit, auto more, uint32_t & c_out, int &dst_out, bool & wr_out)
           {
             constexpr int strand = decltype (ST)::value;
             int &nf = strand ? nf1 : nf0;
+            const uint32_t c = valid ? hdr.x : 0u;
+            const uint32_t incl = pm_wave_incl_sum (c);
+            const int dst = nf + (int) (incl - c);
+            nf += __builtin_amdgcn_readlane ((int) incl, 63);
+            if (nf > limit)
+              big = true;       // (wave-uniform) nothing more is written for this end: it goes to the big-end list
+            const bool wr = valid && !big;
+            const int off = (seg < cuts || cuts == 0) ? seg * idepth : last_off;
+            const uint32_t bias = (uint32_t) (PM_DIAG_BIAS - off);
+            if (wr)
+              {
+                atomicAdd (&sh.seg_cnt[strand * S + seg], (int) c);
+                uint32_t *kk = &sh.key[strand][dst];
+                uint8_t *tt = &sh.tag[strand][dst];
+                kk[0] = hdr.y + bias;
+                tt[0] = (uint8_t) seg;
+                kk[1] = hdr.z + bias;
+                tt[1] = (uint8_t) seg;
+                if (c > 2)
+                  {
+                    kk[2] = hdr.w + bias;
+                    tt[2] = (uint8_t) seg;
+                  }
+              }
+            PM_S3_T (13);
+            c_out = c;
+            dst_out = dst;
+            wr_out = wr;
+            if (!decltype (more)::value)
+              return;
+            const bool need2 = wr && c > 3;
+            if (__ballot (need2) != 0ull)
+              {
+                if (need2)
+                  {
+                    const uint4 h2 = *(const uint4 *) (ix.multi + (size_t) unit_ * 4 + 4);
+                    uint32_t *kk = &sh.key[strand][dst];
+                    uint8_t *tt = &sh.tag[strand][dst];
+                    kk[3] = h2.x + bias;
+                    tt[3] = (uint8_t) seg;
+                    if (c > 4)
+                      {
+                        kk[4] = h2.y + bias;
+                        tt[4] = (uint8_t) seg;
+                      }
+                    if (c > 5)
+                      {
+                        kk[5] = h2.z + bias;
+                        tt[5] = (uint8_t) seg;
+                      }
+                    if (c > 6)
+                      {
+                        kk[6] = h2.w + bias;
+                        tt[6] = (uint8_t) seg;
+                      }
+                  }
+              }
+            PM_S3_T (14);
+            unsigned long long bl = __ballot (wr && c > 7);
+            while (bl)
+              {
+                const int l = __ffsll ((long long) bl) - 1;
+                bl &= bl - 1;
+                const int cc = __builtin_amdgcn_readlane ((int) c, l), dd = __builtin_amdgcn_readlane (dst, l), sgl = __builtin_amdgcn_readlane (seg, l);
+                const uint32_t bl_bias = (uint32_t) __builtin_amdgcn_readlane ((int) bias, l);
+                const uint32_t *rec = ix.multi + (size_t) (uint32_t) __builtin_amdgcn_readlane ((int) unit_, l) * 4 + 1;
+                for (int q = 7 + lane; q < cc; q += 64)
+                  {
+                    sh.key[strand][dd + q] = rec[q] + bl_bias;
+                    sh.tag[strand][dd + q] = (uint8_t) sgl;
+                  }
+              }
+            PM_S3_T (15);
+          };
+          // a strand's records from the 65th on
+          auto records_rest = [&] (auto ST)
+          {
+            constexpr int strand = decltype (ST)::value;
             const int nm = strand ? nm1 : nm0;
 #pragma unroll 1
-            for (int i0 = 0; i0 < nm && !big; i0 += 128)
+            for (int i0 = 64; i0 < nm && !big; i0 += 128)
               {
                 uint4 hd[2];
                 int sgv[2];
@@ -341,104 +516,145 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
                 for (int r = 0; r < 2; r++)
                   if (i0 + r * 64 < nm && !big)
                     {
-                      const bool valid = i0 + r * 64 + lane < nm;
-                      const uint32_t c = valid ? hd[r].x : 0u;
-                      const int seg = sgv[r];
-                      uint32_t incl = c;
-                      for (int o = 1; o < 64; o <<= 1)
-                        {
-                          const uint32_t t = __shfl_up (incl, o);
-                          if (lane >= o)
-                            incl += t;
-                        }
-                      const int dst = nf + (int) (incl - c);
-                      nf += __builtin_amdgcn_readlane ((int) incl, 63);
-                      if (nf > limit)
-                        big = true;     // (wave-uniform) nothing more is written for this end: it goes to the big-end list
-                      const bool wr = valid && !big;
-                      const int off = (seg < cuts || cuts == 0) ? seg * idepth : last_off;
-                      const uint32_t bias = (uint32_t) (PM_DIAG_BIAS - off);
-                      if (wr)
-                        {
-                          atomicAdd (&sh.seg_cnt[strand * S + seg], (int) c);
-                          uint32_t *kk = &sh.key[strand][dst];
-                          uint8_t *tt = &sh.tag[strand][dst];
-                          kk[0] = hd[r].y + bias;
-                          tt[0] = (uint8_t) seg;
-                          kk[1] = hd[r].z + bias;
-                          tt[1] = (uint8_t) seg;
-                          if (c > 2)
-                            {
-                              kk[2] = hd[r].w + bias;
-                              tt[2] = (uint8_t) seg;
-                            }
-                        }
-                      const bool need2 = wr && c > 3;
-                      if (__ballot (need2) != 0ull)
-                        {
-                          if (need2)
-                            {
-                              const uint4 h2 = *(const uint4 *) (ix.multi + (size_t) unit[r] * 4 + 4);
-                              uint32_t *kk = &sh.key[strand][dst];
-                              uint8_t *tt = &sh.tag[strand][dst];
-                              kk[3] = h2.x + bias;
-                              tt[3] = (uint8_t) seg;
-                              if (c > 4)
-                                {
-                                  kk[4] = h2.y + bias;
-                                  tt[4] = (uint8_t) seg;
-                                }
-                              if (c > 5)
-                                {
-                                  kk[5] = h2.z + bias;
-                                  tt[5] = (uint8_t) seg;
-                                }
-                              if (c > 6)
-                                {
-                                  kk[6] = h2.w + bias;
-                                  tt[6] = (uint8_t) seg;
-                                }
-                            }
-                        }
-                      unsigned long long bl = __ballot (wr && c > 7);
-                      while (bl)
-                        {
-                          const int l = __ffsll ((long long) bl) - 1;
-                          bl &= bl - 1;
-                          const int cc = __builtin_amdgcn_readlane ((int) c, l), dd = __builtin_amdgcn_readlane (dst, l), sgl = __builtin_amdgcn_readlane (seg, l);
-                          const uint32_t bl_bias = (uint32_t) __builtin_amdgcn_readlane ((int) bias, l);
-                          const uint32_t *rec = ix.multi + (size_t) (uint32_t) __builtin_amdgcn_readlane ((int) unit[r], l) * 4 + 1;
-                          for (int q = 7 + lane; q < cc; q += 64)
-                            {
-                              sh.key[strand][dd + q] = rec[q] + bl_bias;
-                              sh.tag[strand][dd + q] = (uint8_t) sgl;
-                            }
-                        }
+                      uint32_t c_;
+                      int d_;
+                      bool w_;
+                      rec_round (ST, hd[r], sgv[r], unit[r], i0 + r * 64 + lane < nm, limit, std::true_type { }, c_, d_, w_);
                     }
               }
           };
-          records_strand (std::integral_constant < int, 0 > { });
-          records_strand (std::integral_constant < int, 1 > { });
+          {
+            uint4 hA = make_uint4 (0u, 0u, 0u, 0u), hB = make_uint4 (0u, 0u, 0u, 0u);
+            int sgA = 0, sgB = 0;
+            uint32_t uA = 0, uB = 0;
+            if (lane < nm0)
+              {
+                uA = sh.key[0][SH::CAP - 1 - lane];
+                sgA = sh.tag[0][SH::CAP - 1 - lane];
+                hA = *(const uint4 *) (ix.multi + (size_t) uA * 4);
+              }
+            if (lane < nm1)
+              {
+                uB = sh.key[1][SH::CAP - 1 - lane];
+                sgB = sh.tag[1][SH::CAP - 1 - lane];
+                hB = *(const uint4 *) (ix.multi + (size_t) uB * 4);
+              }
+#ifdef PEMAP_TIMING_PROBES
+            { const uint32_t w_ = hA.x + hB.x; asm volatile ("" :: "v" (w_)); }      // (the loads have landed)
+            PM_S3_T (12);
+#endif
+            // the first three positions of each record; the 4th and later ones of all 2 x 64 records as ONE flattened list, lane =
+            // element, so that their loads are in flight together whatever records they belong to (record by record, every record
+            // of more than 7 positions cost a memory round trip of its own): the record of element t is the largest record number
+            // marked at or before t (a prefix maximum), its source word and list slot are affine in t
+            uint32_t cA = 0, cB = 0;
+            int dA = 0, dB = 0;
+            bool wA = false, wB = false;
+            if (nm0 > 0)
+              rec_round (std::integral_constant < int, 0 > { }, hA, sgA, uA, lane < nm0, nm0 > 64 ? SH::CAP - nm0 : SH::CAP, std::false_type { }, cA, dA, wA);
+            if (nm1 > 0 && !big)
+              rec_round (std::integral_constant < int, 1 > { }, hB, sgB, uB, lane < nm1, nm1 > 64 ? SH::CAP - nm1 : SH::CAP, std::false_type { }, cB, dB, wB);
+            if (!big)
+              {
+                const uint32_t restA = (wA && cA > 3u) ? cA - 3u : 0u, restB = (wB && cB > 3u) ? cB - 3u : 0u;
+                const uint32_t inA = pm_wave_incl_sum (restA), inB = pm_wave_incl_sum (restB);
+                const int totA = __builtin_amdgcn_readlane ((int) inA, 63), M = totA + __builtin_amdgcn_readlane ((int) inB, 63);
+                if (M > 0)
+                  {
+                    for (int i = lane; i < (M + 15) / 16; i += 64)
+                      ((uint4 *) sh.a.x.mark)[i] = make_uint4 (0u, 0u, 0u, 0u);
+                    pm_wave_sync ();
+                    if (restA)
+                      {
+                        const int ro = (int) (inA - restA);
+                        sh.a.x.mark[ro] = (uint8_t) (lane + 1);
+                        sh.a.x.src[lane] = uA * 4u + 4u - (uint32_t) ro;
+                        sh.a.x.dst[lane] = dA + 3 - ro;
+                        sh.a.x.sg[lane] = (uint8_t) sgA;
+                      }
+                    if (restB)
+                      {
+                        const int ro = totA + (int) (inB - restB);
+                        sh.a.x.mark[ro] = (uint8_t) (lane + 65);
+                        sh.a.x.src[64 + lane] = uB * 4u + 4u - (uint32_t) ro;
+                        sh.a.x.dst[64 + lane] = dB + 3 - ro;
+                        sh.a.x.sg[64 + lane] = (uint8_t) (sgB | 0x80);
+                      }
+                    pm_wave_sync ();
+                    int carry = 0;
+#pragma unroll 1
+                    for (int t0 = 0; t0 < M; t0 += 256)
+                      {
+                        uint32_t val[4];
+                        int own[4];
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                          {
+                            const int t = t0 + 64 * j + lane;
+                            const int m = t < M ? (int) sh.a.x.mark[t] : 0;
+                            const int o = max (pm_wave_incl_max (m), carry);
+                            carry = __builtin_amdgcn_readlane (o, 63);
+                            own[j] = o - 1;
+                            val[j] = 0u;
+                            if (t < M)
+                              val[j] = ix.multi[(size_t) (sh.a.x.src[o - 1] + (uint32_t) t)];
+                          }
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                          {
+                            const int t = t0 + 64 * j + lane;
+                            if (t < M)
+                              {
+                                const int o = own[j];
+                                const int d = sh.a.x.dst[o] + t;
+                                const int sgs = (int) sh.a.x.sg[o];
+                                const int seg = sgs & 31, st = sgs >> 7;
+                                const int off = (seg < cuts || cuts == 0) ? seg * idepth : last_off;
+                                sh.key[st][d] = val[j] + (uint32_t) (PM_DIAG_BIAS - off);
+                                sh.tag[st][d] = (uint8_t) seg;
+                              }
+                          }
+                      }
+                  }
+                PM_S3_T (15);
+                records_rest (std::integral_constant < int, 0 > { });
+                if (!big)
+                  records_rest (std::integral_constant < int, 1 > { });
+              }
+          }
           pm_wave_sync ();
+          PM_S3_T (4);
           T0 = nf0;
           T1 = nf1;
           big = big || T0 > SH::CAP || T1 > SH::CAP;
           // pemapper.c:2200-2207: a strand is not searched when every one of its segments holds more than max_hits positions
           {
             const int c = lane < 2 * S ? sh.seg_cnt[lane] : 10000;
-            cmin0 = __builtin_amdgcn_readfirstlane (pm_wave_min (lane < S ? c : 10000));
-            cmin1 = __builtin_amdgcn_readfirstlane (pm_wave_min (lane >= S ? c : 10000));
+            cmin0 = pm_wave_min (lane < S ? c : 10000);
+            cmin1 = pm_wave_min (lane >= S ? c : 10000);
           }
         }
+      // ---- O: the PREVIOUS end's hits leave LDS (its vote wrote them, this end's vote has not run yet), and the counter hands out the
+      //      end after the next two.  Both are issued here, ahead of the loads below and with this end's vote between them and the
+      //      next wait on the memory counter: at the bottom of the loop they made every iteration wait for an atomic's round trip.
+      // (atomicInc: the compiler's wave-aggregation of atomicAdd reads the result back at once; only lane 0's value is ever read)
+      uint32_t raw_next;
+      auto out_and_next = [&] ()
+      {
+        flush_out ();
+        if (lane == 0)
+          raw_next = atomicInc (out.next_end, 0xFFFFFFFFu);
+      };
       // ---- P: the next end's k-mers and line requests (its bytes arrived during the previous iteration); R: the bytes of the end after
       int SP = 0, lenP = 0;
       uint32_t kP = 0;
       if (eP < n_ends)
-        {
-          SP = stage_p (kP, lenP);
-        }
+        SP = stage_p (kP, lenP, out_and_next);
+      else
+        out_and_next ();
       if (eR < n_ends)
         load_bytes (eR);
+      PM_S3_T (5);
       // ---- V: find_matches (pemapper.c:2189-2289) on the lists in LDS
       if (S > 0 && !big)
         {
@@ -479,6 +695,7 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
                   }
               }
           pm_wave_sync ();
+          PM_S3_T (6);
           unsigned long long any_cand = 0ull;
           // candidate anchors: positions of a segment the walk can reach whose three bins hold at least min_match - 1 LATER segments
           // (everything within max_off - 1 <= 15 diagonals of an anchor lies in those bins; colliding bins only add candidates)
@@ -521,6 +738,7 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
                   }
               }
           pm_wave_sync ();
+          PM_S3_T (7);
           // the positions next to a candidate (same or adjacent bin), both strands, compacted
           int nR = 0;
           for (int st = 0; st < 2 && any_cand != 0ull; st++)      // (most ends that do not map have no candidate at all)
@@ -561,6 +779,7 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
                   }
               }
           pm_wave_sync ();
+          PM_S3_T (8);
           if (nR > SH::RCAP)
             big = true;         // a repeat: left to the monolithic kernel
           else
@@ -600,6 +819,7 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
                   ns1 += (int) __popcll (b1);
                 }
               pm_wave_sync ();
+              PM_S3_T (9);
               bool go_on = true;
               for (int strand = 0; strand < 2 && go_on; strand++)
                 {
@@ -713,32 +933,29 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
                 }
             }
         }
-      if (big)
-        {
-          if (lane == 0)
-            out.big_list[atomicAdd (out.n_big, 1u)] = (uint32_t) e;
-        }
-      else
-        {
-          // ---- raw hits out (pm_seed_emit's format); pm_emit_kernel makes windows and task lists of them
-          if (lane == 0)
-            h.n_hits[e] = tot;
-          for (int t = lane; t < tot; t += 64)
-            {
-              const size_t o = (size_t) e * PM_MAX_HITS + t;
-              h.spot[o] = sh.hits[t];
-              h.nn[o] = (int16_t) sh.hits_off[t];
-              h.orient[o] = sh.hits_or[t];
-            }
-        }
+      PM_S3_T (10);
+      e_out = e;
+      tot_out = tot;
+      big_out = big;
       pm_wave_sync ();
+      PM_S3_T (11);
       eQ = eP;
       eP = eR;
-      eR = next_end ();
+      const int raw_s = __builtin_amdgcn_readfirstlane ((int) raw_next);
+      eR = grid_n + raw_s;
+      // (pinned to a scalar register HERE: left alone the compiler defers the read of the atomic's result to eR's first use, which
+      // comes right behind the next line requests -- and the in-order memory counter then waits for those as well)
+      asm volatile ("; work counter read %0"::"s" (raw_s));
       SQ = SP;
       lenQ = lenP;
       kQ = kP;
     }
+  flush_out ();
+#ifdef PEMAP_TIMING_PROBES
+  if (lane == 0)
+    for (int i = 0; i < 16; i++)
+      atomicAdd (&pm_s3_probe[i], pacc[i]);
+#endif
   if (lane == 0 && n_pos)
     atomicAdd (out.positions, n_pos);
 }
