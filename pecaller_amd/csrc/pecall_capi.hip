@@ -43,7 +43,7 @@ struct pecall_dev
   long staged_sites;
   int staged_indiv;
   hipEvent_t ev_site[2];
-  unsigned long long *d_next_site;      // work counter of the per-site kernel; the word after it counts the listed columns
+  unsigned long long *d_next_site;      // work counter of the per-site kernel; behind it the PCS_BUCKETS counts of listed columns
   unsigned *d_slow;             // columns left to the beam search
 };
 
@@ -312,7 +312,7 @@ static int pcs_ensure (pecall_dev * d, long n_sites, int indiv)
     {
       hipFree (d->d_sreads); hipFree (d->d_dom); hipFree (d->d_chromy); hipFree (d->d_call); hipFree (d->d_type);
       hipFree (d->d_npass); hipFree (d->d_post); hipFree (d->d_ac); hipFree (d->d_den); hipFree (d->d_slow);
-      PCCHK (d, hipMalloc ((void **) &d->d_slow, n_sites * sizeof (unsigned)));
+      PCCHK (d, hipMalloc ((void **) &d->d_slow, (size_t) PCS_BUCKETS * n_sites * sizeof (unsigned)));
       PCCHK (d, hipMalloc ((void **) &d->d_sreads, items * PCS_NA * sizeof (uint16_t)));
       PCCHK (d, hipMalloc ((void **) &d->d_dom, n_sites));
       PCCHK (d, hipMalloc ((void **) &d->d_chromy, n_sites));
@@ -514,10 +514,10 @@ extern "C" int pecall_dev_sites_run (pecall_dev * d, int haploid, double thresho
     }
   if (!d->d_next_site)
     {
-      PCCHK (d, hipMalloc ((void **) &d->d_next_site, 2 * sizeof (unsigned long long)));
+      PCCHK (d, hipMalloc ((void **) &d->d_next_site, 4 * sizeof (unsigned long long)));
       PCCHK (d, hipFuncSetAttribute ((const void *) pcs_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PCS_FAST_LDS_BYTES));
     }
-  PCCHK (d, hipMemsetAsync (d->d_next_site, 0, 2 * sizeof (unsigned long long), d->stream));
+  PCCHK (d, hipMemsetAsync (d->d_next_site, 0, 4 * sizeof (unsigned long long), d->stream));
   PCCHK (d, hipEventRecord (d->ev_site[0], d->stream));
   // the columns every sample agrees on are settled by pcs_fast_kernel; the rest, listed by it, go through the beam search
   unsigned *n_slow = (unsigned *) (d->d_next_site + 1);
@@ -533,6 +533,13 @@ extern "C" int pecall_dev_sites_run (pecall_dev * d, int haploid, double thresho
   PCCHK (d, hipStreamSynchronize (d->stream));
   if (kernel_ms)
     PCCHK (d, hipEventElapsedTime (kernel_ms, d->ev_site[0], d->ev_site[1]));
+  if (getenv ("PECALL_LIST_STATS"))
+    {
+      // how many columns the shortcut left to the beam search, by part of the list
+      unsigned c[PCS_BUCKETS];
+      if (hipMemcpy (c, n_slow, sizeof c, hipMemcpyDeviceToHost) == hipSuccess)
+        fprintf (stderr, "[pecall] %ld columns, listed for the beam by unsettled samples <3 / <8 / <20 / more: %u %u %u %u\n", n_sites, c[0], c[1], c[2], c[3]);
+    }
   return 0;
 }
 

@@ -552,6 +552,7 @@ __device__ int pcs_expand (const PcsPool & cur, PcsPool & nw, const PcsPool & bi
   return newcount;
 }
 
+#define PCS_BUCKETS 4           // parts of the list of columns left to the beam search (pcs_fast_kernel files, pcs_call_kernel walks them)
 // One wave per site.  Outputs are what the reference prints per row: call 0..13 or 14 (N), posterior,
 // site type (0 REF, 1 SNP, 2 DEL, 3 INS, 4 LOW, 5 MULTIALLELIC, 6 MESS; -1 = reference base not A/C/G/T, skipped),
 // Allele_Counts, passes.
@@ -571,10 +572,34 @@ __global__ __launch_bounds__ (64) void pcs_call_kernel (PcsParams P, const uint1
   // columns are handed out through a counter (the first grid-ful by block index): a column that needs the whole beam search
   // takes ~50 times as long as one settled by the shortcut below, so a fixed stride would leave most waves waiting for a few
   // (site_list: only the listed columns -- the ones pcs_fast_kernel could not settle)
-  const long n_iter = site_list ? (long) *n_list : n_sites;
+  // The list comes in PCS_BUCKETS parts of n_sites slots each, by the number of samples that disagreed with the shortcut (n_list[b]
+  // columns in part b): the parts are walked from the last -- the columns likely to hold the largest beams -- to the first, so
+  // that the launch does not end waiting for a heavy column that was handed out late.
+  long cnt[PCS_BUCKETS] = { 0, 0, 0, 0 };
+  long n_iter = n_sites;
+  if (site_list)
+    {
+      n_iter = 0;
+      for (int b = 0; b < PCS_BUCKETS; b++)
+        {
+          cnt[b] = (long) n_list[b];
+          n_iter += cnt[b];
+        }
+    }
   for (long it = blockIdx.x; it < n_iter; it = (long) gridDim.x + (long) __shfl ((long long) (lane == 0 ? atomicAdd (next_site, 1ull) : 0ull), 0))
     {
-      const long site = site_list ? (long) site_list[it] : it;
+      long site = it;
+      if (site_list)
+        {
+          long k = it;
+          int b = PCS_BUCKETS - 1;
+          while (b > 0 && k >= cnt[b])
+            {
+              k -= cnt[b];
+              b--;
+            }
+          site = (long) site_list[(size_t) b * (size_t) n_sites + (size_t) k];
+        }
       const int dom = dom_of[site];
       const int chrom = chrom_of[site] & 3;
       // bit 4: HAPLOID forced for this column (BED guide mode on chrY / chrMT, pecaller.c:955-957): only the initial allele
@@ -746,7 +771,39 @@ __global__ __launch_bounds__ (64) void pcs_call_kernel (PcsParams P, const uint1
             pcs_cfg_like (pool[ci], pool[ci].ord[i], sh, deep, N);
           pcs_sync ();
           total = pcs_clean (pool[ci], total, dom, ct, sh, deep, P, site_hap, lane);
-          for (int k = 0; k < N; k++)
+          // ---- the settled samples at the head of the order, in one go.  While the list is the single all-`dom` configuration, a
+          //      sample whose best genotype is `dom` by more than 2.31 nats leaves it that: pcs_expand prices the candidate `dom`
+          //      first (templ = (like - l_dom) + l_dom, prior 0: it is kept and becomes the list), and every other candidate has
+          //      templ <= that - 2.31 + rounding, which fails both acceptance tests (templ + 2.3 > best_post, templ + 0.01 >
+          //      best_like, pecaller.c:2628 / 2750); pcs_clean then finds the one homozygous configuration and changes nothing.  The
+          //      only thing that moves is the configuration's likelihood, by the rounding of that subtraction and addition: it is
+          //      replayed here sample by sample, in the same order, instead of a whole expansion + clean-up per sample (the samples
+          //      are ordered by margin, descending, so in a typical column all but the last one or two are of this kind).
+          int k_first = 0;
+          if (total == 1 && pool[ci].ord[0] == 0 && pool[ci].nall[0] == 1 && pool[ci].prior[0] == 0.0 && pool[ci].nden[0] == 0
+              && pool[ci].acount[dom] == (int16_t) (__popcll (deep) * (site_hap ? 1 : 2)))
+            {
+              const unsigned long long settled = __ballot (lane < N && tot > md && initial_call == dom && initial_p > 2.31);
+              while (k_first < N && ((settled >> sh.sord[k_first]) & 1ull))
+                k_first++;
+              if (k_first > 0)
+                {
+                  double L = pool[ci].like[0];
+                  for (int k = 0; k < k_first; k++)
+                    {
+                      const double l = sh.like[sh.sord[k]][dom];
+                      L = (L - l) + l;
+                    }
+                  pcs_sync ();
+                  if (lane == 0)
+                    {
+                      pool[ci].like[0] = L;
+                      pool[ci].post[0] = 0.0 + L;
+                    }
+                  pcs_sync ();
+                }
+            }
+          for (int k = k_first; k < N; k++)
             {
               const int ind = sh.sord[k];
               if ((deep >> ind) & 1ull)
@@ -1109,6 +1166,7 @@ __global__ __launch_bounds__ (PCS_FAST_BLOCK) void pcs_fast_kernel (PcsParams P,
       const int dom = dom_of[site];
       const int chrom = chrom_of[site] & 3;
       int decided = 1;          // 1: written here, 0: left to the beam
+      int n_unset = 0;          // samples the shortcut could not settle (left to the beam: a measure of its work)
       int my_call = PCS_NG, npass = 0, ac_dom = 0, type = 0;
       if (dom > 3)
         type = -1;              // the reference skips the column (pecaller.c:1208, 1718)
@@ -1182,7 +1240,10 @@ __global__ __launch_bounds__ (PCS_FAST_BLOCK) void pcs_fast_kernel (PcsParams P,
                     ac_dom = (int) __popcll (__ballot (deep)) * (P.haploid ? 1 : 2);
                 }
               else
-                decided = 0;
+                {
+                  decided = 0;
+                  n_unset = (int) __popcll (__ballot (!ok));
+                }
             }
         }
       if (decided)
@@ -1201,7 +1262,13 @@ __global__ __launch_bounds__ (PCS_FAST_BLOCK) void pcs_fast_kernel (PcsParams P,
               denovo_out[site] = 0;
             }
         }
-      else if (lane == 0)
-        slow_list[atomicAdd (n_slow, 1u)] = (unsigned) site;
+      else
+        {
+          // listed for the beam search, in the part of the list that goes with the number of samples that were not settled
+          const int ns = n_unset;
+          const int b = ns >= 20 ? 3 : ns >= 8 ? 2 : ns >= 3 ? 1 : 0;
+          if (lane == 0)
+            slow_list[(size_t) b * (size_t) n_sites + atomicAdd (&n_slow[b], 1u)] = (unsigned) site;
+        }
     }
 }
