@@ -23,6 +23,7 @@
 #include <stdint.h>
 #include <zlib.h>
 #include <pthread.h>
+#include <time.h>
 #include <unistd.h>
 #include "../../include/pemap_hip.h"
 #include "host_io.h"
@@ -183,6 +184,85 @@ lr_gets (lreader * r)
       pthread_cond_broadcast (&r->cv);
       pthread_mutex_unlock (&r->mu);
     }
+}
+
+/* ---- one mate file's share of a batch: the records of the reference's read loop (pemapper.c:649-748: the first record is the line
+        after the first line; after a sequence two lines are skipped, then lines up to one that starts with '@', and the line after it
+        is the next sequence), trimmed (pemapper_tsw.c:693-704), copied into the batch's rows.  The two mate files are scanned by two
+        threads side by side; the main loop takes the shorter of the two counts, as the reference's loop ends with the first file
+        that runs out. */
+typedef struct
+{
+  lreader *in;
+  char *rows;
+  int *lens;
+  int want;                     /* records to take at most */
+  int trim_s, trim_e;
+  int first_mate;               /* the `sl1 <= 12` end-of-input rule looks at the first mate only (pemapper.c:663) */
+  int started;                  /* the stream's first record has been taken */
+  int got;
+  int end;                      /* 0 the batch is full, 1 the stream ended, 2 a first-mate read of 12 bases or fewer, 3 a length out of range */
+  int bad_len;
+} fill_job;
+
+static void *
+fill_rows (void *arg)
+{
+  fill_job *j = (fill_job *) arg;
+  lreader *r = j->in;
+  j->got = 0;
+  j->end = 0;
+  while (j->got < j->want)
+    {
+      char *s;
+      if (!j->started)
+        {
+          lr_gets (r);
+          s = lr_gets (r);
+          j->started = 1;
+        }
+      else
+        {
+          lr_gets (r);
+          lr_gets (r);
+          s = lr_gets (r);
+          int not_there = 1;
+          while (s != NULL && not_there)
+            {
+              if (s[0] == '@')
+                not_there = 0;
+              s = lr_gets (r);
+            }
+          if (not_there)
+            s = NULL;
+        }
+      if (s == NULL)
+        {
+          j->end = 1;
+          break;
+        }
+      const int full = (int) strlen (s);
+      int sl = full - j->trim_s;
+      s += (sl >= 0) ? j->trim_s : full;
+      sl -= j->trim_e;
+      if (sl < 0)
+        sl = 0;
+      if (j->first_mate && sl <= 12)
+        {
+          j->end = 2;
+          break;
+        }
+      if (sl > PEMAP_MAX_READ || sl < PEMAP_MIN_READ)
+        {
+          j->end = 3;
+          j->bad_len = sl;
+          break;
+        }
+      memcpy (j->rows + (size_t) j->got * ROW_STRIDE, s, (size_t) sl);
+      j->lens[j->got] = sl;
+      j->got++;
+    }
+  return NULL;
 }
 
 /* find_chrom, pemapper.c:2168-2186, on the real (un-compressed) contig starts for the indel table (856) */
@@ -647,87 +727,65 @@ main (int argc, char *argv[])
         lr_open (&in2, names2[iter]);
       size_t cap = 1 << 20, current_read = 0;
       uint32_t *maps1 = (uint32_t *) calloc (cap, sizeof (uint32_t)), *maps2 = paired ? (uint32_t *) calloc (cap, sizeof (uint32_t)) : NULL;
-      /* first record: header line, then the sequence (pemapper.c:649-656) */
-      char *s2 = NULL, *s1;
-      if (paired)
-        {
-          lr_gets (&in2);
-          s2 = lr_gets (&in2);
-        }
-      lr_gets (&in1);
-      s1 = lr_gets (&in1);
-      int not_done = (s1 != NULL) && (!paired || s2 != NULL);
+      struct timespec ts0, ts1;
+      clock_gettime (CLOCK_MONOTONIC, &ts0);
+      fill_job j1, j2;
+      memset (&j1, 0, sizeof j1);
+      memset (&j2, 0, sizeof j2);
+      j1.in = &in1;
+      j1.trim_s = trim_s;
+      j1.trim_e = trim_e;
+      j1.first_mate = 1;
+      j2 = j1;
+      j2.in = &in2;
+      j2.first_mate = 0;
+      int not_done = 1;
       int nb = 0;
       printf ("\n Ready to map \n");
       while (not_done)
         {
-          /* trimming, pemapper_tsw.c:693-704 */
-          int sl1 = (int) strlen (s1) - trim_s;
-          s1 += (sl1 >= 0) ? trim_s : (int) strlen (s1);
-          sl1 = sl1 - trim_e;
-          if (sl1 < 0)
-            sl1 = 0;
-          int sl2 = 0;
+          long want = BATCH_PAIRS;
+          if ((long) current_read + want > max_reads)
+            want = max_reads - (long) current_read;
+          j1.rows = r1;
+          j1.lens = l1;
+          j1.want = (int) want;
+          j2.rows = r2;
+          j2.lens = l2;
+          j2.want = (int) want;
+          pthread_t t2;
+          int threaded = 0;
+          if (paired)
+            threaded = pthread_create (&t2, NULL, fill_rows, &j2) == 0;
+          fill_rows (&j1);
           if (paired)
             {
-              sl2 = (int) strlen (s2) - trim_s;
-              s2 += (sl2 >= 0) ? trim_s : (int) strlen (s2);
-              sl2 = sl2 - trim_e;
-              if (sl2 < 0)
-                sl2 = 0;
+              if (threaded)
+                pthread_join (t2, NULL);
+              else
+                fill_rows (&j2);
             }
-          if (sl1 <= 12)
-            break;              /* pemapper.c:663 */
-          if (sl1 > PEMAP_MAX_READ || sl1 < PEMAP_MIN_READ || (paired && (sl2 > PEMAP_MAX_READ || sl2 < PEMAP_MIN_READ)))
+          /* the reference's loop checks the first mate's length for the end-of-input rule before either length for the range, and
+             stops at the first record either file cannot supply */
+          nb = j1.got;
+          if (paired && j2.got < nb)
+            nb = j2.got;
+          if (j1.end == 3 && j1.got == nb)
             {
-              printf ("\n Read %ld of %s has length %d/%d: supported range is %d..%d \n", (long) current_read, names1[iter], sl1, sl2,
-                      PEMAP_MIN_READ, PEMAP_MAX_READ);
+              printf ("\n Read %ld of %s has length %d: supported range is %d..%d \n", (long) current_read + nb, names1[iter], j1.bad_len, PEMAP_MIN_READ,
+                      PEMAP_MAX_READ);
               exit (1);
             }
-          memcpy (r1 + (size_t) nb * ROW_STRIDE, s1, (size_t) sl1);
-          l1[nb] = sl1;
-          if (paired)
+          if (paired && j2.end == 3 && j2.got == nb && !(j1.end == 2 && j1.got == nb))
             {
-              memcpy (r2 + (size_t) nb * ROW_STRIDE, s2, (size_t) sl2);
-              l2[nb] = sl2;
+              printf ("\n Read %ld of %s has length %d: supported range is %d..%d \n", (long) current_read + nb, names2[iter], j2.bad_len, PEMAP_MIN_READ,
+                      PEMAP_MAX_READ);
+              exit (1);
             }
-          nb++;
-          current_read++;
-          if ((long) current_read >= max_reads)
+          current_read += (size_t) nb;
+          if (nb < want || (long) current_read >= max_reads)
             not_done = 0;
-          else
-            {
-              /* skip two lines, then scan to the next line that starts with '@'; the line after it is the sequence
-                 (pemapper.c:713-748) */
-              lr_gets (&in1);
-              lr_gets (&in1);
-              s1 = lr_gets (&in1);
-              int not_there = 1;
-              while (s1 != NULL && not_there)
-                {
-                  if (s1[0] == '@')
-                    not_there = 0;
-                  s1 = lr_gets (&in1);
-                }
-              if (not_there || s1 == NULL)
-                not_done = 0;
-              if (paired && not_done)
-                {
-                  not_there = 1;
-                  lr_gets (&in2);
-                  lr_gets (&in2);
-                  s2 = lr_gets (&in2);
-                  while (s2 != NULL && not_there)
-                    {
-                      if (s2[0] == '@')
-                        not_there = 0;
-                      s2 = lr_gets (&in2);
-                    }
-                  if (not_there || s2 == NULL)
-                    not_done = 0;
-                }
-            }
-          if (nb == BATCH_PAIRS || !not_done)
+          if (nb > 0)
             {
               if (current_read > cap)
                 {
@@ -775,6 +833,12 @@ main (int argc, char *argv[])
           ck (dev, pemap_dev_map_batch (dev, r1, l1, r2, l2, nb, ROW_STRIDE, maps1 + (current_read - (size_t) nb),
                                         paired ? maps2 + (current_read - (size_t) nb) : NULL, mt));
         }
+      clock_gettime (CLOCK_MONOTONIC, &ts1);
+      {
+        const double sec = (double) (ts1.tv_sec - ts0.tv_sec) + 1e-9 * (double) (ts1.tv_nsec - ts0.tv_nsec);
+        printf ("\n pemapper_hip: %ld %s read and mapped in %.3f s (%.2f M reads/s, input parsing included) \n", (long) current_read,
+                paired ? "pairs" : "reads", sec, (paired ? 2.0 : 1.0) * (double) current_read / (sec > 0 ? sec : 1) / 1e6);
+      }
       printf ("\n Made it out alive, and have started cleanup \n\n");
       snprintf (path, sizeof path, "%s.mfile", names1[iter]);
       FILE *m = fopen (path, "wb");

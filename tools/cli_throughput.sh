@@ -1,6 +1,8 @@
 #!/bin/bash
-# wall-clock rate of the host program on 1 M pairs (the 20 k-pair fixture concatenated 50 times: gz members concatenate)
+# wall-clock rate of the host program pemapper_hip on N x 20 k pairs (the golden fixture concatenated: gz members concatenate), from
+# gz input and from the same reads as plain text.   tools/cli_throughput.sh [copies=100]
 set -e
+N=${1:-100}
 ROOT=$(pwd); W=$(mktemp -d); cd $W
 cp $ROOT/tests/golden/g1.sdx .
 python3 - <<PY
@@ -10,12 +12,17 @@ import refio, numpy as np
 _, seqs = refio.read_fasta("$ROOT/tests/golden/g1.fa.gz")
 gzip.open("g1.seq", "wb", compresslevel=1).write(np.concatenate(seqs).tobytes())
 PY
-for k in 1 2; do for i in $(seq 50); do cat $ROOT/tests/golden/g1_${k}_.fastq.gz; done > big_${k}_.fastq.gz; done
-ls -la big_1_.fastq.gz | awk '{print "fastq.gz bytes per mate file:", $5}'
-T0=$(date +%s.%N)
-$ROOT/pecaller_amd/pemapper_hip out g1.sdx p big_1_.fastq.gz big_2_.fastq.gz 500 0 N 0.85 24 200000000 > log.txt 2>&1 || { tail -3 log.txt; exit 1; }
-T1=$(date +%s.%N)
-python3 -c "print('wall %.2f s' % ($T1 - $T0))"
-python3 -c "
-import os; n=os.path.getsize('big_1_.fastq.gz.mfile')//4; print('pairs', n)"
+for k in 1 2; do for i in $(seq $N); do cat $ROOT/tests/golden/g1_${k}_.fastq.gz; done > big_${k}_.fastq.gz; gzip -dc big_${k}_.fastq.gz > plain_${k}_.fastq; done
+ls -la big_1_.fastq.gz plain_1_.fastq | awk '{print "bytes per mate file:", $5, $9}'
+cat plain_1_.fastq plain_2_.fastq > /dev/null     # (page cache: the plain files were written a moment ago)
+for kind in big plain plain; do
+  sfx=fastq.gz; [ $kind = plain ] && sfx=fastq
+  T0=$(date +%s.%N)
+  $ROOT/pecaller_amd/pemapper_hip out_$kind g1.sdx p ${kind}_1_.$sfx ${kind}_2_.$sfx 500 0 N 0.85 24 2000000000 > log_$kind.txt 2>&1 || { tail -3 log_$kind.txt; exit 1; }
+  T1=$(date +%s.%N)
+  grep "read and mapped" log_$kind.txt
+  python3 -c "
+import os; n=os.path.getsize('${kind}_1_.$sfx.mfile')//4; w=$T1-$T0; print('$kind input: pairs', n, 'wall %.2f s' % w, '= %.2f M reads/s end to end (start-up, index build of the 5 Mbp fixture genome and output included)' % (2*n/w/1e6))"
+done
+cmp out_big.pileup.gz out_plain.pileup.gz > /dev/null 2>&1 && echo "pileups of the two runs: identical bytes" || { gzip -dc out_big.pileup.gz | md5sum; gzip -dc out_plain.pileup.gz | md5sum; }
 cd /; rm -rf $W
