@@ -395,7 +395,7 @@ def pmc_traffic(kernel, gsize, B, L):
     MI355X_MICROARCH.md applies to coalesced streams)."""
     if not (gsize == 3100000000 and B == 1000000 and L == 150):
         return None, None
-    for name in ("r02_bench_pmc.json",):
+    for name in ("r02_bench_pmc_final.json", "r02_bench_pmc.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             pm = json.load(open(path))
