@@ -1384,7 +1384,7 @@ static int absorb_run (pemap_dev * d)
 #ifdef PEMAP_TIMING_PROBES
   {
     // the fused seed kernel's phase probes (pemap_seed3.hip.h): cycles summed over waves, printed per run
-    unsigned long long pr[16], z[16] = { 0ull };
+    unsigned long long pr[20], z[20] = { 0ull };
     if (hipMemcpyFromSymbol (pr, HIP_SYMBOL (pm_s3_probe), sizeof pr) == hipSuccess)
       {
         unsigned long long tot = 0;
@@ -1396,7 +1396,7 @@ static int absorb_run (pemap_dev * d)
             fprintf (stderr, "[pm_s3_probe]");
             for (int i = 0; i < 16; i++)
               fprintf (stderr, " %s %.1f%%", nm[i], 100.0 * (double) pr[i] / (double) tot);
-            fprintf (stderr, " | total %.3f G wave-cycles\n", (double) tot / 1e9);
+            fprintf (stderr, " | total %.3f G wave-cycles | segments %llu, dropped for a too-many bucket %llu, of them by the k-mer's own bucket %llu\n", (double) tot / 1e9, pr[16], pr[17], pr[18]);
           }
         (void) hipMemcpyToSymbol (HIP_SYMBOL (pm_s3_probe), z, sizeof z);
       }

@@ -151,7 +151,7 @@ extern __shared__ __align__ (16) uint8_t pm_seed3_lds[];
 // Cycle probes of the kernel's phases (a library built with -DPEMAP_TIMING_PROBES only): per wave the core-clock cycles between
 // the marks below, summed over the grid into pm_s3_probe[]; pemap_capi.hip prints and clears them after every run.
 #ifdef PEMAP_TIMING_PROBES
-__device__ unsigned long long pm_s3_probe[16];
+__device__ unsigned long long pm_s3_probe[20];      // 16 phases; 16..18: segments decoded, dropped (a too-many bucket), dropped by the k-mer's own bucket
 #define PM_S3_T(i) do { const unsigned long long t_ = __builtin_readcyclecounter (); pacc[i] += t_ - plast; plast = t_; } while (0)
 #else
 #define PM_S3_T(i) do { } while (0)
@@ -309,7 +309,7 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
     e_out = -1;
   };
 #ifdef PEMAP_TIMING_PROBES
-  unsigned long long pacc[16] = { 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull };
+  unsigned long long pacc[20] = { 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull };
   unsigned long long plast = __builtin_readcyclecounter ();
 #endif
   while (eQ < n_ends)
@@ -367,6 +367,14 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
                 const uint32_t ent = ent_next;
                 if (seg + 1 < S)
                   ent_next = entry_of (sg + 1);         // (its LDS read flies while this segment is filed)
+#ifdef PEMAP_TIMING_PROBES
+                {
+                  const unsigned long long tm_ = __ballot (ent == 0xFFFFFFFEu);
+                  pacc[16] += 1ull;
+                  pacc[17] += tm_ != 0ull;
+                  pacc[18] += (tm_ & 1ull) != 0ull;
+                }
+#endif
                 if (__ballot (ent == 0xFFFFFFFEu) != 0ull)
                   continue;
                 const bool single = ent < multi_base, multi = ent >= multi_base && ent != 0xFFFFFFFFu;
@@ -953,7 +961,7 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
   flush_out ();
 #ifdef PEMAP_TIMING_PROBES
   if (lane == 0)
-    for (int i = 0; i < 16; i++)
+    for (int i = 0; i < 20; i++)
       atomicAdd (&pm_s3_probe[i], pacc[i]);
 #endif
   if (lane == 0 && n_pos)

@@ -75,6 +75,37 @@ def test_cli_array_mode_and_max_reads(tmp_path):
     assert r.returncode == 1 and b"Max_threads" in r.stdout
 
 
+def test_cli_plain_text_input_and_uneven_mate_files(tmp_path):
+    """the two mate files are scanned by two threads (fill_rows): plain-text fastq gives the files the gz input gives (gzopen reads
+    both, pemapper.c:626); a second mate file that ends early ends the run at its last record, as the reference's loop does
+    (pemapper.c:739-748); a first-mate read of 12 bases or fewer ends it there (663); text between records that does not start
+    with '@' is skipped by the scan for the next header (722-733)"""
+    sdx = _prep(tmp_path)
+    g1, g2 = (gzip.open(os.path.join(fixtures.GOLD, "g1_%d_.fastq.gz" % k)).read() for k in (1, 2))
+    f1, f2 = str(tmp_path / "p_1_.fastq"), str(tmp_path / "p_2_.fastq")
+    open(f1, "wb").write(g1)
+    open(f2, "wb").write(g2)
+    out = str(tmp_path / "outp")
+    log = subprocess.check_output([EXE, out, sdx, "p", f1, f2, "500", "0", "N", "0.85", "8", "200000000"])
+    assert b"read and mapped in" in log
+    _compare("r150", out, f1, f2)
+    # second mate file cut after 7,000 records, junk lines between two records of the first, a short first-mate read at record 9,000
+    l1, l2 = g1.split(b"\n"), g2.split(b"\n")
+    l1[4 * 100:4 * 100] = [b"junk line", b"+another"]
+    cut = l1[:]
+    cut[4 * 9000 + 1 + 2] = b"ACGTACGTACGT"            # (+ 2: the junk lines shifted everything behind record 100)
+    for tag, a, b, n in (("e", l1, l2[:4 * 7000], 7000), ("s", cut, l2, 9000)):
+        fa, fb = str(tmp_path / (tag + "_1_.fastq")), str(tmp_path / (tag + "_2_.fastq"))
+        open(fa, "wb").write(b"\n".join(a))
+        open(fb, "wb").write(b"\n".join(b) + (b"\n" if tag == "e" else b""))
+        subprocess.check_call([EXE, str(tmp_path / ("out" + tag)), sdx, "p", fa, fb, "500", "0", "N", "0.85", "8", "200000000"],
+                              stdout=subprocess.DEVNULL)
+        m1, m2 = np.fromfile(fa + ".mfile", dtype="<u4"), np.fromfile(fb + ".mfile", dtype="<u4")
+        assert len(m1) == n and len(m2) == n, (tag, len(m1), len(m2))
+        # every pair is mapped on its own (no state between pairs): the first n coordinates are the full run's
+        assert np.array_equal(m1, fixtures.golden_m("r150", 1)[:n]) and np.array_equal(m2, fixtures.golden_m("r150", 2)[:n])
+
+
 def test_index_builder_cli_writes_reference_files(tmp_path):
     """index_genome_hip: the reference builder's dialogue on stdin, its four files out (.sdx text, .seq letters, .mdx, .idx)"""
     exe = os.path.join(ROOT, "pecaller_amd", "index_genome_hip")
