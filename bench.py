@@ -322,14 +322,16 @@ def main():
     # ---- end of the run: the per-GPU pileup partials are summed (the reference's one shared all_base_list, pemapper.c:156)
     if world > 1:
         cnt = pd.device_tensor(torch, dev, 4)
-        local = cnt.sum(dtype=torch.int64).reshape(1)
+        def grand_total(t):       # of the 16-bit counters, two to a word
+            return (t & 0xFFFF).sum(dtype=torch.int64) + ((t >> 16) & 0xFFFF).sum(dtype=torch.int64)
+        local = grand_total(cnt).reshape(1)
         tot = local.clone() if on_gpu else local.cpu()
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         barrier()
         t0 = time.perf_counter()
         pd.reduce_pileup(dist, cnt)
         timings["pileup_reduce_s"] = allmax(time.perf_counter() - t0)
-        after = int(cnt.sum(dtype=torch.int64).item())
+        after = int(grand_total(cnt).item())
         # every rank now holds the sum: the grand total of the counters equals the sum of the ranks' totals before
         assert after == int(tot.item()), (after, int(tot.item()))
         timings["pileup_reduce_checked_total"] = after

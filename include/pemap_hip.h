@@ -90,7 +90,8 @@ int pemap_dev_set_lookup_replicas (pemap_dev * dev, int n);
 int pemap_dev_lookup_replicas (pemap_dev * dev, int *n_replicas, uint64_t * record_bytes);
 
 /* Device pointers and sizes of the resident arrays: which = 0 pos_index (u32[2^32+1]), 1 mers (u32[n_mers]),
- * 2 genome (u8[genome_size]), 3 contig_starts (u32[n_contigs+1]), 4 pileup counters (u32[genome_size][6]),
+ * 2 genome (u8[genome_size]), 3 contig_starts (u32[n_contigs+1]), 4 pileup counters (six planes A C G T Del Ins of 16-bit
+ * wrapping counters, two positions to a 32-bit word, each plane padded to 256-byte blocks: n_bytes / 6 bytes per plane),
  * 5 the look-up replicas (u32[8][2^32]; replica p holds the entry of k-mer k at k with its 4-bit fields 0 and p
  * swapped), 6 the records of the multi-position buckets (16-byte units {count, positions...}); 5 and 6 are empty
  * (n_bytes = 0) when no replicas are in use.

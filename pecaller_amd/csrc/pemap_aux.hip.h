@@ -450,13 +450,17 @@ __global__ __launch_bounds__ (256) void ix_rep_permute_kernel (const uint32_t * 
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Pileup export (the final genome walk, pemapper.c:828-843): u32 device counters -> the reference's u16 columns.
+// Pileup export (the final genome walk, pemapper.c:828-843): the device's counter planes (PmPile) -> the reference's u16 columns.
 // ------------------------------------------------------------------------------------------------------------
-__global__ void pile_to_u16_kernel (const uint32_t * counts, uint64_t n_words, uint16_t * out)
+// out[(pos - first) * 6 + col] for `count` positions from `first`: the planes transposed back to the reference's six columns per position
+__global__ void pile_to_u16_kernel (PmPile counts, uint64_t first, uint64_t count, uint16_t * out)
 {
   uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_words)
-    out[i] = (uint16_t) counts[i];
+  if (i < count * 6)
+    {
+      const uint64_t pos = i / 6;
+      out[i] = pm_pile_get (counts, first + pos, (int) (i - pos * 6));
+    }
 }
 
 struct __attribute__ ((packed)) PileRec
@@ -467,18 +471,18 @@ struct __attribute__ ((packed)) PileRec
 
 // ordered compaction of the non-zero sites of [first, first+count): tile counts, scan, emit
 #define PR_BLOCK 256
-__device__ __forceinline__ bool pile_nonzero (const uint32_t * counts, uint64_t p, uint16_t * c)
+__device__ __forceinline__ bool pile_nonzero (const PmPile & counts, uint64_t p, uint16_t * c)
 {
   unsigned tot = 0;
   for (int k = 0; k < 6; k++)
     {
-      c[k] = (uint16_t) counts[p * 6 + k];
+      c[k] = pm_pile_get (counts, p, k);
       tot += c[k];              // int sum of the six u16 columns, pemapper.c:829-831
     }
   return tot > 0;
 }
 
-__global__ __launch_bounds__ (PR_BLOCK) void pile_count_kernel (const uint32_t * counts, uint64_t first, uint64_t count,
+__global__ __launch_bounds__ (PR_BLOCK) void pile_count_kernel (PmPile counts, uint64_t first, uint64_t count,
                                                                 uint32_t * tile_count)
 {
   __shared__ unsigned s_cnt;
@@ -495,7 +499,7 @@ __global__ __launch_bounds__ (PR_BLOCK) void pile_count_kernel (const uint32_t *
     tile_count[blockIdx.x] = s_cnt;
 }
 
-__global__ __launch_bounds__ (PR_BLOCK) void pile_emit_kernel (const uint32_t * counts, uint64_t first, uint64_t count,
+__global__ __launch_bounds__ (PR_BLOCK) void pile_emit_kernel (PmPile counts, uint64_t first, uint64_t count,
                                                                const uint64_t * tile_offset, PileRec * out, uint64_t cap)
 {
   __shared__ unsigned s_wave[PR_BLOCK / 64];

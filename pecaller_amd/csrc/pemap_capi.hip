@@ -150,7 +150,8 @@ struct pemap_dev
   uint64_t n_mers, gsize;
   int n_contigs, idepth;
   bool index_ready;
-  uint32_t *d_counts;           // [gsize][6]
+  uint32_t *d_counts;           // the pileup counter planes (PmPile): 6 planes of pile_plane_words words
+  size_t pile_plane_words;
   // params
   int paired, min_dist, max_dist, bisulfite;
   double min_align;
@@ -218,6 +219,14 @@ struct pemap_dev
   std::vector < uint8_t > h_ins;        // host copy of all insertion-log bytes so far
   long summary[13];
 };
+
+static inline PmPile pile_of (const pemap_dev * d)
+{
+  PmPile p;
+  p.w = d->d_counts;
+  p.plane_words = d->pile_plane_words;
+  return p;
+}
 
 static int fail (pemap_dev * d, const char *fmt, ...)
 {
@@ -535,9 +544,11 @@ extern "C" int pemap_dev_index_alloc (pemap_dev * d, uint64_t n_mers, uint64_t g
   HIPCHK (d, hipMemset (d->d_genome_alloc, 0, 256));
   d->d_genome = d->d_genome_alloc + 256;
   TRY (dev_alloc (d, &d->d_contig_starts, (size_t) n_contigs + 2));
-  TRY (dev_alloc (d, &d->d_counts, genome_size * 6 + 6));
+  // (a plane is a whole number of 256-byte blocks: planes start line-aligned)
+  d->pile_plane_words = (((size_t) genome_size + 2) / 2 + 63) & ~(size_t) 63;
+  TRY (dev_alloc (d, &d->d_counts, 6 * d->pile_plane_words));
   HIPCHK (d, hipMemset (d->d_genome + genome_size, 0, 512));
-  HIPCHK (d, hipMemset (d->d_counts, 0, (genome_size * 6 + 6) * sizeof (uint32_t)));
+  HIPCHK (d, hipMemset (d->d_counts, 0, 6 * d->pile_plane_words * sizeof (uint32_t)));
   return 0;
 }
 
@@ -808,7 +819,7 @@ extern "C" int pemap_dev_buffer (pemap_dev * d, int which, void **d_ptr, uint64_
     case 1: *d_ptr = d->d_mers; *n_bytes = d->n_mers * 4; break;
     case 2: *d_ptr = d->d_genome; *n_bytes = d->gsize; break;
     case 3: *d_ptr = d->d_contig_starts; *n_bytes = ((uint64_t) d->n_contigs + 1) * 4; break;
-    case 4: *d_ptr = d->d_counts; *n_bytes = d->gsize * 6 * 4; break;
+    case 4: *d_ptr = d->d_counts; *n_bytes = 6 * d->pile_plane_words * 4; break;
     case 5: *d_ptr = d->d_rep; *n_bytes = d->n_rep ? 8ull * (1ull << 32) * 4ull : 0ull; break;
     case 6: *d_ptr = d->d_multi; *n_bytes = d->n_rep ? d->multi_units * 16ull : 0ull; break;
     default: return fail (d, "buffer: which = %d", which);
@@ -1359,14 +1370,14 @@ template < int W, int LPA > static void launch_chunk (pemap_dev * d, const RunCt
   unsigned long long *path = set2 ? d->d_path2 : d->d_path;
   uint16_t *nsteps = set2 ? d->d_nsteps2 : d->d_nsteps;
   hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_walk_kernel < W, LPA >), dim3 (wgrid), dim3 (256), 0, ws, c.b, H, wins, ctr, d->d_cur,
-                      dirbuf, c.tstride, d->d_counts, d->d_ins_log, d->ins_cap, path, d->path_words, nsteps);
+                      dirbuf, c.tstride, pile_of (d), d->d_ins_log, d->ins_cap, path, d->path_words, nsteps);
   {
     // one wave per winning alignment applies the recorded steps to the pileup
     const int pbp = d->kn.pile_blocks_per_cu;
     int pgrid = (n_ends + 3) / 4;
     if (pgrid > d->n_cus * pbp)
       pgrid = d->n_cus * pbp;
-    hipLaunchKernelGGL (pm_pile_kernel, dim3 (pgrid), dim3 (256), 0, ws, c.b, H, wins, ctr, d->d_counts, path, d->path_words, nsteps);
+    hipLaunchKernelGGL (pm_pile_kernel, dim3 (pgrid), dim3 (256), 0, ws, c.b, H, wins, ctr, pile_of (d), path, d->path_words, nsteps);
   }
   hipEventRecord (ev[8], ws);
   if (split)
@@ -2312,7 +2323,7 @@ extern "C" int pemap_dev_reset_pileup (pemap_dev * d)
   if (!d->d_counts)
     return fail (d, "reset_pileup: no index");
   HIPCHK (d, hipStreamSynchronize (d->stream));
-  HIPCHK (d, hipMemset (d->d_counts, 0, (d->gsize * 6 + 6) * sizeof (uint32_t)));
+  HIPCHK (d, hipMemset (d->d_counts, 0, 6 * d->pile_plane_words * sizeof (uint32_t)));
   HIPCHK (d, hipMemset (d->d_cur, 0, sizeof (PmInsCursor)));
   d->h_ins.clear ();
   memset (d->summary, 0, sizeof (d->summary));
@@ -2328,16 +2339,15 @@ extern "C" int pemap_dev_fetch_pileup (pemap_dev * d, uint16_t * counts, pemap_i
   TRY (drain_ins (d));
   if (counts)
     {
-      const uint64_t n_words = d->gsize * 6;
-      const uint64_t chunk = 1ull << 28;
+      const uint64_t chunk = 48ull << 20;       // positions per round (6 counters each)
       uint16_t *d_tmp = nullptr;
-      TRY (dev_alloc (d, &d_tmp, (size_t) (n_words < chunk ? n_words : chunk)));
-      for (uint64_t o = 0; o < n_words; o += chunk)
+      TRY (dev_alloc (d, &d_tmp, (size_t) (d->gsize < chunk ? d->gsize : chunk) * 6));
+      for (uint64_t o = 0; o < d->gsize; o += chunk)
         {
-          uint64_t m = n_words - o < chunk ? n_words - o : chunk;
-          hipLaunchKernelGGL (pile_to_u16_kernel, dim3 ((unsigned) ((m + 255) / 256)), dim3 (256), 0, d->stream, d->d_counts + o, m, d_tmp);
+          const uint64_t m = d->gsize - o < chunk ? d->gsize - o : chunk;
+          hipLaunchKernelGGL (pile_to_u16_kernel, dim3 ((unsigned) ((m * 6 + 255) / 256)), dim3 (256), 0, d->stream, pile_of (d), o, m, d_tmp);
           HIPCHK (d, hipStreamSynchronize (d->stream));
-          HIPCHK (d, hipMemcpy (counts + o, d_tmp, m * sizeof (uint16_t), hipMemcpyDeviceToHost));
+          HIPCHK (d, hipMemcpy (counts + o * 6, d_tmp, m * 6 * sizeof (uint16_t), hipMemcpyDeviceToHost));
         }
       hipFree (d_tmp);
     }
@@ -2384,7 +2394,7 @@ extern "C" int pemap_dev_fetch_records (pemap_dev * d, uint64_t first, uint64_t 
   TRY (dev_alloc (d, &d_tc, n_tiles));
   TRY (dev_alloc (d, &d_to, n_tiles));
   TRY (dev_alloc (d, &d_total, 1));
-  hipLaunchKernelGGL (pile_count_kernel, dim3 ((unsigned) n_tiles), dim3 (PR_BLOCK), 0, d->stream, d->d_counts, first, count, d_tc);
+  hipLaunchKernelGGL (pile_count_kernel, dim3 ((unsigned) n_tiles), dim3 (PR_BLOCK), 0, d->stream, pile_of (d), first, count, d_tc);
   hipLaunchKernelGGL (ix_scan_tiles_kernel, dim3 (1), dim3 (1024), 0, d->stream, d_tc, d_to, n_tiles, d_total);
   uint64_t total = 0;
   HIPCHK (d, hipMemcpyAsync (&total, d_total, 8, hipMemcpyDeviceToHost, d->stream));
@@ -2402,7 +2412,7 @@ extern "C" int pemap_dev_fetch_records (pemap_dev * d, uint64_t first, uint64_t 
           rc = dev_alloc (d, &d_out, (size_t) total);
           if (!rc)
             {
-              hipLaunchKernelGGL (pile_emit_kernel, dim3 ((unsigned) n_tiles), dim3 (PR_BLOCK), 0, d->stream, d->d_counts, first, count, d_to,
+              hipLaunchKernelGGL (pile_emit_kernel, dim3 ((unsigned) n_tiles), dim3 (PR_BLOCK), 0, d->stream, pile_of (d), first, count, d_to,
                                   d_out, total);
               if (hipStreamSynchronize (d->stream) != hipSuccess
                   || hipMemcpy (out, d_out, total * sizeof (PileRec), hipMemcpyDeviceToHost) != hipSuccess)

@@ -37,6 +37,36 @@ struct PmIndex
   int n_rep;
 };
 
+// The pileup counters (the reference's all_base_list: six unsigned short columns per genome position, pemapper.c:156, 1840-1870).
+// Plane-major, 16 bits each, two positions to a word: counter (pos, col) is half (pos & 1) of word col * plane_words + (pos >> 1).
+// A read's ~150 increments then fall into ~23 lines of 64 bytes (4 planes x 300 bytes) instead of 57 with six u32 counters per
+// position side by side -- and every touched line goes back to HBM once.  The arithmetic is the reference's: 16 bits, wrapping.
+// Both halves are incremented with 32-bit atomics; the high half wraps by itself, the low half's wrap would carry into its
+// neighbour, so increments of a low half return the old value and take the carry back when they see 0xFFFF.
+struct PmPile
+{
+  uint32_t *w;
+  size_t plane_words;
+};
+
+__device__ __forceinline__ void pm_pile_inc (const PmPile & p, size_t pos, int col)
+{
+  uint32_t *q = p.w + (size_t) col * p.plane_words + (pos >> 1);
+  if (pos & 1)
+    atomicAdd (q, 0x10000u);
+  else
+    {
+      const uint32_t old = atomicAdd (q, 1u);
+      if ((old & 0xFFFFu) == 0xFFFFu)
+        atomicSub (q, 0x10000u);
+    }
+}
+
+__device__ __forceinline__ uint16_t pm_pile_get (const PmPile & p, size_t pos, int col)
+{
+  return (uint16_t) (p.w[(size_t) col * p.plane_words + (pos >> 1)] >> (16 * (pos & 1)));
+}
+
 // counters shared by the kernels of one run (zeroed at the start of every run)
 struct PmCounters
 {

@@ -884,7 +884,7 @@ __device__ __forceinline__ void pm_log_insertion (uint8_t * ins_log, unsigned in
 
 template < int W, int PM_LPA > __global__ __launch_bounds__ (256) void pm_walk_kernel (PmBatch b, PmHits h, const uint32_t * wins, PmCounters * ctr,
                                                                            PmInsCursor * cur, const uint32_t * dirbuf, int tstride,
-                                                                           uint32_t * counts, uint8_t * ins_log, unsigned ins_cap,
+                                                                           PmPile counts, uint8_t * ins_log, unsigned ins_cap,
                                                                            unsigned long long *path, int path_words, uint16_t * n_steps)
 {
   constexpr int DW = PmSwGeom < W >::DW;
@@ -963,7 +963,7 @@ template < int W, int PM_LPA > __global__ __launch_bounds__ (256) void pm_walk_k
               if (ins_len > 0)
                 {
                   pm_log_insertion (ins_log, ins_cap, cur, gpos + (uint32_t) i1, read, mm, orient, j, ins_len);
-                  atomicAdd (&counts[((size_t) gpos + (size_t) i1) * 6 + 5], 1u);
+                  pm_pile_inc (counts, (size_t) gpos + (size_t) i1, 5);
                   incs++;
                   nins++;
                 }
@@ -981,7 +981,7 @@ template < int W, int PM_LPA > __global__ __launch_bounds__ (256) void pm_walk_k
       if (ins_len > 0 && i >= 1)    // pemapper.c:1918-1958: attached to base[i1] of the last step
         {
           pm_log_insertion (ins_log, ins_cap, cur, gpos + (uint32_t) i1, read, mm, orient, j, ins_len);
-          atomicAdd (&counts[((size_t) gpos + (size_t) i1) * 6 + 5], 1u);
+          pm_pile_inc (counts, (size_t) gpos + (size_t) i1, 5);
           incs++;
           nins++;
         }
@@ -993,7 +993,7 @@ template < int W, int PM_LPA > __global__ __launch_bounds__ (256) void pm_walk_k
 }
 
 // second half: the recorded steps of every alignment applied to the pileup (pemapper.c:1840-1870), one wave per alignment
-__global__ __launch_bounds__ (256) void pm_pile_kernel (PmBatch b, PmHits h, const uint32_t * wins, PmCounters * ctr, uint32_t * counts,
+__global__ __launch_bounds__ (256) void pm_pile_kernel (PmBatch b, PmHits h, const uint32_t * wins, PmCounters * ctr, PmPile counts,
                                                        const unsigned long long *path, int path_words, const uint16_t * n_steps)
 {
   const int lane = threadIdx.x & 63;
@@ -1025,12 +1025,12 @@ __global__ __launch_bounds__ (256) void pm_pile_kernel (PmBatch b, PmHits h, con
               const uint8_t ch = pm_oriented (read, mm, orient, jb - 1);
               const int slot = (ch == 'A') ? 0 : (ch == 'C') ? 1 : (ch == 'G') ? 2 : (ch == 'T') ? 3 : -1;       // pemapper.c:1850-1857
               if (slot >= 0)
-                atomicAdd (&counts[((size_t) gpos + (size_t) (ib - 1)) * 6 + slot], 1u);
+                pm_pile_inc (counts, (size_t) gpos + (size_t) (ib - 1), slot);
               incs += slot >= 0;
             }
           else if (code == 1)
             {
-              atomicAdd (&counts[((size_t) gpos + (size_t) (ib - 1)) * 6 + 4], 1u);
+              pm_pile_inc (counts, (size_t) gpos + (size_t) (ib - 1), 4);
               incs++;
             }
           i -= __popcll (mi);

@@ -3,9 +3,10 @@
 The path shards by reads: every rank holds a full index replica and its own pileup counters, nothing is exchanged
 while mapping.  Two collectives exist, both outside the timed loop:
   * broadcast_index: rank `src` loaded or built the index; the others receive pos_index / mers / genome / contig table;
-  * reduce_pileup:   element-wise sum of the u32 counters (the reference's shared all_base_list, pemapper.c:156).  The
-    reference's counters are unsigned short and wrap; sums are taken in 32 bits and truncated at the writer, which is the
-    same arithmetic (int32 two's-complement addition == uint32 addition).
+  * reduce_pileup:   sum of the counters over ranks (the reference's shared all_base_list, pemapper.c:156).  The
+    reference's counters are unsigned short and wrap; the device keeps them the same way, two 16-bit counters to a 32-bit
+    word (PmPile, pemap_kernels.hip.h).  The two halves of every word are summed separately in 32 bits and truncated to 16
+    when they are packed again: the arithmetic of one u16 counter that saw all ranks' increments.
 shard_range gives the contiguous slice of reads a rank maps; .mfile entries are concatenated in rank order.
 The tensors may live on the GPU (wrapping the device pointers of pemap_dev_buffer) or on the CPU (gloo tests).
 """
@@ -58,23 +59,46 @@ def broadcast_tensors(dist, tensors, src=0, chunk=1 << 28):
                 dist.broadcast(c, src=src)
 
 
-def reduce_pileup(dist, counts, dst=None, chunk=1 << 28):
-    """in-place sum of the int32-viewed counters over all ranks (all_reduce, or reduce to `dst`)"""
+def reduce_pileup(dist, counts, dst=None, chunk=1 << 27):
+    """in-place sum over all ranks (all_reduce, or reduce to `dst`) of the counters, an int32 view of words that hold two
+    16-bit counters each: the halves are summed apart and packed again modulo 2^16"""
     for c in _chunks(counts.view(-1), chunk):
         h = c.cpu() if _host_bounce(dist, c) else c
-        if dst is None:
-            dist.all_reduce(h, op=dist.ReduceOp.SUM)
-        else:
-            dist.reduce(h, dst=dst, op=dist.ReduceOp.SUM)
-        if h is not c:
-            c.copy_(h)
+        lo = h & 0xFFFF
+        hi = (h >> 16) & 0xFFFF
+        for part in (lo, hi):
+            if dst is None:
+                dist.all_reduce(part, op=dist.ReduceOp.SUM)
+            else:
+                dist.reduce(part, dst=dst, op=dist.ReduceOp.SUM)
+        lo &= 0xFFFF
+        hi &= 0xFFFF
+        # (hi << 16 in 32 bits: values of 0x8000 and more land in the sign bit, which is the bit pattern wanted)
+        packed = lo | (hi << 16)
+        c.copy_(packed)
     return counts
 
 
 def counts_to_u16(counts_i32):
-    """what the pileup writer does with the summed counters (numpy or torch int32 array)"""
+    """the 16-bit counters of the packed words, in memory order (numpy or torch int32 array)"""
     a = counts_i32.cpu().numpy() if hasattr(counts_i32, "cpu") else np.asarray(counts_i32)
-    return a.astype(np.uint32).astype(np.uint16)
+    return np.ascontiguousarray(a).view(np.uint16)
+
+
+def pack_counts(counts_u16):
+    """[positions][6] u16 columns -> the device's layout: six planes, two positions to a word, each plane padded to a whole number
+    of 256-byte blocks (pemap_capi.hip: pile_plane_words)"""
+    n = counts_u16.shape[0]
+    plane_words = ((n + 2) // 2 + 63) & ~63
+    out = np.zeros((6, 2 * plane_words), np.uint16)
+    out[:, :n] = np.asarray(counts_u16, np.uint16).T
+    return out.reshape(-1).view(np.int32)
+
+
+def unpack_counts(words_i32, n_positions):
+    """inverse of pack_counts"""
+    a = np.ascontiguousarray(words_i32).view(np.uint16).reshape(6, -1)
+    return np.ascontiguousarray(a[:, :n_positions].T)
 
 
 def merge_summaries(dist, torch, summary13):

@@ -43,13 +43,13 @@ def _worker(rank, world, port, q):
     lo, hi = pd.shard_range(N, rank, world)
     o = oracle_py.Oracle(mine, paired=True)
     m1, m2, mt, _, _ = o.map_batch(r1[lo:hi], l1[lo:hi], r2[lo:hi], l2[lo:hi], threads=2)
-    counts = torch.from_numpy(o.counts().astype(np.uint32).view(np.int32).copy())
+    counts = torch.from_numpy(pd.pack_counts(o.counts()).copy())
     pd.reduce_pileup(dist, counts, chunk=1 << 20)
     summ = pd.merge_summaries(dist, torch, o.summary())
     gathered = [None] * world
     dist.all_gather_object(gathered, (m1, m2, mt, o.insertions()))
     if rank == 0:
-        q.put((pd.counts_to_u16(counts), summ, gathered))
+        q.put((pd.unpack_counts(counts.numpy(), len(mine["genome"])), summ, gathered))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -80,11 +80,34 @@ def test_two_ranks_equal_one():
     assert np.array_equal(m1, fixtures.golden_m("r150", 1)[:N])
 
 
+class _OneRank:
+    """a stand-in for torch.distributed with one rank whose all_reduce adds a second rank's tensor (the halves arrive in the
+    order reduce_pileup sends them: low, high)"""
+
+    class ReduceOp:
+        SUM = 0
+
+    def __init__(self, other_lo, other_hi):
+        self.parts = [other_lo, other_hi]
+
+    def get_backend(self):
+        return "gloo"
+
+    def all_reduce(self, t, op=None):
+        t += self.parts.pop(0)
+
+
 def test_u16_wrap_survives_the_reduction():
-    """the reference's counters are unsigned short: partial sums in 32 bits, truncated once, wrap the same way"""
+    """the reference's counters are unsigned short: the device packs two to a word, the reduction sums the halves apart and
+    truncates once -- every counter wraps on its own, a low half's overflow does not reach its neighbour"""
+    import torch
     from pecaller_amd import dist as pd
-    a = np.array([65535, 40000, 1, 0], dtype=np.uint32)
-    b = np.array([1, 40000, 65535, 0], dtype=np.uint32)
-    s = (a.view(np.int32) + b.view(np.int32))
-    expect = ((a.astype(np.uint16).astype(np.uint32) + b.astype(np.uint16)) & 0xFFFF).astype(np.uint16)
-    assert np.array_equal(pd.counts_to_u16(s), expect)
+    a = np.array([[65535, 40000, 1, 0, 65535, 7], [1, 2, 3, 65535, 65535, 65535]], dtype=np.uint16)
+    b = np.array([[1, 40000, 65535, 0, 65535, 9], [65535, 0, 0, 1, 65535, 1]], dtype=np.uint16)
+    wa, wb = pd.pack_counts(a), pd.pack_counts(b)
+    t = torch.from_numpy(wa.copy())
+    tb = torch.from_numpy(wb.copy())
+    pd.reduce_pileup(_OneRank(tb & 0xFFFF, (tb >> 16) & 0xFFFF), t)
+    expect = ((a.astype(np.uint32) + b.astype(np.uint32)) & 0xFFFF).astype(np.uint16)
+    assert np.array_equal(pd.unpack_counts(t.numpy(), 2), expect)
+    assert np.array_equal(pd.unpack_counts(pd.pack_counts(a), 2), a)

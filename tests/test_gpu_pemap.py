@@ -317,6 +317,42 @@ print("alias ok")
     assert r.returncode == 0 and b"alias ok" in r.stdout, r.stdout[-2000:]
 
 
+def test_pileup_counters_wrap_like_unsigned_short():
+    """the device keeps the reference's unsigned short counters two to a 32-bit word (PmPile) and increments them with 32-bit
+    atomics: a low half that passes 65,535 must wrap to 0 WITHOUT carrying into the counter that shares its word.  The A counters
+    of the first 40,000 even positions start at 65,535 (words of plane 0 preset to 0x0000FFFF through the torch view of the
+    buffer), the reads are mapped, and every column must be the golden pileup modulo 2^16 -- the odd positions' A counters, in the
+    high halves of those words, exactly the golden."""
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, torch
+torch.cuda.set_device(0)
+import fixtures
+from pecaller_amd import PemapDev, dist as pd
+ix = fixtures.index()
+dev = PemapDev(0)
+dev.build_index(ix["genome"], ix["contig_len"])
+r1, l1, r2, l2 = fixtures.reads("r150")
+dev.set_params(paired=True, min_dist=0, max_dist=500, min_align=0.85)
+cnt = pd.device_tensor(torch, dev, 4)
+cnt[:20000] = 0xFFFF
+torch.cuda.synchronize()
+dev.map_batch(r1, l1, r2, l2)
+counts, _ = dev.fetch_pileup()
+bumped = counts[0:40000:2, 0].copy()
+assert (bumped != 65535).sum() > 2000          # the positions whose base is A and that a read covers (~3x coverage): those low halves did wrap
+counts[0:40000:2, 0] = (bumped.astype(np.uint32) + 1).astype(np.uint16)        # 65,535 + n = n - 1 modulo 2^16
+fixtures.check_pileup_against_golden("r150", counts)
+dev.close()
+print("wrap ok")
+'''
+    import os
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))]))
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0 and b"wrap ok" in r.stdout, r.stdout[-2000:]
+
+
 def test_gapless_rule_counts_and_can_be_switched_off(dev):
     """the gapless rule (pm_gapless_kernel) decides most alignments of the golden read set without the DP; its results are
     already pinned by the golden tests above -- here: it is in use, and the full-DP path (PEMAP_GAPLESS=0, a process of
