@@ -212,6 +212,22 @@ __device__ __forceinline__ uint32_t pm_neighbour (uint32_t k, int j)
   return (k & ~(3u << sh)) + (alt << sh);
 }
 
+// the look-up replicas (pemap_aux.hip.h): replica p holds the entry of k-mer k at k with its 4-bit fields 0 and p swapped
+__device__ __forceinline__ uint32_t pm_swap_fields (uint32_t k, int p)
+{
+  const unsigned sh = 4u * (unsigned) p;
+  const uint32_t f0 = k & 15u, fp = (k >> sh) & 15u;
+  return (k & ~(15u | (15u << sh))) | (f0 << sh) | fp;        // p = 0: k itself
+}
+
+// neighbour j of k-mer k through the replicas: the entry (0xFFFFFFFF empty, 0xFFFFFFFE too many, < multi_base the bucket's only
+// position, else the code of its record), read from the replica in which k and its neighbours at that pair of bases share a line
+__device__ __forceinline__ uint32_t pm_rep_entry (const PmIndex & ix, uint32_t k, int j)
+{
+  const int p = j > 0 ? (((j - 1) / 3) >> 1) & 7 : 0;
+  return ix.rep[((size_t) p << 32) + (size_t) pm_swap_fields (pm_neighbour (k, j), p)];
+}
+
 // s_setprio takes an immediate: wave issue priority 0 (default) .. 3 among the waves of a SIMD
 __device__ __forceinline__ void pm_set_prio (int p)
 {

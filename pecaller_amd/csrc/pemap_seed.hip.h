@@ -403,6 +403,41 @@ __global__ __launch_bounds__ (256) void pm_emit_kernel (PmIndex ix, PmBatch b, P
     }
 }
 
+// A look-up item (bucket) of the monolithic kernel: it_start / it_len, and the q-th position of its slice.  On the reference's
+// layout it_start indexes `mers`; through the replicas a bucket of one position carries it in it_start (it_len 1: records hold
+// 2..99), a longer one the word of its record's first position in `multi` (the record's count is read here: one dependent load).
+__device__ __forceinline__ void pm_item_of_entry (const PmIndex & ix, uint32_t ent, uint32_t & it_start, uint16_t & it_len)
+{
+  if (ent == 0xFFFFFFFFu)
+    {
+      it_start = 0;
+      it_len = 0;
+    }
+  else if (ent == 0xFFFFFFFEu)
+    {
+      it_start = 0;
+      it_len = 0xFFFF;
+    }
+  else if (ent < ix.multi_base)
+    {
+      it_start = ent;
+      it_len = 1;
+    }
+  else
+    {
+      const uint32_t w = (ent - ix.multi_base) * 4u;
+      it_start = w + 1u;
+      it_len = (uint16_t) ix.multi[w];
+    }
+}
+
+__device__ __forceinline__ uint32_t pm_item_pos (const PmIndex & ix, uint32_t it_start, uint16_t it_len, uint32_t q)
+{
+  if (ix.n_rep != 8)
+    return ix.mers[it_start + q];
+  return it_len == 1 ? it_start : ix.multi[it_start + q];
+}
+
 // Stage A of a read-end (software-pipelined one end ahead of the vote): the read and its reverse complement into LDS
 // buffer `buf`, the N filter, the segment offsets and 16-mers, and the 2 x S x 49 look-ups ISSUED into registers.
 // They complete while the workgroup votes on the previous end.
@@ -459,11 +494,20 @@ __device__ __forceinline__ void pm_seed_stage_a (SH & sh, const PmIndex & ix, co
       if (!skip && x < 2 * S * 49)
         {
           const int sg = x / 49, j = x - sg * 49;
-          const uint32_t nb = pm_neighbour (sh.kmer[buf][sg], j);
-          // one 8-byte gather for the pair (dword aligned), nothing depends on it until the commit one iteration later
-          const pm_u32x2 pr = *(const pm_u32x2 *) (ix.pos_index + nb);
-          v0[r] = pr.x;
-          v1[r] = pr.y;
+          if (ix.n_rep == 8)
+            {
+              // with the look-up replicas: the bucket's entry, 8 lines per segment instead of 43 (the record header follows at the
+              // commit)
+              v0[r] = pm_rep_entry (ix, sh.kmer[buf][sg], j);
+            }
+          else
+            {
+              const uint32_t nb = pm_neighbour (sh.kmer[buf][sg], j);
+              // one 8-byte gather for the pair (dword aligned), nothing depends on it until the commit one iteration later
+              const pm_u32x2 pr = *(const pm_u32x2 *) (ix.pos_index + nb);
+              v0[r] = pr.x;
+              v1[r] = pr.y;
+            }
         }
     }
 }
@@ -529,10 +573,15 @@ template < int SMAX > __global__ __launch_bounds__ (PM_SEED_THREADS, 4) void pm_
             {
               // the all-T k-mer's successor is entry 0: `which + 1` is evaluated in 32 bits (pemapper.c:2163)
               const int sg = x / 49, j = x - sg * 49;
-              const uint32_t nb = pm_neighbour (sh.kmer[buf][sg], j);
-              const uint32_t ln = ((nb == 0xFFFFFFFFu) ? pos_index_0 : v1[r]) - v0[r];
-              sh.u.it.it_start[x] = v0[r];
-              sh.u.it.it_len[x] = (ln >= PM_TOO_MANY) ? 0xFFFF : (uint16_t) ln;
+              if (ix.n_rep == 8)
+                pm_item_of_entry (ix, v0[r], sh.u.it.it_start[x], sh.u.it.it_len[x]);
+              else
+                {
+                  const uint32_t nb = pm_neighbour (sh.kmer[buf][sg], j);
+                  const uint32_t ln = ((nb == 0xFFFFFFFFu) ? pos_index_0 : v1[r]) - v0[r];
+                  sh.u.it.it_start[x] = v0[r];
+                  sh.u.it.it_len[x] = (ln >= PM_TOO_MANY) ? 0xFFFF : (uint16_t) ln;
+                }
             }
         }
       pm_lds_barrier ();
@@ -594,7 +643,7 @@ template < int SMAX > __global__ __launch_bounds__ (PM_SEED_THREADS, 4) void pm_
               else
                 hi = mid - 1;
             }
-          const uint32_t m = ix.mers[sh.u.it.it_start[x0 + lo] + (uint32_t) (q - (int) sh.u.it.it_off[x0 + lo])];
+          const uint32_t m = pm_item_pos (ix, sh.u.it.it_start[x0 + lo], sh.u.it.it_len[x0 + lo], (uint32_t) (q - (int) sh.u.it.it_off[x0 + lo]));
           sh.ekey[strand][p] = m + (uint32_t) (PM_DIAG_BIAS - sh.offsets[buf][seg]);
           sh.eseg[strand][p] = (uint8_t) seg;
         }
@@ -621,11 +670,16 @@ template < int SMAX > __global__ __launch_bounds__ (PM_SEED_THREADS, 4) void pm_
                   for (int x = tid; x < S * 49; x += PM_SEED_THREADS)
                     {
                       const int sg = strand * S + x / 49, j = x % 49;
-                      const uint32_t nb = pm_neighbour (sh.kmer[buf][sg], j);
-                      const uint32_t i0 = ix.pos_index[nb];
-                      const uint32_t ln = ix.pos_index[(uint32_t) (nb + 1u)] - i0;
-                      sh.u.it.it_start[strand * S * 49 + x] = i0;
-                      sh.u.it.it_len[strand * S * 49 + x] = (ln >= PM_TOO_MANY) ? 0xFFFF : (uint16_t) ln;
+                      if (ix.n_rep == 8)
+                        pm_item_of_entry (ix, pm_rep_entry (ix, sh.kmer[buf][sg], j), sh.u.it.it_start[strand * S * 49 + x], sh.u.it.it_len[strand * S * 49 + x]);
+                      else
+                        {
+                          const uint32_t nb = pm_neighbour (sh.kmer[buf][sg], j);
+                          const uint32_t i0 = ix.pos_index[nb];
+                          const uint32_t ln = ix.pos_index[(uint32_t) (nb + 1u)] - i0;
+                          sh.u.it.it_start[strand * S * 49 + x] = i0;
+                          sh.u.it.it_len[strand * S * 49 + x] = (ln >= PM_TOO_MANY) ? 0xFFFF : (uint16_t) ln;
+                        }
                     }
                   __syncthreads ();
                   if (tid < S)
@@ -656,7 +710,7 @@ template < int SMAX > __global__ __launch_bounds__ (PM_SEED_THREADS, 4) void pm_
                           else
                             hi = mid - 1;
                         }
-                      const uint32_t m = ix.mers[sh.u.it.it_start[x0 + lo] + (uint32_t) (q - (int) sh.u.it.it_off[x0 + lo])];
+                      const uint32_t m = pm_item_pos (ix, sh.u.it.it_start[x0 + lo], sh.u.it.it_len[x0 + lo], (uint32_t) (q - (int) sh.u.it.it_off[x0 + lo]));
                       g_key[p] = m + (uint32_t) (PM_DIAG_BIAS - sh.offsets[buf][seg]);
                       g_seg[p] = (uint8_t) seg;
                     }

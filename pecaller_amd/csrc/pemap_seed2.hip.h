@@ -442,13 +442,6 @@ template < int SMAX > struct __align__ (16) PmLookupRepShared
   uint8_t seq[2][320];
 };
 
-__device__ __forceinline__ uint32_t pm_swap_fields (uint32_t k, int p)
-{
-  const unsigned sh = 4u * (unsigned) p;
-  const uint32_t f0 = k & 15u, fp = (k >> sh) & 15u;
-  return (k & ~(15u | (15u << sh))) | (f0 << sh) | fp;        // p = 0: k itself
-}
-
 template < int SMAX, int PM_LR_BATCH, class SH >
 __device__ __forceinline__ void pm_lookup_rep_one_end (SH & sh, const PmIndex & ix, const PmBatch & b, const PmParams & prm, const PmLists & out, const int e,
                                                        const int lane, const int idepth, unsigned long long &n_pos)
