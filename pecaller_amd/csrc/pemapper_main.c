@@ -142,46 +142,64 @@ lr_close (lreader * r)
   free (r->buf);
 }
 
-/* next line without its '\n' (a '\r' stays, as in the reference), NULL at end of data */
+/* next line without its '\n' (a '\r' stays, as in the reference) and its length, NULL at end of data.  A line that lies inside one
+   block of the ring is returned where it is (valid until the next call); only a line that straddles blocks is put together in
+   r->buf.  (The reference's my_gzgets copies every line, pemapper.c:2447-2483.) */
 static char *
-lr_gets (lreader * r)
+lr_gets (lreader * r, size_t *len_out)
 {
+  size_t have = 0;              /* bytes of a straddling line collected in r->buf so far */
   for (;;)
     {
-      char *nl = (char *) memchr (r->buf + r->pos, '\n', r->len - r->pos);
-      if (nl)
+      if (r->pos < r->len)
         {
-          char *s = r->buf + r->pos;
-          *nl = '\0';
-          r->pos = (size_t) (nl - r->buf) + 1;
-          return s;
+          char *base = r->ring[r->head] + r->pos;
+          char *nl = (char *) memchr (base, '\n', r->len - r->pos);
+          const size_t n = nl ? (size_t) (nl - base) : r->len - r->pos;
+          if (nl && have == 0)
+            {
+              *nl = '\0';
+              r->pos += n + 1;
+              if (len_out)
+                *len_out = n;
+              return base;
+            }
+          if (have + n + 1 > r->cap)
+            {
+              r->cap = 2 * (have + n + 1);
+              r->buf = (char *) realloc (r->buf, r->cap + 1);
+            }
+          memcpy (r->buf + have, base, n);
+          have += n;
+          r->pos += n + (nl ? 1 : 0);
+          if (nl)
+            {
+              r->buf[have] = '\0';
+              if (len_out)
+                *len_out = have;
+              return r->buf;
+            }
         }
       if (r->eof)
         return NULL;            /* an unterminated last line is dropped, pemapper.c:2466-2481 */
-      memmove (r->buf, r->buf + r->pos, r->len - r->pos);
-      r->len -= r->pos;
-      r->pos = 0;
-      if (r->len + LR_BLOCK > r->cap)
-        {
-          r->cap = 2 * (r->len + LR_BLOCK);
-          r->buf = (char *) realloc (r->buf, r->cap + 1);
-        }
+      /* the block is used up: hand it back and take the next one */
       pthread_mutex_lock (&r->mu);
+      if (r->len > 0)
+        {
+          r->head = (r->head + 1) % LR_RING;
+          r->count--;
+          r->len = r->pos = 0;
+          pthread_cond_broadcast (&r->cv);
+        }
       while (r->count == 0 && !r->done)
         pthread_cond_wait (&r->cv, &r->mu);
       if (r->count == 0)
+        r->eof = 1;
+      else
         {
-          pthread_mutex_unlock (&r->mu);
-          r->eof = 1;
-          continue;
+          r->len = (size_t) r->ring_len[r->head];
+          r->pos = 0;
         }
-      pthread_mutex_unlock (&r->mu);
-      memcpy (r->buf + r->len, r->ring[r->head], (size_t) r->ring_len[r->head]);
-      r->len += (size_t) r->ring_len[r->head];
-      r->head = (r->head + 1) % LR_RING;
-      pthread_mutex_lock (&r->mu);
-      r->count--;
-      pthread_cond_broadcast (&r->cv);
       pthread_mutex_unlock (&r->mu);
     }
 }
@@ -215,23 +233,24 @@ fill_rows (void *arg)
   while (j->got < j->want)
     {
       char *s;
+      size_t full = 0;
       if (!j->started)
         {
-          lr_gets (r);
-          s = lr_gets (r);
+          lr_gets (r, NULL);
+          s = lr_gets (r, &full);
           j->started = 1;
         }
       else
         {
-          lr_gets (r);
-          lr_gets (r);
-          s = lr_gets (r);
+          lr_gets (r, NULL);
+          lr_gets (r, NULL);
+          s = lr_gets (r, &full);
           int not_there = 1;
           while (s != NULL && not_there)
             {
               if (s[0] == '@')
                 not_there = 0;
-              s = lr_gets (r);
+              s = lr_gets (r, &full);
             }
           if (not_there)
             s = NULL;
@@ -241,9 +260,8 @@ fill_rows (void *arg)
           j->end = 1;
           break;
         }
-      const int full = (int) strlen (s);
-      int sl = full - j->trim_s;
-      s += (sl >= 0) ? j->trim_s : full;
+      int sl = (int) full - j->trim_s;
+      s += (sl >= 0) ? j->trim_s : (int) full;
       sl -= j->trim_e;
       if (sl < 0)
         sl = 0;
