@@ -17,7 +17,7 @@
  * With a BED guide file (the last argument, pecaller.c:925-1068) every position of the listed intervals is called, covered
  * or not, and columns on chrY / chrMT are called with HAPLOID forced (955-957).
  *
- * Not supported (an error, not a silent difference): more than 64 samples.  `no_threads` is validated and unused.
+ * Not supported (an error, not a silent difference): more than 64 samples.  `no_threads` is validated; up to 32 of them deflate <outfile>.base.gz.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -28,6 +28,7 @@
 #include <errno.h>
 #include <math.h>
 #include <zlib.h>
+#include <time.h>
 #include "../../include/pemap_hip.h"
 #include "host_io.h"
 
@@ -92,6 +93,16 @@ static void
 advance (sample_t * s, int *running)
 {
   /* (gzeof / gzread of 4 then 12 bytes in the reference: the end of the stream is a read of nothing) */
+  zreader *z = &s->f;
+  if (z->count > 0 && z->pos + 16 <= z->ring_len[z->head])
+    {
+      /* the whole record lies in the block at hand: 64 of these per column are the merge's inner loop */
+      const char *q = z->ring[z->head] + z->pos;
+      memcpy (&s->cur, q, sizeof (unsigned int));
+      memcpy (s->data, q + 4, sizeof (unsigned short) * NA);
+      z->pos += 16;
+      return;
+    }
   if (zr_read (&s->f, &s->cur, sizeof (unsigned int)) != 0)
     zr_read (&s->f, s->data, sizeof (unsigned short) * NA);
   else
@@ -115,8 +126,30 @@ typedef struct
   long n;
 } tile_t;
 
+/* The rows of <outfile>.base.gz are put together in memory and handed to the parallel gz writer tile by tile (host_io.h: gzip
+   members, the same bytes after inflation as gzprintf would have produced, pecaller.c:1760-1775).  A posterior of exactly 1 --
+   nearly all of them -- prints as "1" under %g and is written without going through printf. */
+typedef struct
+{
+  char *p;
+  size_t n, cap;
+} sbuf;
+
+static inline char *
+sb_room (sbuf * b, size_t k)
+{
+  if (b->n + k > b->cap)
+    {
+      b->cap = 2 * (b->n + k) + (1 << 20);
+      b->p = (char *) realloc (b->p, b->cap);
+      if (!b->p)
+        die ("\n pecaller_hip: out of memory for %s", "the output rows");
+    }
+  return b->p + b->n;
+}
+
 static void
-emit_rows (const tile_t * t, int indiv, char **contig_names, gzFile outfile, FILE * snpfile, gzFile pilefile)
+emit_rows (const tile_t * t, int indiv, char **contig_names, sbuf * ob, FILE * snpfile, gzFile pilefile)
 {
   char minor[80], am_count[80], tmp[64];
   for (long s = 0; s < t->n; s++)
@@ -126,12 +159,38 @@ emit_rows (const tile_t * t, int indiv, char **contig_names, gzFile outfile, FIL
       const char *frag = contig_names[t->contig[s]];
       const int8_t *call = t->call + s * indiv;
       const double *p = t->post + s * indiv;
-      gzprintf (outfile, "\n%s\t%d\t%c", frag, (int) t->pos[s], t->ref_char[s]);
-      for (int i = 0; i < indiv; i++)
-        if (call[i] < 14)
-          gzprintf (outfile, "\t%c\t%g", GEN[call[i]], p[i]);
-        else
-          gzprintf (outfile, "\tN\t1");
+      {
+        const size_t fl = strlen (frag);
+        char *w = sb_room (ob, fl + 32 + (size_t) indiv * 32);
+        char *w0 = w;
+        *w++ = '\n';
+        memcpy (w, frag, fl);
+        w += fl;
+        *w++ = '\t';
+        w += sprintf (w, "%d", (int) t->pos[s]);
+        *w++ = '\t';
+        *w++ = t->ref_char[s];
+        for (int i = 0; i < indiv; i++)
+          {
+            *w++ = '\t';
+            if (call[i] < 14)
+              {
+                *w++ = GEN[call[i]];
+                *w++ = '\t';
+                if (p[i] == 1.0)
+                  *w++ = '1';
+                else
+                  w += sprintf (w, "%g", p[i]);
+              }
+            else
+              {
+                *w++ = 'N';
+                *w++ = '\t';
+                *w++ = '1';
+              }
+          }
+        ob->n += (size_t) (w - w0);
+      }
       if (t->type[s] == 0)
         continue;
       minor[0] = am_count[0] = '\0';
@@ -204,12 +263,13 @@ main (int argc, char *argv[])
     die ("\n Can not open file %s for writing which should contain the guide_file", argv[argc - 1]);
   const int haploid = (strchr (argv[7], 'Y') || strchr (argv[7], 'y')) ? 1 : 0;
 
-  gzFile outfile, pilefile;
+  gzFile pilefile;
+  pgz outfile;
+  sbuf ob = { NULL, 0, 0 };
   FILE *snpfile, *distfile;
   sprintf (ss, "%s.base.gz", argv[4]);
-  if (!(outfile = gzopen (ss, "w")))
+  if (pgz_open (&outfile, ss, no_threads > 32 ? 32 : no_threads))
     die ("\n Can not open file %s", ss);
-  gzbuffer (outfile, 131072);
   sprintf (ss, "%s.snp", argv[4]);
   if (!(snpfile = fopen (ss, "w")))
     die ("\n Can not open file %s for writing", ss);
@@ -378,15 +438,20 @@ main (int argc, char *argv[])
         running--;
     }
   fprintf (snpfile, "Fragment\tPosition\tReference\tAlleles\tAllele_Counts\tType");
-  gzprintf (outfile, "Fragment\tPosition\tReference");
+  ob.n += (size_t) sprintf (sb_room (&ob, 64), "Fragment\tPosition\tReference");
   gzprintf (pilefile, "Fragment\tPosition\tReference");
   for (int i = 0; i < indiv; i++)
     {
       fprintf (snpfile, "\t%s\t", sm[i].name);
-      gzprintf (outfile, "\t%s\t", sm[i].name);
+      ob.n += (size_t) sprintf (sb_room (&ob, strlen (sm[i].name) + 8), "\t%s\t", sm[i].name);
       gzprintf (pilefile, "\t%s\t\t\t\t\t", sm[i].name);
     }
 
+  struct timespec tstart, tc0, tc1;
+  double sec_dev = 0, sec_text = 0, sec_merge = 0;
+  long tot_cols = 0;
+  clock_gettime (CLOCK_MONOTONIC, &tstart);
+  tc0 = tc1 = tstart;
   tile_t t;
   t.reads = (uint16_t *) malloc ((size_t) TILE * indiv * NA * sizeof (uint16_t));
   t.ref_base = (uint8_t *) malloc (TILE);
@@ -399,6 +464,7 @@ main (int argc, char *argv[])
   t.post = (double *) malloc ((size_t) TILE * indiv * sizeof (double));
   t.type = (int8_t *) malloc (TILE);
   t.ac = (int32_t *) malloc ((size_t) TILE * NA * sizeof (int32_t));
+  clock_gettime (CLOCK_MONOTONIC, &tc0);
   t.n = 0;
   unsigned int tot_bases = 0;
   const int start_chrom = (no_contigs - 1) / 2 > 0 ? (no_contigs - 1) / 2 : 0;
@@ -539,9 +605,20 @@ main (int argc, char *argv[])
         }
       if (t.n == TILE || (running <= 0 && t.n > 0))
         {
+          clock_gettime (CLOCK_MONOTONIC, &tc1);
+          sec_merge += (double) (tc1.tv_sec - tc0.tv_sec) + 1e-9 * (double) (tc1.tv_nsec - tc0.tv_nsec);
+          tc0 = tc1;
           if (pecall_dev_call_sites (pc, t.reads, t.ref_base, t.chrom, t.n, indiv, haploid, threshold, theta, t.call, t.post, t.type, t.ac, NULL, t.denovo))
             die ("\n pecaller_hip: %s", pecall_dev_last_error (pc));
-          emit_rows (&t, indiv, contig_names, outfile, snpfile, pilefile);
+          clock_gettime (CLOCK_MONOTONIC, &tc1);
+          sec_dev += (double) (tc1.tv_sec - tc0.tv_sec) + 1e-9 * (double) (tc1.tv_nsec - tc0.tv_nsec);
+          emit_rows (&t, indiv, contig_names, &ob, snpfile, pilefile);
+          if (pgz_write (&outfile, ob.p, ob.n))
+            die ("\n pecaller_hip: write to %s.base.gz failed", argv[4]);
+          ob.n = 0;
+          clock_gettime (CLOCK_MONOTONIC, &tc0);
+          sec_text += (double) (tc0.tv_sec - tc1.tv_sec) + 1e-9 * (double) (tc0.tv_nsec - tc1.tv_nsec);
+          tot_cols += t.n;
           t.n = 0;
         }
     }
@@ -602,8 +679,17 @@ main (int argc, char *argv[])
   fprintf (distfile, "\n");
   fclose (distfile);
   fclose (snpfile);
-  gzclose (outfile);
+  if (ob.n && pgz_write (&outfile, ob.p, ob.n))         /* (the header line, when there was no column at all) */
+    die ("\n pecaller_hip: write to %s.base.gz failed", argv[4]);
+  if (pgz_close (&outfile))
+    die ("\n pecaller_hip: closing %s.base.gz failed", argv[4]);
   gzclose (pilefile);
+  clock_gettime (CLOCK_MONOTONIC, &tc1);
+  {
+    const double sec = (double) (tc1.tv_sec - tstart.tv_sec) + 1e-9 * (double) (tc1.tv_nsec - tstart.tv_nsec);
+    printf ("\n pecaller_hip: %ld columns x %d samples merged, called and written in %.3f s (%.3f M columns/s; 64-way merge %.3f s, device calls %.3f s, rows and gz %.3f s) \n",
+            tot_cols, indiv, sec, (double) tot_cols / (sec > 0 ? sec : 1) / 1e6, sec_merge, sec_dev, sec_text);
+  }
   for (int i = 0; i < no_files; i++)
     zr_close (&sm[i].f);
   pecall_dev_destroy (pc);
