@@ -322,8 +322,13 @@ def main():
     # ---- end of the run: the per-GPU pileup partials are summed (the reference's one shared all_base_list, pemapper.c:156)
     if world > 1:
         cnt = pd.device_tensor(torch, dev, 4)
-        def grand_total(t):       # of the 16-bit counters, two to a word
-            return (t & 0xFFFF).sum(dtype=torch.int64) + ((t >> 16) & 0xFFFF).sum(dtype=torch.int64)
+        def grand_total(t):       # of the 16-bit counters, two to a word (in pieces: the masks are temporaries of the piece's size)
+            tot = torch.zeros((), dtype=torch.int64, device=t.device)
+            flat = t.view(-1)
+            for o in range(0, flat.numel(), 1 << 27):
+                c = flat[o:o + (1 << 27)]
+                tot += (c & 0xFFFF).sum(dtype=torch.int64) + ((c >> 16) & 0xFFFF).sum(dtype=torch.int64)
+            return tot
         local = grand_total(cnt).reshape(1)
         tot = local.clone() if on_gpu else local.cpu()
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
