@@ -17,7 +17,7 @@
  * With a BED guide file (the last argument, pecaller.c:925-1068) every position of the listed intervals is called, covered
  * or not, and columns on chrY / chrMT are called with HAPLOID forced (955-957).
  *
- * Not supported (an error, not a silent difference): more than 64 samples.  `no_threads` is validated; up to 32 of them deflate <outfile>.base.gz.
+ * Not supported (an error, not a silent difference): more than 64 samples.  `no_threads` - 1 threads (at most 32) walk the pileup streams, format the rows and deflate <outfile>.base.gz.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -28,6 +28,7 @@
 #include <errno.h>
 #include <math.h>
 #include <zlib.h>
+#include <unistd.h>
 #include <time.h>
 #include "../../include/pemap_hip.h"
 #include "host_io.h"
@@ -148,19 +149,20 @@ sb_room (sbuf * b, size_t k)
   return b->p + b->n;
 }
 
+/* rows of columns [s0, s1): <outfile>.base.gz text into ob, <outfile>.snp text into sb, <outfile>.piles.gz text into pb */
 static void
-emit_rows (const tile_t * t, int indiv, char **contig_names, sbuf * ob, FILE * snpfile, gzFile pilefile)
+emit_rows (const tile_t * t, long s0, long s1, int indiv, char **contig_names, sbuf * ob, sbuf * sb, sbuf * pb)
 {
   char minor[80], am_count[80], tmp[64];
-  for (long s = 0; s < t->n; s++)
+  for (long s = s0; s < s1; s++)
     {
       if (t->type[s] < 0)
         continue;               /* reference base not A/C/G/T: the worker skips the column (pecaller.c:1208, 1718) */
       const char *frag = contig_names[t->contig[s]];
       const int8_t *call = t->call + s * indiv;
       const double *p = t->post + s * indiv;
+      const size_t fl = strlen (frag);
       {
-        const size_t fl = strlen (frag);
         char *w = sb_room (ob, fl + 32 + (size_t) indiv * 32);
         char *w0 = w;
         *w++ = '\n';
@@ -207,17 +209,216 @@ emit_rows (const tile_t * t, int indiv, char **contig_names, sbuf * ob, FILE * s
           minor[strlen (minor) - 1] = '\0';
           am_count[strlen (am_count) - 1] = '\0';
         }
-      fprintf (snpfile, "\n%s\t%d\t%c\t%s\t%s\t%s%s", frag, (int) t->pos[s], t->ref_char[s], minor, am_count, t->denovo[s] > 0 ? "DENOVO_" : "",
-               TYPE_NAME[t->type[s]]);
-      gzprintf (pilefile, "\n%s\t%d\t%c", frag, (int) t->pos[s], t->ref_char[s]);
+      sb->n += (size_t) sprintf (sb_room (sb, fl + 256), "\n%s\t%d\t%c\t%s\t%s\t%s%s", frag, (int) t->pos[s], t->ref_char[s], minor, am_count,
+                                 t->denovo[s] > 0 ? "DENOVO_" : "", TYPE_NAME[t->type[s]]);
+      pb->n += (size_t) sprintf (sb_room (pb, fl + 64), "\n%s\t%d\t%c", frag, (int) t->pos[s], t->ref_char[s]);
       for (int i = 0; i < indiv; i++)
         {
-          fprintf (snpfile, "\t%c\t%g", GEN[call[i]], p[i]);
+          sb->n += (size_t) sprintf (sb_room (sb, 64), "\t%c\t%g", GEN[call[i]], p[i]);
           const uint16_t *r = t->reads + ((size_t) s * indiv + i) * NA;
           for (int a = 0; a < NA; a++)
-            gzprintf (pilefile, "\t%d", (int) r[a]);
+            pb->n += (size_t) sprintf (sb_room (pb, 16), "\t%d", (int) r[a]);
         }
     }
+}
+
+typedef struct
+{
+  const tile_t *t;
+  long s0, s1;
+  int indiv;
+  char **contig_names;
+  sbuf ob, sb, pb;
+} emit_job;
+
+static void *
+emit_thread (void *arg)
+{
+  emit_job *j = (emit_job *) arg;
+  emit_rows (j->t, j->s0, j->s1, j->indiv, j->contig_names, &j->ob, &j->sb, &j->pb);
+  return NULL;
+}
+
+/* the rows of a tile, formatted by `threads` threads (contiguous runs of columns, put together in column order) */
+static void
+emit_tile (const tile_t * t, int indiv, char **contig_names, int threads, sbuf * ob, FILE * snpfile, gzFile pilefile)
+{
+  enum { MAXT = 32 };
+  static emit_job jobs[MAXT];   /* (their buffers are kept from tile to tile) */
+  pthread_t th[MAXT];
+  if (threads > MAXT)
+    threads = MAXT;
+  if (threads < 1 || t->n < 4096)
+    threads = 1;
+  for (int k = 0; k < threads; k++)
+    {
+      jobs[k].t = t;
+      jobs[k].s0 = t->n * k / threads;
+      jobs[k].s1 = t->n * (k + 1) / threads;
+      jobs[k].indiv = indiv;
+      jobs[k].contig_names = contig_names;
+      jobs[k].ob.n = jobs[k].sb.n = jobs[k].pb.n = 0;
+    }
+  for (int k = 1; k < threads; k++)
+    if (pthread_create (&th[k], NULL, emit_thread, &jobs[k]))
+      die ("\n pecaller_hip: can not start %s", "a formatting thread");
+  emit_thread (&jobs[0]);
+  for (int k = 1; k < threads; k++)
+    pthread_join (th[k], NULL);
+  for (int k = 0; k < threads; k++)
+    {
+      memcpy (sb_room (ob, jobs[k].ob.n), jobs[k].ob.p, jobs[k].ob.n);
+      ob->n += jobs[k].ob.n;
+      if (jobs[k].sb.n)
+        fwrite (jobs[k].sb.p, 1, jobs[k].sb.n, snpfile);
+      if (jobs[k].pb.n)
+        gzwrite (pilefile, jobs[k].pb.p, (unsigned) jobs[k].pb.n);
+    }
+}
+
+/* ---- the merge of the pileup streams without a guide file, a range of genome positions at a time.  The reference's dispatcher
+        (find_lowest / the per-column loop, pecaller.c:891-1039, 1820-1833) takes the lowest pending position of all streams, makes
+        a column of it from the streams that have a record there, and advances those: for streams in ascending order (as pemapper
+        writes them) the columns are the union of the positions, each sample's counts where it has a record and zeros where it
+        has none.  Here every stream is walked on its own over the positions [p0, p0 + TILE) into a plane of its own (a thread
+        takes several streams; the statistics of <outfile>.dist are per stream and see the same records in the same order), and
+        the planes are put together column by column, positions without any record left out. */
+typedef struct
+{
+  sample_t *sm;
+  int no_files, indiv, T, k;
+  unsigned int p0;
+  unsigned long long p1;
+  uint16_t *planes;             /* [indiv][TILE][NA] */
+  uint8_t *marks;               /* [T][TILE]: a stream of thread k has a record at the slot */
+  /* second part */
+  tile_t *t;
+  long *chunk_base;             /* column of the first marked slot of each chunk of MG_CHUNK slots */
+  const unsigned int *frag_pos;
+  const uint8_t *chrom_type;
+  const char *genome;
+  unsigned int gsize;
+  int no_contigs, start_chrom;
+} merge_ctx;
+
+#define MG_CHUNK 65536
+
+static void
+advance_nr (sample_t * s)
+{
+  zreader *z = &s->f;
+  if (z->count > 0 && z->pos + 16 <= z->ring_len[z->head])
+    {
+      const char *q = z->ring[z->head] + z->pos;
+      memcpy (&s->cur, q, sizeof (unsigned int));
+      memcpy (s->data, q + 4, sizeof (unsigned short) * NA);
+      z->pos += 16;
+      return;
+    }
+  if (zr_read (&s->f, &s->cur, sizeof (unsigned int)) != 0)
+    zr_read (&s->f, s->data, sizeof (unsigned short) * NA);
+  else
+    s->cur = 0;
+}
+
+static void *
+merge_streams (void *arg)
+{
+  merge_ctx *c = (merge_ctx *) arg;
+  uint8_t *mark = c->marks + (size_t) c->k * TILE;
+  memset (mark, 0, TILE);
+  for (int i = c->k; i < c->no_files; i += c->T)
+    {
+      sample_t *s = &c->sm[i];
+      uint16_t *plane = c->planes + (size_t) i * TILE * NA;
+      size_t done = 0;          /* slots of the plane written so far */
+      while (s->cur != 0 && (unsigned long long) s->cur < c->p1)
+        {
+          if ((unsigned long long) s->cur < (unsigned long long) c->p0 + done)
+            die ("\n pecaller_hip: the records of %s are not in ascending order", s->name);
+          const size_t slot = (size_t) (s->cur - c->p0);
+          memset (plane + done * NA, 0, (slot - done) * NA * sizeof (uint16_t));
+          unsigned int cov = 0;
+          for (int a = 0; a < NA; a++)
+            {
+              plane[slot * NA + a] = s->data[a];
+              cov += s->data[a];
+            }
+          s->mean += (double) cov;
+          if (cov > s->max_coverage)
+            s->max_coverage = cov;
+          s->counts[cov < MAX_DIST - 1 ? cov : MAX_DIST - 1]++;
+          s->base_count++;
+          mark[slot] = 1;
+          done = slot + 1;
+          advance_nr (s);
+        }
+      memset (plane + done * NA, 0, ((size_t) TILE - done) * NA * sizeof (uint16_t));
+    }
+  return NULL;
+}
+
+static int
+slot_marked (const merge_ctx * c, size_t slot)
+{
+  for (int k = 0; k < c->T; k++)
+    if (c->marks[(size_t) k * TILE + slot])
+      return 1;
+  return 0;
+}
+
+static void *
+merge_count (void *arg)
+{
+  merge_ctx *c = (merge_ctx *) arg;
+  for (size_t ch = (size_t) c->k; ch < TILE / MG_CHUNK; ch += (size_t) c->T)
+    {
+      long n = 0;
+      for (size_t slot = ch * MG_CHUNK; slot < (ch + 1) * MG_CHUNK; slot++)
+        n += slot_marked (c, slot);
+      c->chunk_base[ch] = n;
+    }
+  return NULL;
+}
+
+static void *
+merge_columns (void *arg)
+{
+  merge_ctx *c = (merge_ctx *) arg;
+  tile_t *t = c->t;
+  for (size_t ch = (size_t) c->k; ch < TILE / MG_CHUNK; ch += (size_t) c->T)
+    {
+      long col = c->chunk_base[ch];
+      for (size_t slot = ch * MG_CHUNK; slot < (ch + 1) * MG_CHUNK; slot++)
+        if (slot_marked (c, slot))
+          {
+            const unsigned int lowest = c->p0 + (unsigned int) slot;
+            const int which = find_chrom (c->frag_pos, 0, c->no_contigs - 1, c->start_chrom, lowest);
+            const char ref = lowest < c->gsize ? c->genome[lowest] : '\0';
+            t->ref_char[col] = ref;
+            t->ref_base[col] = (uint8_t) gen_to_int (ref);
+            t->contig[col] = which;
+            t->pos[col] = 1 + lowest - c->frag_pos[which - 1];
+            t->chrom[col] = c->chrom_type[which];
+            uint16_t *dst = t->reads + (size_t) col * c->indiv * NA;
+            for (int i = 0; i < c->no_files; i++)
+              memcpy (dst + (size_t) i * NA, c->planes + ((size_t) i * TILE + slot) * NA, NA * sizeof (uint16_t));
+            col++;
+          }
+    }
+  return NULL;
+}
+
+static void
+run_threads (void *(*fn) (void *), merge_ctx * ctx, int T)
+{
+  pthread_t th[64];
+  for (int k = 1; k < T; k++)
+    if (pthread_create (&th[k], NULL, fn, &ctx[k]))
+      die ("\n pecaller_hip: can not start %s", "a merge thread");
+  fn (&ctx[0]);
+  for (int k = 1; k < T; k++)
+    pthread_join (th[k], NULL);
 }
 
 int
@@ -464,10 +665,54 @@ main (int argc, char *argv[])
   t.post = (double *) malloc ((size_t) TILE * indiv * sizeof (double));
   t.type = (int8_t *) malloc (TILE);
   t.ac = (int32_t *) malloc ((size_t) TILE * NA * sizeof (int32_t));
+  /* the threads of the merge and of the row formatting: the reference's worker threads minus its dispatcher, at most 32 */
+  int MT = no_threads - 1;
+  {
+    const long ncpu = sysconf (_SC_NPROCESSORS_ONLN);
+    if (ncpu > 0 && MT > (int) ncpu)
+      MT = (int) ncpu;
+    if (MT > 32)
+      MT = 32;
+    if (MT > no_files)
+      MT = no_files;
+    if (MT < 1)
+      MT = 1;
+  }
+  merge_ctx mc[32];
+  long *chunk_base = (long *) calloc (TILE / MG_CHUNK, sizeof (long));
+  uint16_t *planes = NULL;
+  uint8_t *marks = NULL;
+  if (!guide_file)
+    {
+      planes = (uint16_t *) malloc ((size_t) no_files * TILE * NA * sizeof (uint16_t));
+      marks = (uint8_t *) malloc ((size_t) MT * TILE);
+      if (!planes || !marks)
+        die ("\n pecaller_hip: out of memory for %s", "the merge planes");
+    }
+  for (int k = 0; k < MT; k++)
+    {
+      memset (&mc[k], 0, sizeof mc[k]);
+      mc[k].sm = sm;
+      mc[k].no_files = no_files;
+      mc[k].indiv = indiv;
+      mc[k].T = MT;
+      mc[k].k = k;
+      mc[k].planes = planes;
+      mc[k].marks = marks;
+      mc[k].t = &t;
+      mc[k].chunk_base = chunk_base;
+      mc[k].frag_pos = frag_pos;
+      mc[k].chrom_type = chrom_type;
+      mc[k].genome = genome;
+      mc[k].gsize = gsize;
+      mc[k].no_contigs = no_contigs;
+    }
   clock_gettime (CLOCK_MONOTONIC, &tc0);
   t.n = 0;
   unsigned int tot_bases = 0;
   const int start_chrom = (no_contigs - 1) / 2 > 0 ? (no_contigs - 1) / 2 : 0;
+  for (int k = 0; k < MT; k++)
+    mc[k].start_chrom = start_chrom;
   /* guide mode state: the current interval [lowest, end] of contig `gwhich` (pecaller.c:927-953, 1040-1066) */
   unsigned int lowest = 0, gend = 0;
   int gwhich = -1;
@@ -496,45 +741,35 @@ main (int argc, char *argv[])
     }
   while (running > 0 || t.n > 0)
     {
+      int tile_done = 0;
       if (running > 0 && !guide_file)
         {
-          /* find_lowest, pecaller.c:1820-1833 */
-          lowest = 0;
-          int i = 0;
-          while (lowest < 1 && i < no_files)
-            lowest = sm[i++].cur;
-          for (; i < no_files; i++)
-            if (sm[i].cur > 0 && sm[i].cur < lowest)
-              lowest = sm[i].cur;
-          const int which = find_chrom (frag_pos, 0, no_contigs - 1, start_chrom, lowest);
-          const char ref = lowest < gsize ? genome[lowest] : '\0';
-          const long s = t.n++;
-          t.ref_char[s] = ref;
-          t.ref_base[s] = (uint8_t) gen_to_int (ref);
-          t.contig[s] = which;
-          t.pos[s] = 1 + lowest - frag_pos[which - 1];
-          t.chrom[s] = chrom_type[which];
-          tot_bases++;
-          uint16_t *col = t.reads + (size_t) s * indiv * NA;
-          for (i = 0; i < no_files; i++)
-            if (sm[i].cur == lowest)
-              {
-                unsigned int cov = 0;
-                for (int a = 0; a < NA; a++)
-                  {
-                    col[i * NA + a] = sm[i].data[a];
-                    cov += sm[i].data[a];
-                  }
-                sm[i].mean += (double) cov;
-                if (cov > sm[i].max_coverage)
-                  sm[i].max_coverage = cov;
-                sm[i].counts[cov < MAX_DIST - 1 ? cov : MAX_DIST - 1]++;
-                sm[i].base_count++;
-                advance (&sm[i], &running);
-              }
-            else
-              for (int a = 0; a < NA; a++)
-                col[i * NA + a] = 0;
+          /* the next range of positions: from the lowest pending position of all streams (find_lowest, pecaller.c:1820-1833) */
+          unsigned int p0 = 0;
+          for (int i = 0; i < no_files; i++)
+            if (sm[i].cur > 0 && (p0 == 0 || sm[i].cur < p0))
+              p0 = sm[i].cur;
+          for (int k = 0; k < MT; k++)
+            {
+              mc[k].p0 = p0;
+              mc[k].p1 = (unsigned long long) p0 + TILE;
+            }
+          run_threads (merge_streams, mc, MT);
+          run_threads (merge_count, mc, MT);
+          long ncol = 0;
+          for (size_t ch = 0; ch < TILE / MG_CHUNK; ch++)
+            {
+              const long n = chunk_base[ch];
+              chunk_base[ch] = ncol;
+              ncol += n;
+            }
+          run_threads (merge_columns, mc, MT);
+          t.n = ncol;
+          tot_bases += (unsigned int) ncol;
+          running = 0;
+          for (int i = 0; i < no_files; i++)
+            running += sm[i].cur != 0;
+          tile_done = 1;
         }
       else if (running > 0)
         {
@@ -603,7 +838,7 @@ main (int argc, char *argv[])
                 }
             }
         }
-      if (t.n == TILE || (running <= 0 && t.n > 0))
+      if (tile_done || t.n == TILE || (running <= 0 && t.n > 0))
         {
           clock_gettime (CLOCK_MONOTONIC, &tc1);
           sec_merge += (double) (tc1.tv_sec - tc0.tv_sec) + 1e-9 * (double) (tc1.tv_nsec - tc0.tv_nsec);
@@ -612,7 +847,7 @@ main (int argc, char *argv[])
             die ("\n pecaller_hip: %s", pecall_dev_last_error (pc));
           clock_gettime (CLOCK_MONOTONIC, &tc1);
           sec_dev += (double) (tc1.tv_sec - tc0.tv_sec) + 1e-9 * (double) (tc1.tv_nsec - tc0.tv_nsec);
-          emit_rows (&t, indiv, contig_names, &ob, snpfile, pilefile);
+          emit_tile (&t, indiv, contig_names, MT, &ob, snpfile, pilefile);
           if (pgz_write (&outfile, ob.p, ob.n))
             die ("\n pecaller_hip: write to %s.base.gz failed", argv[4]);
           ob.n = 0;
