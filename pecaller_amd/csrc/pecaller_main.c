@@ -35,8 +35,10 @@
 
 #define NA 6
 #define MAX_DIST 501            /* pecaller.c:222 */
-#define TILE (1 << 21)          /* columns per device call: a call ends with its slowest column (the beam of a few variant columns
-                                   runs 50-90 ms on one wave), so tiles are large enough for that tail to be a small share */
+/* columns per device call, and genome positions per range of the stream merge.  A call has a fixed part (two kernel launches, the
+   transfers' latencies), so tiles are large; PECALLER_TILE_LOG2 (10..22) overrides the exponent (tests: several ranges on a small
+   fixture) */
+static size_t TILE = (size_t) 1 << 21;
 
 static void
 die (const char *fmt, const char *arg)
@@ -301,7 +303,7 @@ typedef struct
   int no_contigs, start_chrom;
 } merge_ctx;
 
-#define MG_CHUNK 65536
+static size_t MG_CHUNK = 65536;        /* slots per work item of the column pass (<= TILE) */
 
 static void
 advance_nr (sample_t * s)
@@ -653,6 +655,13 @@ main (int argc, char *argv[])
   long tot_cols = 0;
   clock_gettime (CLOCK_MONOTONIC, &tstart);
   tc0 = tc1 = tstart;
+  {
+    const char *tl = getenv ("PECALLER_TILE_LOG2");
+    if (tl && atoi (tl) >= 10 && atoi (tl) <= 22)
+      TILE = (size_t) 1 << atoi (tl);
+    if (MG_CHUNK > TILE)
+      MG_CHUNK = TILE;
+  }
   tile_t t;
   t.reads = (uint16_t *) malloc ((size_t) TILE * indiv * NA * sizeof (uint16_t));
   t.ref_base = (uint8_t *) malloc (TILE);
@@ -838,7 +847,7 @@ main (int argc, char *argv[])
                 }
             }
         }
-      if (tile_done || t.n == TILE || (running <= 0 && t.n > 0))
+      if (tile_done || (size_t) t.n == TILE || (running <= 0 && t.n > 0))
         {
           clock_gettime (CLOCK_MONOTONIC, &tc1);
           sec_merge += (double) (tc1.tv_sec - tc0.tv_sec) + 1e-9 * (double) (tc1.tv_nsec - tc0.tv_nsec);

@@ -16,8 +16,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "pecaller_amd", "pecaller_hip")
 
 
-def test_pecaller_cli_outputs(tmp_path):
+@pytest.mark.parametrize("tile_log2", [None, "10"])
+def test_pecaller_cli_outputs(tmp_path, tile_log2, monkeypatch):
+    """(tile_log2 = 10: the stream merge and the device calls take the fixture's 6,000 positions in six ranges of 1,024 -- records
+    of a stream on both sides of a range boundary, streams without a record in a range, the last range partly empty)"""
     assert os.path.exists(EXE), "build with make -C pecaller_amd/csrc"
+    if tile_log2:
+        monkeypatch.setenv("PECALLER_TILE_LOG2", tile_log2)
     z = np.load(os.path.join(fx.GOLD, "pecall_sites.npz"))
     names = [str(x) for x in z["names"]]
     reads, pos, pad = z["reads"], z["pos"], int(z["pad"][0])
