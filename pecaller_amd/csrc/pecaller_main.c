@@ -423,6 +423,96 @@ run_threads (void *(*fn) (void *), merge_ctx * ctx, int T)
     pthread_join (th[k], NULL);
 }
 
+/* ---- the device call and the text of a tile run on a thread of their own while the main thread merges the next tile (two sets of
+        tile arrays change hands) */
+typedef struct
+{
+  pthread_t th;
+  pthread_mutex_t mu;
+  pthread_cond_t cv;
+  int has_job, busy, stop;
+  tile_t job;
+  /* what the work needs */
+  pecall_dev *pc;
+  int indiv, haploid, threads;
+  double threshold, theta;
+  char **contig_names;
+  sbuf *ob;
+  FILE *snpfile;
+  gzFile pilefile;
+  pgz *outfile;
+  const char *outname;
+  double sec_dev, sec_text;
+  long tot_cols;
+} consumer_t;
+
+static void *
+consumer_main (void *arg)
+{
+  consumer_t *c = (consumer_t *) arg;
+  for (;;)
+    {
+      pthread_mutex_lock (&c->mu);
+      while (!c->has_job && !c->stop)
+        pthread_cond_wait (&c->cv, &c->mu);
+      if (!c->has_job && c->stop)
+        {
+          pthread_mutex_unlock (&c->mu);
+          return NULL;
+        }
+      c->has_job = 0;
+      c->busy = 1;
+      pthread_mutex_unlock (&c->mu);
+      tile_t *t = &c->job;
+      struct timespec a, b, d;
+      clock_gettime (CLOCK_MONOTONIC, &a);
+      if (pecall_dev_call_sites (c->pc, t->reads, t->ref_base, t->chrom, t->n, c->indiv, c->haploid, c->threshold, c->theta, t->call, t->post, t->type, t->ac,
+                                 NULL, t->denovo))
+        die ("\n pecaller_hip: %s", pecall_dev_last_error (c->pc));
+      clock_gettime (CLOCK_MONOTONIC, &b);
+      emit_tile (t, c->indiv, c->contig_names, c->threads, c->ob, c->snpfile, c->pilefile);
+      if (pgz_write (c->outfile, c->ob->p, c->ob->n))
+        die ("\n pecaller_hip: write to %s.base.gz failed", c->outname);
+      c->ob->n = 0;
+      clock_gettime (CLOCK_MONOTONIC, &d);
+      c->sec_dev += (double) (b.tv_sec - a.tv_sec) + 1e-9 * (double) (b.tv_nsec - a.tv_nsec);
+      c->sec_text += (double) (d.tv_sec - b.tv_sec) + 1e-9 * (double) (d.tv_nsec - b.tv_nsec);
+      c->tot_cols += t->n;
+      pthread_mutex_lock (&c->mu);
+      c->busy = 0;
+      pthread_cond_broadcast (&c->cv);
+      pthread_mutex_unlock (&c->mu);
+    }
+}
+
+static void
+consumer_wait_idle (consumer_t * c)
+{
+  pthread_mutex_lock (&c->mu);
+  while (c->has_job || c->busy)
+    pthread_cond_wait (&c->cv, &c->mu);
+  pthread_mutex_unlock (&c->mu);
+}
+
+static void
+tile_alloc (tile_t * t, int indiv)
+{
+  t->reads = (uint16_t *) malloc ((size_t) TILE * indiv * NA * sizeof (uint16_t));
+  t->ref_base = (uint8_t *) malloc (TILE);
+  t->chrom = (uint8_t *) malloc (TILE);
+  t->denovo = (int32_t *) malloc (TILE * sizeof (int32_t));
+  t->ref_char = (char *) malloc (TILE);
+  t->contig = (int *) malloc (TILE * sizeof (int));
+  t->pos = (unsigned int *) malloc (TILE * sizeof (unsigned int));
+  t->call = (int8_t *) malloc ((size_t) TILE * indiv);
+  t->post = (double *) malloc ((size_t) TILE * indiv * sizeof (double));
+  t->type = (int8_t *) malloc (TILE);
+  t->ac = (int32_t *) malloc ((size_t) TILE * NA * sizeof (int32_t));
+  t->n = 0;
+  if (!t->reads || !t->post || !t->call || !t->ac)
+    die ("\n pecaller_hip: out of memory for %s", "a tile");
+}
+
 int
 main (int argc, char *argv[])
 {
@@ -651,7 +741,7 @@ main (int argc, char *argv[])
     }
 
   struct timespec tstart, tc0, tc1;
-  double sec_dev = 0, sec_text = 0, sec_merge = 0;
+  double sec_dev = 0, sec_text = 0, sec_merge = 0, sec_wait = 0;
   long tot_cols = 0;
   clock_gettime (CLOCK_MONOTONIC, &tstart);
   tc0 = tc1 = tstart;
@@ -662,18 +752,9 @@ main (int argc, char *argv[])
     if (MG_CHUNK > TILE)
       MG_CHUNK = TILE;
   }
-  tile_t t;
-  t.reads = (uint16_t *) malloc ((size_t) TILE * indiv * NA * sizeof (uint16_t));
-  t.ref_base = (uint8_t *) malloc (TILE);
-  t.chrom = (uint8_t *) malloc (TILE);
-  t.denovo = (int32_t *) malloc (TILE * sizeof (int32_t));
-  t.ref_char = (char *) malloc (TILE);
-  t.contig = (int *) malloc (TILE * sizeof (int));
-  t.pos = (unsigned int *) malloc (TILE * sizeof (unsigned int));
-  t.call = (int8_t *) malloc ((size_t) TILE * indiv);
-  t.post = (double *) malloc ((size_t) TILE * indiv * sizeof (double));
-  t.type = (int8_t *) malloc (TILE);
-  t.ac = (int32_t *) malloc ((size_t) TILE * NA * sizeof (int32_t));
+  tile_t t, spare;
+  tile_alloc (&t, indiv);
+  tile_alloc (&spare, indiv);
   /* the threads of the merge and of the row formatting: the reference's worker threads minus its dispatcher, at most 32 */
   int MT = no_threads - 1;
   {
@@ -716,6 +797,24 @@ main (int argc, char *argv[])
       mc[k].gsize = gsize;
       mc[k].no_contigs = no_contigs;
     }
+  consumer_t cons;
+  memset (&cons, 0, sizeof cons);
+  pthread_mutex_init (&cons.mu, NULL);
+  pthread_cond_init (&cons.cv, NULL);
+  cons.pc = pc;
+  cons.indiv = indiv;
+  cons.haploid = haploid;
+  cons.threads = MT;
+  cons.threshold = threshold;
+  cons.theta = theta;
+  cons.contig_names = contig_names;
+  cons.ob = &ob;
+  cons.snpfile = snpfile;
+  cons.pilefile = pilefile;
+  cons.outfile = &outfile;
+  cons.outname = argv[4];
+  if (pthread_create (&cons.th, NULL, consumer_main, &cons))
+    die ("\n pecaller_hip: can not start %s", "the device-and-text thread");
   clock_gettime (CLOCK_MONOTONIC, &tc0);
   t.n = 0;
   unsigned int tot_bases = 0;
@@ -851,21 +950,32 @@ main (int argc, char *argv[])
         {
           clock_gettime (CLOCK_MONOTONIC, &tc1);
           sec_merge += (double) (tc1.tv_sec - tc0.tv_sec) + 1e-9 * (double) (tc1.tv_nsec - tc0.tv_nsec);
-          tc0 = tc1;
-          if (pecall_dev_call_sites (pc, t.reads, t.ref_base, t.chrom, t.n, indiv, haploid, threshold, theta, t.call, t.post, t.type, t.ac, NULL, t.denovo))
-            die ("\n pecaller_hip: %s", pecall_dev_last_error (pc));
-          clock_gettime (CLOCK_MONOTONIC, &tc1);
-          sec_dev += (double) (tc1.tv_sec - tc0.tv_sec) + 1e-9 * (double) (tc1.tv_nsec - tc0.tv_nsec);
-          emit_tile (&t, indiv, contig_names, MT, &ob, snpfile, pilefile);
-          if (pgz_write (&outfile, ob.p, ob.n))
-            die ("\n pecaller_hip: write to %s.base.gz failed", argv[4]);
-          ob.n = 0;
-          clock_gettime (CLOCK_MONOTONIC, &tc0);
-          sec_text += (double) (tc0.tv_sec - tc1.tv_sec) + 1e-9 * (double) (tc0.tv_nsec - tc1.tv_nsec);
-          tot_cols += t.n;
+          /* hand the tile to the device-and-text thread and go on with the other set of arrays (free once that thread is idle) */
+          consumer_wait_idle (&cons);
+          pthread_mutex_lock (&cons.mu);
+          cons.job = t;
+          cons.has_job = 1;
+          pthread_cond_broadcast (&cons.cv);
+          pthread_mutex_unlock (&cons.mu);
+          {
+            const tile_t given = t;
+            t = spare;
+            spare = given;
+          }
           t.n = 0;
+          clock_gettime (CLOCK_MONOTONIC, &tc0);
+          sec_wait += (double) (tc0.tv_sec - tc1.tv_sec) + 1e-9 * (double) (tc0.tv_nsec - tc1.tv_nsec);
         }
     }
+  consumer_wait_idle (&cons);
+  pthread_mutex_lock (&cons.mu);
+  cons.stop = 1;
+  pthread_cond_broadcast (&cons.cv);
+  pthread_mutex_unlock (&cons.mu);
+  pthread_join (cons.th, NULL);
+  sec_dev = cons.sec_dev;
+  sec_text = cons.sec_text;
+  tot_cols = cons.tot_cols;
 
   /* ---- <outfile>.dist, pecaller.c:1077-1140 */
   unsigned int *tot_1x = (unsigned int *) calloc (no_files, sizeof (unsigned int)), *tot_8x = (unsigned int *) calloc (no_files, sizeof (unsigned int));
@@ -931,8 +1041,8 @@ main (int argc, char *argv[])
   clock_gettime (CLOCK_MONOTONIC, &tc1);
   {
     const double sec = (double) (tc1.tv_sec - tstart.tv_sec) + 1e-9 * (double) (tc1.tv_nsec - tstart.tv_nsec);
-    printf ("\n pecaller_hip: %ld columns x %d samples merged, called and written in %.3f s (%.3f M columns/s; 64-way merge %.3f s, device calls %.3f s, rows and gz %.3f s) \n",
-            tot_cols, indiv, sec, (double) tot_cols / (sec > 0 ? sec : 1) / 1e6, sec_merge, sec_dev, sec_text);
+    printf ("\n pecaller_hip: %ld columns x %d samples merged, called and written in %.3f s (%.3f M columns/s; stream merge %.3f s + %.3f s waiting for the other thread: device calls %.3f s, rows and gz %.3f s) \n",
+            tot_cols, indiv, sec, (double) tot_cols / (sec > 0 ? sec : 1) / 1e6, sec_merge, sec_wait, sec_dev, sec_text);
   }
   for (int i = 0; i < no_files; i++)
     zr_close (&sm[i].f);
