@@ -199,6 +199,12 @@ def roofline_of(leg, dt, steps, L, n_rep, gs, B):
             "step_traffic_bytes": step_traffic,
             "step_traffic_over_algorithmic": (round(step_traffic / (total_b * ends / steps), 2) if step_traffic else None),
             "cells_per_s": round((agg["cells_score"] + agg["cells_dirs"] + agg.get("cells_band", 0)) / dt, 0)}
+    if step_traffic:
+        # what the two streams share: the step's counter traffic as 64-byte lines per second -- nearly all of them
+        # single lines at random addresses -- against what the chip delivers of those at best (tools/micro/line_gather: 48.8 G/s)
+        lines_s = step_traffic / 64.0 / (dt / steps)
+        roof["random_lines"] = {"step_G_lines_per_s": round(lines_s / 1e9, 2), "ceiling_G_lines_per_s": 48.8, "frac": round(lines_s / 48.8e9, 3),
+                                "source": "profiles/r01_line_gather.txt"}
     if dom != "lookup" and split:
         # the path's HBM-heavy kernel beside the dominant one: same accounting
         lk_name = lookup_kernel_name(n_rep)
