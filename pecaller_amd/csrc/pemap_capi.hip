@@ -152,6 +152,7 @@ struct pemap_dev
   bool index_ready;
   uint32_t *d_counts;           // the pileup counter planes (PmPile): 6 planes of pile_plane_words words
   size_t pile_plane_words;
+  bool rest_on_alu;
   // params
   int paired, min_dist, max_dist, bisulfite;
   double min_align;
@@ -1192,7 +1193,7 @@ static void launch_lookup (pemap_dev * d, const RunCtx & c, int slot, PmChunkCtr
 static bool pm_fused (const pemap_dev * d);
 static bool pm_vote_rest_on_alu (const pemap_dev * d)
 {
-  return d->kn.vote_rest_on_alu >= 0 ? d->kn.vote_rest_on_alu != 0 : pm_fused (d);
+  return d->rest_on_alu;        // set per run (run_slice)
 }
 
 // part 0: the whole stage; 1: the vote kernel only; 2: what follows it
@@ -1567,6 +1568,10 @@ static int run_slice (pemap_dev * d, int first, int n, int sync, const hipEvent_
   // 0 monolithic seed kernel, one stream; 2 split kernels on one stream (diagnostic).
   const bool split = d->kn.pipeline != 0 && !d->kn.seed_phase;
   d->serial_split = d->kn.pipeline == 2;
+  // PEMAP_VOTE_REST_ON_ALU unset: with the fused seed kernel the big read-ends' remainder and the emit kernel run on the ALU stream for
+  // reads of up to 160 bases (where the seed kernel is the longer side: 29.8 ms per step against 31.4), behind the seed kernel for
+  // longer ones (2 x 245: 56.9 ms against 58.6)
+  d->rest_on_alu = d->kn.vote_rest_on_alu >= 0 ? d->kn.vote_rest_on_alu != 0 : (pm_fused (d) && seg_template (L) <= 10);
   d->walk_on_mem = d->kn.walk_on_mem != 0;
   // PEMAP_VOTE_ON_MEM=1: the vote runs behind its look-ups on the memory stream, beside the SW / walk of the previous chunk
   // PEMAP_VOTE_ON_MEM=1: the vote runs behind its look-ups on the memory stream; 2: on a third stream of its own, beside
