@@ -76,6 +76,7 @@ struct PmKnobs
   bool vote_stream_prio_set;
   int chunk_pairs;
   int d2h_stream;               // 1: the results of a submitted batch return on a stream of their own instead of the ALU stream
+  int gapless_blocks_per_cu;
   int band, band_waves_per_cu;  // the banded DP (pm_band_kernel) for the problems it is exact for; its waves per CU
   int seed_phase, vote_probe;   // always 0 without PEMAP_TIMING_PROBES
 };
@@ -124,6 +125,8 @@ static void read_knobs (PmKnobs & k)
   k.chunk_pairs = env_int ("PEMAP_CHUNK_PAIRS", 262144);
   k.d2h_stream = env_int ("PEMAP_D2H_STREAM", 0);
   k.band = env_int ("PEMAP_BAND", 1);
+  k.gapless_blocks_per_cu = env_int ("PEMAP_GAPLESS_BLOCKS_PER_CU", 16);
+  if (k.gapless_blocks_per_cu < 1) k.gapless_blocks_per_cu = 1;
   k.band_waves_per_cu = env_int ("PEMAP_BAND_WAVES_PER_CU", 12);
   if (k.band_waves_per_cu < 1) k.band_waves_per_cu = 1;
   k.seed_phase = k.vote_probe = 0;
@@ -1307,8 +1310,8 @@ template < int W, int LPA > static void launch_chunk (pemap_dev * d, const RunCt
       uint32_t *tasks_dp = tasks_s + d->cap_ends;
       uint32_t *tasks_band = d->kn.band ? tasks_s + 2 * (size_t) d->cap_ends : nullptr;
       int ggrid = (n_ends + 7) / 8;
-      if (ggrid > d->n_cus * 16)
-        ggrid = d->n_cus * 16;
+      if (ggrid > d->n_cus * d->kn.gapless_blocks_per_cu)
+        ggrid = d->n_cus * d->kn.gapless_blocks_per_cu;
       hipLaunchKernelGGL (pm_gapless_kernel, dim3 (ggrid), dim3 (256), 0, d->stream, c.ix, c.b, c.prm, H, tasks_s, &ctr->n_tasks_s, tasks_dp,
                           &ctr->n_tasks_dp, pm_gapless_max_x (d), tasks_band, &ctr->n_band[0]);
       if (tasks_band)
