@@ -16,10 +16,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "pecaller_amd", "pecaller_hip")
 
 
-@pytest.mark.parametrize("tile_log2", [None, "10"])
-def test_pecaller_cli_outputs(tmp_path, tile_log2, monkeypatch):
+@pytest.mark.parametrize("tile_log2,threads", [(None, "2"), (None, "8"), ("10", "8")])
+def test_pecaller_cli_outputs(tmp_path, tile_log2, threads, monkeypatch):
     """(tile_log2 = 10: the stream merge and the device calls take the fixture's 6,000 positions in six ranges of 1,024 -- records
-    of a stream on both sides of a range boundary, streams without a record in a range, the last range partly empty)"""
+    of a stream on both sides of a range boundary, streams without a record in a range, the last range partly empty; threads = 8:
+    seven threads walk the 20 streams and format the rows, 2: one does)"""
     assert os.path.exists(EXE), "build with make -C pecaller_amd/csrc"
     if tile_log2:
         monkeypatch.setenv("PECALLER_TILE_LOG2", tile_log2)
@@ -37,7 +38,7 @@ def test_pecaller_cli_outputs(tmp_path, tile_log2, monkeypatch):
         recs += [struct.pack("<I6H", int(pos[-1]) + 1 + k, 20, 0, 0, 0, 0, 0) for k in range(pad)]
         with gzip.open(run / ("%s.pileup.gz" % nm), "wb", compresslevel=1) as f:
             f.write(b"".join(recs))
-    subprocess.check_call([EXE, "pileup", str(tmp_path / "g1.sdx"), "20", "out", "0.95", "0.001", "n", "2", "n"], cwd=run, stdout=subprocess.DEVNULL)
+    subprocess.check_call([EXE, "pileup", str(tmp_path / "g1.sdx"), "20", "out", "0.95", "0.001", "n", threads, "n"], cwd=run, stdout=subprocess.DEVNULL)
     base = gzip.open(run / "out.base.gz", "rt").read().split("\n")
     cols = [c for c in base[0].split("\t")[3:] if c]
     assert sorted(cols) == sorted(names)
