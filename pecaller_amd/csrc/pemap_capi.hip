@@ -214,6 +214,11 @@ struct pemap_dev
   PmInsCursor last_cur;
   // batches in flight
   std::mutex mu;                // guards the enqueue state: submit / wait may be called from several host threads
+  // Submitters are serialised for the whole of a submit (taken BEFORE mu).  ring_finish drops mu while the host blocks on the old
+  // batch's event; with mu alone a second submitter saw the same ring_seq there, chose the same slot, and whichever came second went
+  // on with a stale slot and `first` -- overwriting an active slot's staging and handing out a ticket of another slot (round-2 review).
+  // Waiters take mu only, so a wait is never held up by a submit that blocks on a full ring.
+  std::mutex submit_mu;
   PmRingSlot ring[PM_RING];
   int ring_cap;                 // rows per slot, 0 = the ring is not set up (the staged arrays hold a resident read set)
   unsigned long long ring_seq;
@@ -2035,6 +2040,7 @@ static int ring_finish_all (pemap_dev * d, std::unique_lock < std::mutex > &lk)
 // the staged arrays go back to holding one resident read set (stage_reads, synth_reads): no batch may be in flight
 static int ring_leave (pemap_dev * d)
 {
+  std::unique_lock < std::mutex > sub (d->submit_mu);
   std::unique_lock < std::mutex > lk (d->mu);
   TRY (ring_finish_all (d, lk));
   d->ring_cap = 0;
@@ -2094,6 +2100,7 @@ static int ring_setup (pemap_dev * d, int n, int stride, std::unique_lock < std:
 extern "C" int pemap_dev_submit_batch (pemap_dev * d, const char *reads1, const int *len1, const char *reads2, const int *len2,
                                        int n, int stride, uint32_t * m1, uint32_t * m2, int *mapping_type, uint64_t * ticket)
 {
+  std::unique_lock < std::mutex > sub (d->submit_mu);   // ring_seq, the slot and `first` below stay this call's own while mu is dropped
   std::unique_lock < std::mutex > lk (d->mu);
   HIPCHK (d, hipSetDevice (d->device));
   if (!d->index_ready)
@@ -2161,13 +2168,6 @@ extern "C" int pemap_dev_submit_batch (pemap_dev * d, const char *reads1, const 
       HIPCHK (d, hipEventCreateWithFlags (&e, hipEventDisableTiming));
       r.ev_copy.push_back (e);
     }
-  r.active = true;
-  r.seq = d->ring_seq;
-  r.n = n;
-  r.first = first;
-  r.m1 = m1;
-  r.m2 = m2;
-  r.mt = mapping_type;
   for (int k = 0, off = 0; off < n; off += slice, k++)
     {
       const int m = n - off < slice ? n - off : slice;
@@ -2210,6 +2210,15 @@ extern "C" int pemap_dev_submit_batch (pemap_dev * d, const char *reads1, const 
     HIPCHK (d, hipMemcpyAsync (r.h_res + d->ring_cap, d->d_m2 + first, (size_t) n * 4, hipMemcpyDeviceToHost, rs));
   HIPCHK (d, hipMemcpyAsync (r.h_res + 2 * (size_t) d->ring_cap, d->d_mtype + first, (size_t) n * 4, hipMemcpyDeviceToHost, rs));
   HIPCHK (d, hipEventRecord (r.ev_done, rs));
+  // the slot becomes a batch in flight only now that its event is recorded: an error above leaves it free, and nothing stale is
+  // ever "delivered" into the caller's buffers or folded into the summary
+  r.active = true;
+  r.seq = d->ring_seq;
+  r.n = n;
+  r.first = first;
+  r.m1 = m1;
+  r.m2 = m2;
+  r.mt = mapping_type;
   *ticket = d->ring_seq++;
   return 0;
 }

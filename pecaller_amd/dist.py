@@ -60,8 +60,9 @@ def broadcast_tensors(dist, tensors, src=0, chunk=1 << 28):
 
 
 def reduce_pileup(dist, counts, dst=None, chunk=1 << 27):
-    """in-place sum over all ranks (all_reduce, or reduce to `dst`) of the counters, an int32 view of words that hold two
-    16-bit counters each: the halves are summed apart and packed again modulo 2^16"""
+    """in-place sum over all ranks (all_reduce, or reduce to `dst`: only rank `dst` then holds the sum, the others keep their own
+    counters) of the counters, an int32 view of words that hold two 16-bit counters each: the halves are summed apart and packed
+    again modulo 2^16"""
     for c in _chunks(counts.view(-1), chunk):
         h = c.cpu() if _host_bounce(dist, c) else c
         lo = h & 0xFFFF
@@ -71,6 +72,8 @@ def reduce_pileup(dist, counts, dst=None, chunk=1 << 27):
                 dist.all_reduce(part, op=dist.ReduceOp.SUM)
             else:
                 dist.reduce(part, dst=dst, op=dist.ReduceOp.SUM)
+        if dst is not None and dist.get_rank() != dst:
+            continue            # (a reduce leaves the other ranks' buffers unspecified: their own counters stay as they were)
         lo &= 0xFFFF
         hi &= 0xFFFF
         # (hi << 16 in 32 bits: values of 0x8000 and more land in the sign bit, which is the bit pattern wanted)

@@ -279,6 +279,41 @@ def test_batches_in_flight_equal_one_call(dev):
     counts, ins = dev.fetch_pileup()
     fixtures.check_pileup_against_golden("r150", counts)
     assert dev.summary()[0] == tot
+    # six worker threads (more than the ring's three slots: submits queue up behind a full ring and must each keep a slot of
+    # their own -- the round-2 review's slot race), then two threads that keep two batches in flight each (four over three slots)
+    for mode in ("map_batch x 6", "submit, submit, wait x 2"):
+        dev.reset_pileup()
+        out = {}
+        errs = []
+
+        def worker6(k):
+            try:
+                for a in range(k * 500, 20000, 3000):
+                    out[a] = dev.map_batch(r1[a:a + 500], l1[a:a + 500], r2[a:a + 500], l2[a:a + 500])
+            except Exception as e:          # noqa: BLE001
+                errs.append(e)
+
+        def worker2(k):
+            try:
+                starts = list(range(k * 1000, 20000, 2000))
+                for i in range(0, len(starts), 2):
+                    pend = [(a, dev.submit_batch(r1[a:a + 1000], l1[a:a + 1000], r2[a:a + 1000], l2[a:a + 1000])) for a in starts[i:i + 2]]
+                    for a, t in pend:
+                        out[a] = dev.wait_batch(t)
+            except Exception as e:          # noqa: BLE001
+                errs.append(e)
+        th = [threading.Thread(target=worker6, args=(k,)) for k in range(6)] if mode.startswith("map") else [threading.Thread(target=worker2, args=(k,)) for k in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, (mode, errs)
+        assert np.array_equal(np.concatenate([out[a][0] for a in sorted(out)]), fixtures.golden_m("r150", 1)), mode
+        assert np.array_equal(np.concatenate([out[a][1] for a in sorted(out)]), fixtures.golden_m("r150", 2)), mode
+        assert np.array_equal(np.concatenate([out[a][2] for a in sorted(out)]), mt), mode
+        counts, ins = dev.fetch_pileup()
+        fixtures.check_pileup_against_golden("r150", counts)
+        assert dev.summary()[0] == tot, mode
 
 
 def test_torch_tensors_alias_the_library_buffers():
