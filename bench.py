@@ -48,20 +48,17 @@ def algorithmic_bytes_per_end(L, P_per_end, H_per_end):
 
 
 def sw_geometry(L):
-    """lanes per alignment and columns per lane as pick_geom (pemap_capi.hip) chooses them by default"""
-    lanes, W = (8, 13) if L <= 104 else (8, 19) if L <= 152 else (8, 26) if L <= 208 else (8, 32) if L <= 256 else (8, 38)
-    if L > 104 and os.environ.get("PEMAP_GAPLESS", "2") != "0" and "PEMAP_SW_LANES" not in os.environ:
-        lanes, W = (16, 10) if L <= 160 else (16, 13) if L <= 208 else (16, 16) if L <= 256 else (16, 19)
-    return lanes, W
+    """lanes per alignment and columns per lane as pick_geom (pemap_capi.hip) chooses them"""
+    if L <= 104:
+        return 8, 13
+    if os.environ.get("PEMAP_GAPLESS", "2") == "0" and L <= 152:
+        return 8, 19
+    return (16, 10) if L <= 160 else (16, 13) if L <= 208 else (16, 16) if L <= 256 else (16, 19)
 
 
 def lookup_kernel_name(n_rep):
-    """the kernel that serves the look-ups (with the 8 table replicas, by default, the fused look-up + vote kernel)"""
-    if os.environ.get("PEMAP_LOOKUP_WAVES", "7") == "0":
-        return "pm_lookup_kernel"
-    if not n_rep:
-        return "pm_lookup_wave_kernel"
-    return {"1": "pm_lookup_rep_kernel", "2": "pm_lookup_rep2_kernel", "3": "pm_seed3_kernel"}[os.environ.get("PEMAP_LOOKUP_V", "3")]
+    """the kernel that serves the look-ups: with the 8 table replicas the fused look-up + vote kernel"""
+    return "pm_seed3_kernel" if n_rep else "pm_lookup_wave_kernel"
 
 
 def mapper_leg(dev, a, L, B, steps, warmup, rank, world, barrier, allmax, indel_read_frac=0.0, seed_off=7, seam=True):

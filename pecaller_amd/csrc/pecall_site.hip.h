@@ -552,6 +552,106 @@ __device__ int pcs_expand (const PcsPool & cur, PcsPool & nw, const PcsPool & bi
   return newcount;
 }
 
+// calls and site classification of one column (pecaller.c:1565-1636, de-novo rows 1650-1671), lane = sample: what the reference
+// prints for it -- calls and posteriors, Allele_Counts, the row's type, the passes it took
+__device__ __forceinline__ void pcs_write_site (const PcsParams & P, long site, int lane, int dom, int chrom, const int (&r)[PCS_NA], int tot,
+                                                double average_depth, int final_call, double final_p, int pass, int8_t * call, double *post_out,
+                                                int8_t * type_out, int32_t * allele_count, int8_t * n_pass, int32_t * denovo_out)
+{
+  const int N = P.indiv, md = P.min_depth;
+  // ---- calls and site classification (pecaller.c:1565-1636)
+  const double low_base = (8 > 0.4 * average_depth) ? 8 : 0.4 * average_depth;
+  int ac6[PCS_NA] = { 0, 0, 0, 0, 0, 0 }, on_target = 0, off_target = 0, not_low = 0;
+  const bool called = lane < N && tot > md;
+  if (called && final_p >= P.threshold)
+    {
+#pragma unroll
+      for (int a = 0; a < PCS_NA; a++)
+        {
+          const int k = pcs_ac (dom, final_call, a, P.haploid);
+          if (k)
+            {
+              ac6[a] = k;
+              on_target += r[a];
+            }
+          else if (a != dom || final_call != PCS_NA - 1)
+            off_target += r[a];
+        }
+      if (tot > low_base && final_call != dom)
+        not_low = 1;
+    }
+  for (int o = 32; o; o >>= 1)
+    {
+#pragma unroll
+      for (int a = 0; a < PCS_NA; a++)
+        ac6[a] += __shfl_xor (ac6[a], o);
+      on_target += __shfl_xor (on_target, o);
+      off_target += __shfl_xor (off_target, o);
+      not_low += __shfl_xor (not_low, o);
+    }
+  if (lane < N)
+    {
+      call[site * N + lane] = called ? (int8_t) final_call : (int8_t) PCS_NG;
+      post_out[site * N + lane] = called ? final_p : 1.0;
+    }
+  int n_all = 0, isdel = 0, isins = 0, type = 0;
+#pragma unroll
+  for (int a = 0; a < PCS_NA; a++)
+    if (ac6[a] > 0)
+      {
+        n_all++;
+        if (a == 4)
+          isdel = 1;
+        else if (a == 5)
+          isins = 1;
+        else if (a != dom)
+          type = 1;
+      }
+  int dom_count = 0;
+#pragma unroll
+  for (int a = 0; a < PCS_NA; a++)
+    dom_count = (a == dom) ? ac6[a] : dom_count;
+  if (n_all > 1 || (n_all > 0 && dom_count < 1))
+    {
+      if ((double) off_target / (double) (on_target + off_target) > 0.15)
+        type = 6;
+      else if (n_all > 2)
+        type = 5;
+      else if (not_low > 0)
+        type = isdel ? 2 : isins ? 3 : 1;
+      else
+        type = 4;
+    }
+  int mine = 0;
+#pragma unroll
+  for (int a = 0; a < PCS_NA; a++)
+    mine = (lane == a) ? ac6[a] : mine;
+  if (lane < PCS_NA)
+    allele_count[site * PCS_NA + lane] = mine;
+  // ---- de-novo events among the confident calls (pecaller.c:1650-1671): the row's type gets a DENOVO_ prefix
+  int dcount = 0;
+  if (type && P.use_ped)
+    {
+      const int fc = called ? final_call : PCS_NG;
+      const double fp = called ? final_p : 1.0;
+      const int d = lane < N ? P.dad[lane] : -1, m = lane < N ? P.mom[lane] : -1;
+      const int dfc = __shfl (fc, d >= 0 ? d : 0), mfc = __shfl (fc, m >= 0 ? m : 0);
+      const double dfp = __hiloint2double (__shfl (__double2hiint (fp), d >= 0 ? d : 0), __shfl (__double2loint (fp), d >= 0 ? d : 0));
+      const double mfp = __hiloint2double (__shfl (__double2hiint (fp), m >= 0 ? m : 0), __shfl (__double2loint (fp), m >= 0 ? m : 0));
+      if (lane < N && fp >= P.threshold)
+        dcount = pcs_add_denovo (P, fc, (d >= 0 && dfp >= P.threshold) ? dfc : PCS_NG, (m >= 0 && mfp >= P.threshold) ? mfc : PCS_NG, P.sex[lane],
+                                 chrom, dom);
+      for (int o = 32; o; o >>= 1)
+        dcount += __shfl_xor (dcount, o);
+    }
+  if (lane == 0)
+    {
+      type_out[site] = (int8_t) type;
+      n_pass[site] = (int8_t) pass;
+      denovo_out[site] = dcount;
+    }
+}
+
 #define PCS_BUCKETS 4           // parts of the list of columns left to the beam search (pcs_fast_kernel files, pcs_call_kernel walks them)
 // One wave per site.  Outputs are what the reference prints per row: call 0..13 or 14 (N), posterior,
 // site type (0 REF, 1 SNP, 2 DEL, 3 INS, 4 LOW, 5 MULTIALLELIC, 6 MESS; -1 = reference base not A/C/G/T, skipped),
@@ -1031,100 +1131,276 @@ __global__ __launch_bounds__ (64) void pcs_call_kernel (PcsParams P, const uint1
             }
           initial_call = final_call;
         }
-      // ---- calls and site classification (pecaller.c:1565-1636)
-      const double low_base = (8 > 0.4 * average_depth) ? 8 : 0.4 * average_depth;
-      int ac6[PCS_NA] = { 0, 0, 0, 0, 0, 0 }, on_target = 0, off_target = 0, not_low = 0;
-      const bool called = lane < N && tot > md;
-      if (called && final_p >= P.threshold)
-        {
-#pragma unroll
-          for (int a = 0; a < PCS_NA; a++)
-            {
-              const int k = pcs_ac (dom, final_call, a, P.haploid);
-              if (k)
-                {
-                  ac6[a] = k;
-                  on_target += r[a];
-                }
-              else if (a != dom || final_call != PCS_NA - 1)
-                off_target += r[a];
-            }
-          if (tot > low_base && final_call != dom)
-            not_low = 1;
-        }
-      for (int o = 32; o; o >>= 1)
-        {
-#pragma unroll
-          for (int a = 0; a < PCS_NA; a++)
-            ac6[a] += __shfl_xor (ac6[a], o);
-          on_target += __shfl_xor (on_target, o);
-          off_target += __shfl_xor (off_target, o);
-          not_low += __shfl_xor (not_low, o);
-        }
-      if (lane < N)
-        {
-          call[site * N + lane] = called ? (int8_t) final_call : (int8_t) PCS_NG;
-          post_out[site * N + lane] = called ? final_p : 1.0;
-        }
-      int n_all = 0, isdel = 0, isins = 0, type = 0;
-#pragma unroll
-      for (int a = 0; a < PCS_NA; a++)
-        if (ac6[a] > 0)
-          {
-            n_all++;
-            if (a == 4)
-              isdel = 1;
-            else if (a == 5)
-              isins = 1;
-            else if (a != dom)
-              type = 1;
-          }
-      int dom_count = 0;
-#pragma unroll
-      for (int a = 0; a < PCS_NA; a++)
-        dom_count = (a == dom) ? ac6[a] : dom_count;
-      if (n_all > 1 || (n_all > 0 && dom_count < 1))
-        {
-          if ((double) off_target / (double) (on_target + off_target) > 0.15)
-            type = 6;
-          else if (n_all > 2)
-            type = 5;
-          else if (not_low > 0)
-            type = isdel ? 2 : isins ? 3 : 1;
-          else
-            type = 4;
-        }
-      int mine = 0;
-#pragma unroll
-      for (int a = 0; a < PCS_NA; a++)
-        mine = (lane == a) ? ac6[a] : mine;
-      if (lane < PCS_NA)
-        allele_count[site * PCS_NA + lane] = mine;
-      // ---- de-novo events among the confident calls (pecaller.c:1650-1671): the row's type gets a DENOVO_ prefix
-      int dcount = 0;
-      if (type && P.use_ped)
-        {
-          const int fc = called ? final_call : PCS_NG;
-          const double fp = called ? final_p : 1.0;
-          const int d = lane < N ? P.dad[lane] : -1, m = lane < N ? P.mom[lane] : -1;
-          const int dfc = __shfl (fc, d >= 0 ? d : 0), mfc = __shfl (fc, m >= 0 ? m : 0);
-          const double dfp = __hiloint2double (__shfl (__double2hiint (fp), d >= 0 ? d : 0), __shfl (__double2loint (fp), d >= 0 ? d : 0));
-          const double mfp = __hiloint2double (__shfl (__double2hiint (fp), m >= 0 ? m : 0), __shfl (__double2loint (fp), m >= 0 ? m : 0));
-          if (lane < N && fp >= P.threshold)
-            dcount = pcs_add_denovo (P, fc, (d >= 0 && dfp >= P.threshold) ? dfc : PCS_NG, (m >= 0 && mfp >= P.threshold) ? mfc : PCS_NG, P.sex[lane],
-                                     chrom, dom);
-          for (int o = 32; o; o >>= 1)
-            dcount += __shfl_xor (dcount, o);
-        }
-      if (lane == 0)
-        {
-          type_out[site] = (int8_t) type;
-          n_pass[site] = (int8_t) pass;
-          denovo_out[site] = dcount;
-        }
+      pcs_write_site (P, site, lane, dom, chrom, r, tot, average_depth, final_call, final_p, pass, call, post_out, type_out, allele_count, n_pass, denovo_out);
       pcs_sync ();
     }
 }
+
+// ---- The columns with a few unsettled samples, without the pools.  In a column of BASELINE config 4 (64 samples, 30x) one or two
+// samples usually carry two or three error reads and miss the shortcut's 2.31-nat margin: 1.03 M of 2 M columns, each of which cost
+// pcs_call_kernel a whole wave with 36 KB of LDS for ~70 K cycles.  What the reference computes for such a column is small: the
+// samples are taken in descending order of margin, so the settled ones come first and leave the single all-reference configuration
+// as it is (the argument at pcs_call_kernel's replay: only its likelihood moves, by the rounding of (L - l) + l, sample by sample);
+// then each unsettled sample expands a list of one to four configurations by its 14 genotypes (fill_config_probs, pecaller.c:2511-
+// 2788) and the list is sorted and cut (clean_config_probs, 2248-2344); posteriors, marginals and calls follow (1423-1468).  Here the
+// wave that computed the column's likelihoods in pcs_fast_kernel does that on the spot: a configuration lives in a LANE (likelihood,
+// prior, posterior, allele counts, heterozygotes, the genotypes of the unsettled samples packed four bits each), a candidate
+// (configuration, genotype) is priced by its own lane exactly as pcs_expand prices it, the acceptance rule is replayed in candidate
+// order, the sort is a rank + ds_permute.  Every floating-point sum runs in the reference's order in one lane or in wave-uniform
+// registers.  The column is handed to pcs_call_kernel instead (-> false, nothing written) whenever the small form does not apply:
+// a pedigree, more than PCS_MINI_U unsettled samples, an unsettled sample whose margin is not below every settled one's (a real
+// variant carrier: it would come first in the order), a list that grows past four configurations before the last expansion, no
+// homozygous configuration left after a cut (the fallback of 2286-2333), or calls that change (a second pass).
+#define PCS_MINI_U 4
+__device__ __forceinline__ int pcs_pack_ac (const int (&ac)[PCS_NA], int which)
+{
+  return which ? (ac[3] | (ac[4] << 8) | (ac[5] << 16)) : (ac[0] | (ac[1] << 8) | (ac[2] << 16));
+}
+
+__device__ bool pcs_mini_beam (const PcsParams & P, const double *tab_unused, const double (&lk)[PCS_NG], const int (&r)[PCS_NA], bool deep, bool ok, int best,
+                               double margin, int dom, int site_hap, uint8_t * w_sord, double *w_like, int lane, int &final_call, double &final_p)
+{
+  const int N = P.indiv, G = P.max_gen;
+  const unsigned long long deep_m = __ballot (deep), unset_m = __ballot (deep && !ok);
+  const int nu = __popcll (unset_m);
+  if (P.use_ped || nu > PCS_MINI_U || nu == 0)
+    return false;
+  if ((int) __popcll (deep_m) * (site_hap ? 1 : 2) > 255)
+    return false;               // (allele counts are packed in bytes here)
+  // ---- the order of the samples: margin descending, sample index ascending on ties (sort_compare_sample_pointer; the sort is stable)
+  const double ip = deep ? margin : -1.0;        // (the samples under the depth floor last: they take no part in the beam)
+  int rank = 0;
+  for (int jn = 0; jn < N; jn++)
+    {
+      const double pj = pcs_bcast (ip, jn);
+      rank += (pj > ip) || (pj == ip && jn < lane);
+    }
+  const int n_set = (int) __popcll (deep_m & ~unset_m);
+  // the unsettled samples must follow every settled one (the leading run of settled samples is then all of them)
+  if (__any (deep && !ok && rank < n_set))
+    return false;
+  if (lane < N)
+    w_sord[rank] = (uint8_t) lane;
+  pcs_sync ();
+  const int sord = (int) w_sord[lane];
+  // ---- fill_config_like of the all-reference configuration (pecaller.c:2347-2360): the deep samples' likelihoods of `dom`, in
+  //      sample order; then the settled samples' expansions, each of which leaves (L - l) + l
+  double lk_dom = 0.0;
+#pragma unroll
+  for (int g = 0; g < 4; g++)
+    lk_dom = (g == dom) ? lk[g] : lk_dom;
+  double L = 0.0;
+  for (int i = 0; i < N; i++)
+    if ((deep_m >> i) & 1ull)
+      L += pcs_bcast (lk_dom, i);
+  for (int k = 0; k < n_set; k++)
+    {
+      const double l = pcs_bcast (lk_dom, pcs_bcast (sord, k));
+      L = (L - l) + l;
+    }
+  // ---- the list: configuration i in lane i
+  double c_like = L, c_prior = 0.0, c_post = 0.0 + L;
+  int c_ac0, c_ac1, c_misc = 1 << 8;   // misc: hets | nall << 8 | genotypes of the unsettled samples << 12
+  {
+    int ac[PCS_NA] = { 0, 0, 0, 0, 0, 0 };
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      ac[k] = (k == dom) ? (int) __popcll (deep_m) * (site_hap ? 1 : 2) : 0;
+    c_ac0 = pcs_pack_ac (ac, 0);
+    c_ac1 = pcs_pack_ac (ac, 1);
+  }
+  int n = 1;
+  const double thres = 2.3;
+  for (int t = 0; t < nu; t++)
+    {
+      if (n > 4)
+        return false;
+      const int who = pcs_bcast (sord, n_set + t);
+      // the sample's likelihoods, where every lane can index them
+      pcs_sync ();
+      if (lane == who)
+        {
+#pragma unroll
+          for (int g = 0; g < PCS_NG; g++)
+            w_like[g] = lk[g];
+        }
+      pcs_sync ();
+      const int r4 = pcs_bcast (r[4], who), r5 = pcs_bcast (r[5], who);
+      double best_post = pcs_bcast (c_post, 0), best_like = pcs_bcast (c_like, 0);
+      // ---- every candidate (configuration, genotype) priced by its own lane (pcs_expand; the sample's old genotype is `dom`)
+      const int total = n * G;
+      const bool in = lane < total;
+      const int pos = in ? lane / G : 0, jj = in ? lane - pos * G : 0;
+      const int j = pcs_order (dom, jj, P.haploid);
+      const double s_like = __hiloint2double (__shfl (__double2hiint (c_like), pos), __shfl (__double2loint (c_like), pos));
+      const int s_ac0 = __shfl (c_ac0, pos), s_ac1 = __shfl (c_ac1, pos), s_misc = __shfl (c_misc, pos);
+      double base = s_like;
+      base -= w_like[dom];
+      double templ = base + w_like[j];
+      if ((j == 4 || j == 12) && r4 < 3)
+        templ -= 1e10;
+      if ((j == 13 || j == 5) && r5 < 3)
+        templ -= 1e10;
+      int ac[PCS_NA], nall = 0;
+      int oa = dom, ob = dom, na, nb;
+      pcs_het (j, na, nb, dom);
+      if (P.haploid)
+        {
+          ob = -1;
+          nb = -1;
+        }
+#pragma unroll
+      for (int k = 0; k < PCS_NA; k++)
+        {
+          const int old = ((k < 3 ? s_ac0 : s_ac1) >> (8 * (k % 3))) & 0xFF;
+          ac[k] = old - (k == oa) - (k == ob) + (k == na) + (k == nb);
+          nall += ac[k] > 0;
+        }
+      const int hets = (s_misc & 0xFF) + (j >= PCS_NA ? 1 : 0);
+      double prior = 0;
+      if (nall > 1)
+        prior = (nall - 1) * P.ln_theta;
+      if (!site_hap && nall > 1)
+        {
+          int major = 0, minor = 0;
+#pragma unroll
+          for (int k = 1; k < PCS_NA; k++)
+            if (ac[k] > ac[major])
+              major = k;
+#pragma unroll
+          for (int k = 0; k < PCS_NA; k++)
+            if (k != major)
+              minor += ac[k];
+          int mj = 0;
+#pragma unroll
+          for (int k = 0; k < PCS_NA; k++)
+            mj = (k == major) ? ac[k] : mj;
+          major = mj;
+          if (minor > major)
+            {
+              const int sw = major;
+              major = minor;
+              minor = sw;
+            }
+          const int hh = min (minor, hets);
+          const int tot_n = (minor + major) / 2;
+          if ((minor - hh) % 2 == 1)
+            {
+              minor++;
+              major++;
+            }
+          if (in)
+            prior += P.hw[P.hw_off[tot_n] + (long) minor * (tot_n + 1) + hh];
+        }
+      const double post = prior + templ;
+      const int misc_new = hets | (nall << 8) | (s_misc & ~0xFFF) | (j << (12 + 4 * t));
+      const int ac0_new = pcs_pack_ac (ac, 0), ac1_new = pcs_pack_ac (ac, 1);
+      // ---- the acceptance rule in candidate order (pecaller.c:2628, 2738-2758); the kept ones become the new list, in that order
+      double n_like = 0, n_prior = 0, n_post = 0;
+      int n_ac0 = 0, n_ac1 = 0, n_misc = 0, newcount = 0;
+      unsigned long long m = __ballot (in && ((templ + thres > best_post) || (templ + 0.01 > best_like)));
+      while (m)
+        {
+          const int k = __ffsll ((long long) m) - 1;
+          m &= m - 1;
+          const double tt = pcs_bcast (templ, k), po = pcs_bcast (post, k);
+          if (!((tt + thres > best_post) || (tt + 0.01 > best_like)))
+            continue;
+          best_like = (tt > best_like) ? tt : best_like;
+          best_post = (po > best_post) ? po : best_post;
+          if (!(po + thres > best_post))
+            continue;
+          const double pr = pcs_bcast (prior, k);
+          const int a0 = pcs_bcast (ac0_new, k), a1 = pcs_bcast (ac1_new, k), mi = pcs_bcast (misc_new, k);
+          if (lane == newcount)
+            {
+              n_like = tt;
+              n_prior = pr;
+              n_post = po;
+              n_ac0 = a0;
+              n_ac1 = a1;
+              n_misc = mi;
+            }
+          newcount++;
+        }
+      // ---- clean_config_probs (pecaller.c:2248-2344): stable sort by posterior, descending; cut 2.3 nats below the best
+      int rk = 0;
+      for (int q = 0; q < newcount; q++)
+        {
+          const double pq = pcs_bcast (n_post, q);
+          rk += (pq > n_post) || (pq == n_post && q < lane);
+        }
+      const int dst = (lane < newcount ? rk : lane) * 4;        // (lanes beyond the list keep their place: a permutation of all 64)
+#define PCS_PUSH(x) __builtin_amdgcn_ds_permute (dst, (x))
+      c_like = __hiloint2double (PCS_PUSH (__double2hiint (n_like)), PCS_PUSH (__double2loint (n_like)));
+      c_prior = __hiloint2double (PCS_PUSH (__double2hiint (n_prior)), PCS_PUSH (__double2loint (n_prior)));
+      c_post = __hiloint2double (PCS_PUSH (__double2hiint (n_post)), PCS_PUSH (__double2loint (n_post)));
+      c_ac0 = PCS_PUSH (n_ac0);
+      c_ac1 = PCS_PUSH (n_ac1);
+      c_misc = PCS_PUSH (n_misc);
+#undef PCS_PUSH
+      int mx = newcount;        // (at most 56: max_configs = 514 is out of reach)
+      {
+        const double p0 = pcs_bcast (c_post, 0);
+        const unsigned long long cutm = __ballot (lane >= 1 && lane < mx && p0 > c_post + thres);
+        if (cutm)
+          mx = __ffsll ((long long) cutm) - 1;
+      }
+      if (!__any (lane < mx && ((c_misc >> 8) & 0xF) == 1))
+        return false;           // no homozygous configuration in the list: the reference adds one (2286-2333) -- pcs_call_kernel's case
+      n = mx;
+    }
+  // ---- posteriors of the configurations (pecaller.c:1423-1441)
+  double e;
+  {
+    const double max_post = pcs_bcast (c_post, 0);
+    const double dlt = c_post - max_post;
+    e = (lane < n && dlt > -40) ? exp (dlt) : 0;
+    double tot_post = 0;
+    for (int i = 0; i < n; i++)
+      tot_post += pcs_bcast (e, i);
+    e /= tot_post;
+  }
+  // ---- marginal posteriors and calls (pecaller.c:1443-1468), lane = sample: a settled sample is `dom` in every configuration
+  int my_t = -1;
+  for (int t = 0; t < nu; t++)
+    my_t = (pcs_bcast (sord, n_set + t) == lane) ? t : my_t;
+  int besti = 0;
+  double bestp = 0;
+  for (int g = 0; g < G; g++)
+    {
+      double acc = 0;
+      for (int i = 0; i < n; i++)
+        {
+          const double pi = pcs_bcast (e, i);
+          const int gi = pcs_bcast (c_misc, i);
+          const int mine = my_t >= 0 ? ((gi >> (12 + 4 * my_t)) & 0xF) : dom;
+          if (mine == g)
+            acc += pi;
+        }
+      if (g == 0 || acc > bestp)
+        {
+          besti = g;
+          bestp = acc;
+        }
+    }
+  bool changed = false;
+  if (deep)
+    {
+      final_p = bestp;
+      final_call = besti;
+      changed = final_call != best || final_p < P.threshold;
+    }
+  else
+    {
+      final_call = PCS_NG;
+      final_p = 1.0;
+    }
+  if (__any (changed) && N >= 4)
+    return false;               // a second pass (pecaller.c:1454-1471): the whole machinery
+  return true;
+}
+
 
 // ---- the columns every sample agrees on, without the beam.  One wave per column (lane = sample), eight columns per
 // workgroup round, the ln n! table (80 KB) and the four first-pass Dirichlet mean tables in the workgroup's LDS.  Per column:
@@ -1134,7 +1410,8 @@ __global__ __launch_bounds__ (64) void pcs_call_kernel (PcsParams P, const uint1
 // posterior 1 after one pass, site type REF -- and is written here; so are the columns the site filters drop (every call N,
 // zero passes) and the ones whose reference base is not A/C/G/T.  Everything else goes to slow_list for pcs_call_kernel.
 #define PCS_FAST_BLOCK 512
-#define PCS_FAST_LDS_BYTES ((PC_TABLE + 1 + 4 * PCS_NG * PCS_NA) * 8)
+#define PCS_FAST_WAVE_BYTES (64 + PCS_NG * 8 + 16)        // per wave: the samples' order, one sample's likelihoods (pcs_mini_beam)
+#define PCS_FAST_LDS_BYTES ((PC_TABLE + 1 + 4 * PCS_NG * PCS_NA) * 8 + (PCS_FAST_BLOCK / 64) * PCS_FAST_WAVE_BYTES)
 
 __global__ __launch_bounds__ (PCS_FAST_BLOCK) void pcs_fast_kernel (PcsParams P, const uint16_t * reads, const uint8_t * dom_of, const uint8_t * chrom_of,
                                                                     long n_sites, int8_t * call, double *post_out, int8_t * type_out,
@@ -1160,6 +1437,8 @@ __global__ __launch_bounds__ (PCS_FAST_BLOCK) void pcs_fast_kernel (PcsParams P,
     }
   __syncthreads ();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint8_t *w_sord = (uint8_t *) (mean + 4 * PCS_NG * PCS_NA) + (size_t) wave * PCS_FAST_WAVE_BYTES;
+  double *w_like = (double *) (w_sord + 64);
   const long stride = (long) gridDim.x * (PCS_FAST_BLOCK / 64);
   for (long site = (long) blockIdx.x * (PCS_FAST_BLOCK / 64) + wave; site < n_sites; site += stride)
     {
@@ -1193,43 +1472,55 @@ __global__ __launch_bounds__ (PCS_FAST_BLOCK) void pcs_fast_kernel (PcsParams P,
             {
               const bool deep = lane < N && tot > md;
               bool ok = true;
+              double lk[PCS_NG], margin = 0.0;
+              int best = PCS_NG;
               if (deep)
                 {
                   const double sc0 = (double) min (tot, 100);   // norm of pass 1 is 1
                   const double sc1 = (10 > sc0) ? 10 : sc0;
                   const double scale = (1000 < sc1) ? 1000 : sc1;
                   const double *mrow = mean + dom * PCS_NG * PCS_NA;
-                  double mx = -1e100, lk_dom = 0.0, second = -1e100;
-                  int best = PCS_NG;
-                  for (int g = 0; g < G; g++)
-                    {
-                      int tot_a = 0, tot_tot = 0;
-                      double cf = coef, lk = 0.0;
+                  double mx = -1e100;
 #pragma unroll
-                      for (int a = 0; a < PCS_NA; a++)
+                  for (int g = 0; g < PCS_NG; g++)
+                    {
+                      lk[g] = 0.0;
+                      if (g < G)
                         {
-                          const double cv = ceil (scale * mrow[g * PCS_NA + a]);
-                          const int ta = (int) ((1 > cv) ? 1 : cv);
-                          tot_a += ta;
-                          tot_tot += ta + r[a];
-                          cf -= pc_factln (tab, ta - 1);
-                          lk += pc_factln (tab, ta + r[a] - 1);
-                        }
-                      cf += pc_factln (tab, tot_a - 1);
-                      lk += cf;
-                      lk -= pc_factln (tab, tot_tot - 1);
-                      if (g == dom)
-                        lk_dom = lk;
-                      else
-                        second = (lk > second) ? lk : second;
-                      if (lk > mx)
-                        {
-                          best = g;
-                          mx = lk;
+                          int tot_a = 0, tot_tot = 0;
+                          double cf = coef, l = 0.0;
+#pragma unroll
+                          for (int a = 0; a < PCS_NA; a++)
+                            {
+                              const double cv = ceil (scale * mrow[g * PCS_NA + a]);
+                              const int ta = (int) ((1 > cv) ? 1 : cv);
+                              tot_a += ta;
+                              tot_tot += ta + r[a];
+                              cf -= pc_factln (tab, ta - 1);
+                              l += pc_factln (tab, ta + r[a] - 1);
+                            }
+                          cf += pc_factln (tab, tot_a - 1);
+                          l += cf;
+                          l -= pc_factln (tab, tot_tot - 1);
+                          lk[g] = l;
+                          if (l > mx)
+                            {
+                              best = g;
+                              mx = l;
+                            }
                         }
                     }
-                  // best genotype the reference homozygote, and its margin over every other one (initial_p) above 2.31
-                  ok = best == dom && (lk_dom - second) > 2.31;
+                  // initial_p: the margin of the best genotype over every other one (pecaller.c:2494-2504)
+                  margin = 1e100;
+#pragma unroll
+                  for (int g = 0; g < PCS_NG; g++)
+                    if (g < G && g != best)
+                      {
+                        const double dlt = mx - lk[g];
+                        margin = (dlt < margin) ? dlt : margin;
+                      }
+                  // best genotype the reference homozygote, and its margin above 2.31
+                  ok = best == dom && margin > 2.31;
                   my_call = dom;
                 }
               if (__all (ok))
@@ -1241,6 +1532,15 @@ __global__ __launch_bounds__ (PCS_FAST_BLOCK) void pcs_fast_kernel (PcsParams P,
                 }
               else
                 {
+                  // a few unsettled samples: the small beam, here and now (pcs_mini_beam); anything else is listed for pcs_call_kernel
+                  int fc = PCS_NG;
+                  double fp = 1.0;
+                  const int site_hap = P.haploid | ((chrom_of[site] >> 4) & 1);
+                  if (pcs_mini_beam (P, tab, lk, r, deep, ok, best, margin, dom, site_hap, w_sord, w_like, lane, fc, fp))
+                    {
+                      pcs_write_site (P, site, lane, dom, chrom, r, tot, average_depth, fc, fp, 1, call, post_out, type_out, allele_count, n_pass, denovo_out);
+                      continue;
+                    }
                   decided = 0;
                   n_unset = (int) __popcll (__ballot (!ok));
                 }

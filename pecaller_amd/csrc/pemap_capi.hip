@@ -63,12 +63,11 @@ struct PmKnobs
   int seed_blocks_per_cu, big_blocks_per_cu, sw_waves_per_cu;
   int replicas;                 // -1 unset, 0 never, 1 as the default
   int gapless;                  // 0 off, 1 first case only, 2 both
-  int sw_lanes;                 // 0 unset
   double dir_budget_gb;
-  int lookup_lds_pad_kb, lookup_waves /* -1 unset */, lookup_v, lookup_batch /* -1 unset */;
+  int lookup_waves /* -1 unset */;
   int lookup_prio, vote_prio, sw_prio;
   int rest_stream3;
-  int vote_rest_on_alu, vote_waves, vote_persist /* -1 unset */;
+  int vote_rest_on_alu, vote_waves;
   int walk_blocks_per_cu, pile_blocks_per_cu;
   int mem_cus, mem_prio;
   int pipeline, walk_on_mem, vote_on_mem /* -1 unset */;
@@ -78,7 +77,7 @@ struct PmKnobs
   int d2h_stream;               // 1: the results of a submitted batch return on a stream of their own instead of the ALU stream
   int gapless_blocks_per_cu;
   int band, band_waves_per_cu;  // the banded DP (pm_band_kernel) for the problems it is exact for; its waves per CU
-  int seed_phase, vote_probe;   // always 0 without PEMAP_TIMING_PROBES
+  int seed_phase;               // always 0 without PEMAP_TIMING_PROBES
 };
 
 static int env_int (const char *name, int dflt)
@@ -98,19 +97,15 @@ static void read_knobs (PmKnobs & k)
   if (k.sw_waves_per_cu < 1) k.sw_waves_per_cu = 1;
   k.replicas = getenv ("PEMAP_REPLICAS") ? (env_int ("PEMAP_REPLICAS", 1) ? 1 : 0) : -1;
   k.gapless = env_int ("PEMAP_GAPLESS", 2);
-  k.sw_lanes = env_int ("PEMAP_SW_LANES", 0);
   { const char *e = getenv ("PEMAP_DIR_BUDGET_GB"); k.dir_budget_gb = e ? atof (e) : 40.0; if (k.dir_budget_gb < 0.25) k.dir_budget_gb = 0.25; }
-  k.lookup_lds_pad_kb = env_int ("PEMAP_LOOKUP_LDS_PAD_KB", 20);
   k.lookup_waves = env_int ("PEMAP_LOOKUP_WAVES", -1);
-  k.lookup_v = env_int ("PEMAP_LOOKUP_V", 3);
-  k.lookup_batch = env_int ("PEMAP_LOOKUP_BATCH", -1);
   k.lookup_prio = env_int ("PEMAP_LOOKUP_PRIO", 0);
   k.vote_prio = env_int ("PEMAP_VOTE_PRIO", 0);
   k.sw_prio = env_int ("PEMAP_SW_PRIO", 0);
   k.vote_rest_on_alu = env_int ("PEMAP_VOTE_REST_ON_ALU", -1);       // -1 unset: 1 with the fused seed kernel, else 0
   k.rest_stream3 = env_int ("PEMAP_REST_STREAM3", 0);
   k.vote_waves = env_int ("PEMAP_VOTE_WAVES", 1024);
-  k.vote_persist = env_int ("PEMAP_VOTE_PERSIST", -1);
+  if (k.vote_waves < 1) k.vote_waves = 1;
   k.walk_blocks_per_cu = env_int ("PEMAP_WALK_BLOCKS_PER_CU", 4);
   k.pile_blocks_per_cu = env_int ("PEMAP_PILE_BLOCKS_PER_CU", 8);
   if (k.walk_blocks_per_cu < 1) k.walk_blocks_per_cu = 1;
@@ -129,10 +124,9 @@ static void read_knobs (PmKnobs & k)
   if (k.gapless_blocks_per_cu < 1) k.gapless_blocks_per_cu = 1;
   k.band_waves_per_cu = env_int ("PEMAP_BAND_WAVES_PER_CU", 12);
   if (k.band_waves_per_cu < 1) k.band_waves_per_cu = 1;
-  k.seed_phase = k.vote_probe = 0;
+  k.seed_phase = 0;
 #ifdef PEMAP_TIMING_PROBES
   k.seed_phase = env_int ("PEMAP_SEED_PHASE", 0);
-  k.vote_probe = env_int ("PEMAP_VOTE_PROBE", 0);
 #endif
 }
 
@@ -234,6 +228,7 @@ static inline PmPile pile_of (const pemap_dev * d)
   PmPile p;
   p.w = d->d_counts;
   p.plane_words = d->pile_plane_words;
+  p.genome = d->d_genome;
   return p;
 }
 
@@ -903,9 +898,10 @@ static int ensure_reads (pemap_dev * d, int n, int stride, int paired)
 }
 
 // SW geometry for the longest staged read L: lanes per alignment and W columns per lane, the smallest instantiation with
-// lanes * W >= L.  8 lanes by default (13 / 19 / 26 / 32 / 38 columns).  PEMAP_SW_LANES=16 gives reads over 152 bases 16 lanes
-// x 13 / 16 / 19 columns instead (three waves per SIMD instead of two or one, more steps per cell): measured equal on
-// 2 x 250 bases (112 ms of SW per 1 M pairs either way), so it stays an option.
+// lanes * W >= L.  8 lanes x 13 columns up to 104 bases.  Beyond that 16 lanes (x 10 / 13 / 16 / 19 columns): beside the gapless
+// rule the DP sees few problems per launch and the finer form wins (2 x 150 bp: 44.8 ms per step against 46.2 with 8 x 19;
+// 2 x 250 bp: 111.8 against 120.5 with 8 x 32); with the rule off (PEMAP_GAPLESS=0: every problem through the DP) reads of
+// 105..152 bases take 8 x 19, which was 18 % faster there.  (8 x 26 / 32 / 38 and 12 x 13 were measured equal or slower and are gone.)
 // PEMAP_GAPLESS=0: every problem goes through the DP (the rule of pm_gapless_kernel off); 1: its first case only (diagonals
 // with at most one mismatch); default 2: both cases
 static int pm_gapless_max_x (const pemap_dev * d)
@@ -920,21 +916,9 @@ static bool pm_gapless_on (const pemap_dev * d)
 
 static void pick_geom (const pemap_dev * d, int L, int *lanes, int *w)
 {
-  // PEMAP_SW_LANES unset: 16 lanes for reads over 104 bases when the gapless rule leaves the DP few problems per launch
-  // (2 x 150 bp: 44.8 ms per step against 46.2), 8 otherwise
-  const int lanes_env = d->kn.sw_lanes ? d->kn.sw_lanes : (pm_gapless_on (d) ? -16 : 0);
-  const bool want16 = lanes_env == 16 || lanes_env == -16;
-  // (the default leaves reads of up to 104 bases on 8 x 13; 2 x 250 bp: 111.8 ms per step with 16 lanes against 120.5)
-  const bool want12 = d->kn.sw_lanes == 12;
-  // experiment: 12 lanes x 13 columns, 5 alignments per wave, 128 VGPRs -> 4 waves per SIMD; measured 33 ms of SW per step
-  // alone against 27.5 for 8 x 19 and much worse beside the look-up waves (27 spilled VGPRs): not the default
-  if (want12 && L > 8 * 13 && L <= 12 * 13) { *lanes = 12; *w = 13; return; }
-  // 16 lanes x 10 columns for 105..160 bases: 4 alignments per wave, half the steps' work per wave -- for the few problems per
-  // launch the gapless rule leaves (4.4 K wave-loads of the 8 x 19 form against ~3 K resident waves: two or three rounds)
-  if (want16 && L > 8 * 13 && L <= 16 * 10) { *lanes = 16; *w = 10; return; }
   if (L <= 8 * 13) { *lanes = 8; *w = 13; }
-  else if (L <= 8 * 19) { *lanes = 8; *w = 19; }
-  else if (!want16) { *lanes = 8; *w = L <= 8 * 26 ? 26 : L <= 8 * 32 ? 32 : 38; }
+  else if (!pm_gapless_on (d) && L <= 8 * 19) { *lanes = 8; *w = 19; }
+  else if (L <= 16 * 10) { *lanes = 16; *w = 10; }
   else if (L <= 16 * 13) { *lanes = 16; *w = 13; }
   else if (L <= 16 * 16) { *lanes = 16; *w = 16; }
   else { *lanes = 16; *w = 19; }
@@ -1133,7 +1117,7 @@ static int seg_template (int L)
 // is the seed stage of this run the fused kernel (pm_seed3_kernel: look-ups and vote of a read-end in one wave)?
 static bool pm_fused (const pemap_dev * d)
 {
-  return d->n_rep == 8 && d->kn.lookup_v == 3 && d->kn.lookup_waves != 0;
+  return d->n_rep == 8;
 }
 
 static void launch_lookup (pemap_dev * d, const RunCtx & c, int slot, PmChunkCtr * cc, hipEvent_t * ev, bool split)
@@ -1147,31 +1131,17 @@ static void launch_lookup (pemap_dev * d, const RunCtx & c, int slot, PmChunkCtr
   // kernel makes the stamp the moment the look-up kernel can start, so that ev[0]..ev[1] is the kernel's own duration)
   hipLaunchKernelGGL (pm_nop_kernel, dim3 (1), dim3 (1), 0, st);
   hipEventRecord (ev[0], st);
-  // occupancy knob of the look-up kernel (diagnostic): dynamic LDS padding in KB limits its workgroups per CU, so that
-  // the latency-bound vote kernel running beside it keeps its wave slots
-  const unsigned pad = (unsigned) d->kn.lookup_lds_pad_kb * 1024u;    // 20 KB: 5 look-up workgroups per CU (swept: 8..44 KB)
-  // PEMAP_LOOKUP_WAVES=n (default 6, swept 2..24): n persistent one-wave workgroups per CU; 0 = the workgroup-per-end kernel
-  // PEMAP_LOOKUP_V (with replicas): 1 = pm_lookup_rep_kernel (default), 2 = the pipelined pm_lookup_rep2_kernel (measured
-  // slower: 68 ms per step at its best point, 3 waves per CU, against 65 -- see DESIGN.md)
-  const int lv = d->kn.lookup_v;
-  // waves per CU: 6 (with the replicas 4 was the optimum while the SW kernel scored every problem: one per SIMD; since the
-  // gapless rule took 78 % of its problems away the two streams balance at 6)
-  const int lw = d->kn.lookup_waves >= 0 ? d->kn.lookup_waves : (c.ix.n_rep == 8) ? (lv == 3 ? 5 : lv == 2 ? 3 : 6) : 6;
+  // PEMAP_LOOKUP_WAVES=n: n persistent one-wave workgroups per CU.  Default 5 for the fused kernel (the faster kernel at 6 or 7
+  // makes the slower step: DESIGN.md section 5), 6 for the reference's layout
+  const int lw = d->kn.lookup_waves > 0 ? d->kn.lookup_waves : (c.ix.n_rep == 8 ? 5 : 6);
   int lgrid = lw * d->n_cus;
   if (lgrid > c.b.n_ends)
     lgrid = c.b.n_ends;
-  // PEMAP_LOOKUP_BATCH: look-up rounds (x 64 lanes) a wave keeps in flight: 4, 8 or 16
-  const int lb = d->kn.lookup_batch >= 0 ? d->kn.lookup_batch : (c.ix.n_rep == 8 ? 8 : 4);
   const int lprio = d->kn.lookup_prio;
-#define PM_LKW(SM, B) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_lookup_wave_kernel < SM, B >), dim3 (lgrid), dim3 (64), 0, st, c.ix, c.b, c.prm, L, lprio)
-#define PM_LKR(SM, B) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_lookup_rep_kernel < SM, B >), dim3 (lgrid), dim3 (64), 0, st, c.ix, c.b, c.prm, L, lprio)
   const bool set2 = split && slot;
   const PmHits & H = set2 ? d->hits2 : d->hits;
-#define PM_LK(SM) do { if (lw > 0 && c.ix.n_rep == 8 && lv == 3) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_seed3_kernel < SM >), dim3 (lgrid), dim3 (64), sizeof (PmSeed3Shared < SM >), st, c.ix, c.b, c.prm, H, L, lprio); \
-    else if (lw > 0 && c.ix.n_rep == 8 && lv == 2) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_lookup_rep2_kernel < SM >), dim3 (lgrid), dim3 (64), sizeof (PmLookupRep2Shared < SM >), st, c.ix, c.b, c.prm, L, lprio); \
-    else if (lw > 0 && c.ix.n_rep == 8 && lb >= 8) PM_LKR (SM, 10); else if (lw > 0 && c.ix.n_rep == 8) PM_LKR (SM, 5); \
-    else if (lw > 0 && lb >= 16) PM_LKW (SM, 16); else if (lw > 0 && lb >= 8) PM_LKW (SM, 8); else if (lw > 0) PM_LKW (SM, 4); \
-    else hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_lookup_kernel < SM >), dim3 (c.b.n_ends), dim3 (PM_SEED_THREADS), pad, st, c.ix, c.b, c.prm, L); } while (0)
+#define PM_LK(SM) do { if (c.ix.n_rep == 8) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_seed3_kernel < SM >), dim3 (lgrid), dim3 (64), sizeof (PmSeed3Shared < SM >), st, c.ix, c.b, c.prm, H, L, lprio); \
+    else hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_lookup_wave_kernel < SM, 4 >), dim3 (lgrid), dim3 (64), 0, st, c.ix, c.b, c.prm, L, lprio); } while (0)
   switch (seg_template (c.L))
     {
     case 7: PM_LK (7); break;
@@ -1181,8 +1151,6 @@ static void launch_lookup (pemap_dev * d, const RunCtx & c, int slot, PmChunkCtr
     default: PM_LK (19); break;
     }
 #undef PM_LK
-#undef PM_LKW
-#undef PM_LKR
   hipEventRecord (ev[1], st);
   if (pm_fused (d))
     {
@@ -1220,27 +1188,18 @@ static void launch_vote (pemap_dev * d, const RunCtx & c, bool split, int slot, 
     }
   if (split)
     {
-      const int vote_probe = d->kn.vote_probe;     // timing probe, 0 unless built with -DPEMAP_TIMING_PROBES
       PmLists L = d->lists[slot];
       L.n_big = &cc->n_big;
       L.positions = &cc->positions;
-      // PEMAP_VOTE_WAVES=n: at most n one-wave workgroups per CU, each striding over the ends; 0 = the workgroup-per-end kernel.
-      // Default 1024 = one wave per end: the dispatcher then places vote waves wherever the look-up and SW waves of the
-      // other stream leave room (measured 71.6 ms per step against 74.9 with 12 persistent waves per CU)
+      // PEMAP_VOTE_WAVES=n: at most n one-wave workgroups per CU, each striding over the ends.  Default 1024 = one wave per end: the
+      // dispatcher then places vote waves wherever the look-up and SW waves of the other stream leave room (measured 71.6 ms per
+      // step against 74.9 with 12 persistent waves per CU)
       const int vw = d->kn.vote_waves;
       const int vprio = d->kn.vote_prio;
       int vgrid = vw * d->n_cus;
       if (vgrid > n_ends)
         vgrid = n_ends;
-      // PEMAP_VOTE_PERSIST=0 selects the lean one-end-per-wave form (120 VGPRs instead of 161).  A/B on one box, three runs each:
-      // 77.6 ms per step against 74.3 -- more resident vote waves take slots from the look-up waves -- so the fat form stays
-      // (with the look-up replicas the look-ups are off the critical path and the lean form wins: 55.3 ms against 56.2)
-      const int vpersist_env = d->kn.vote_persist;
-      const int vpersist = vpersist_env >= 0 ? vpersist_env : (c.ix.n_rep == 8 ? 0 : 1);
-#define PM_VT(SM) do { if (vw > 0 && vgrid == n_ends && !vpersist) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_vote_wave_kernel < SM, false >), dim3 (vgrid), dim3 (64), 0, st, c.ix, c.b, c.prm, H, L, vprio); \
-    else if (vw > 0) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_vote_wave_kernel < SM, true >), dim3 (vgrid), dim3 (64), 0, st, c.ix, c.b, c.prm, H, L, vprio); \
-    else hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_vote_kernel < SM >), dim3 (n_ends), dim3 (PM_SEED_THREADS), 0, st, c.ix, c.b, c.prm, \
-                                      H, tasks_s, tasks_m, ctr, L, vote_probe); } while (0)
+#define PM_VT(SM) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_vote_wave_kernel < SM >), dim3 (vgrid), dim3 (64), 0, st, c.ix, c.b, c.prm, H, L, vprio)
       // (the grid never exceeds the blocks d_seed_scratch holds a spill area for; the kernel checks it against its capacity too)
       const int bgrid = d->big_grid < d->scratch_blocks ? d->big_grid : d->scratch_blocks;
 #define PM_SEEDL(SM) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_seed_kernel < SM >), dim3 (bgrid), dim3 (PM_SEED_THREADS), 0, st, c.ix, c.b, \
@@ -1404,7 +1363,7 @@ static int absorb_run (pemap_dev * d)
 #ifdef PEMAP_TIMING_PROBES
   {
     // the fused seed kernel's phase probes (pemap_seed3.hip.h): cycles summed over waves, printed per run
-    unsigned long long pr[20], z[20] = { 0ull };
+    unsigned long long pr[32], z[32] = { 0ull };
     if (hipMemcpyFromSymbol (pr, HIP_SYMBOL (pm_s3_probe), sizeof pr) == hipSuccess)
       {
         unsigned long long tot = 0;
@@ -1417,6 +1376,8 @@ static int absorb_run (pemap_dev * d)
             for (int i = 0; i < 16; i++)
               fprintf (stderr, " %s %.1f%%", nm[i], 100.0 * (double) pr[i] / (double) tot);
             fprintf (stderr, " | total %.3f G wave-cycles | segments %llu, dropped for a too-many bucket %llu, of them by the k-mer's own bucket %llu\n", (double) tot / 1e9, pr[16], pr[17], pr[18]);
+            fprintf (stderr, "[pm_s3_probe] ends decoded %llu; to the big-end kernel: records' room %llu, list capacity %llu, candidates %llu | records of 2-3 / 4-7 / 8-15 / 16+ positions: %llu / %llu / %llu / %llu | "
+                     "ends with a record of 8+ %llu, of 16+ %llu, of 4+ %llu, with any record %llu\n", pr[20], pr[21], pr[22], pr[23], pr[24], pr[25], pr[26], pr[27], pr[28], pr[29], pr[30], pr[31]);
           }
         (void) hipMemcpyToSymbol (HIP_SYMBOL (pm_s3_probe), z, sizeof z);
       }
@@ -1755,17 +1716,13 @@ static int run_slice (pemap_dev * d, int first, int n, int sync, const hipEvent_
         int lanes, w;
         pick_geom (d, L, &lanes, &w);
 #define PM_CH(WW, LL) launch_chunk < WW, LL > (d, c, m1, m2, mt, split, slot, cc, ev)
-        if (lanes == 12)
-          PM_CH (13, 12);
-        else if (lanes == 8)
-          switch (w)
-            {
-            case 13: PM_CH (13, 8); break;
-            case 19: PM_CH (19, 8); break;
-            case 26: PM_CH (26, 8); break;
-            case 32: PM_CH (32, 8); break;
-            default: PM_CH (38, 8); break;
-            }
+        if (lanes == 8)
+          {
+            if (w == 13)
+              PM_CH (13, 8);
+            else
+              PM_CH (19, 8);
+          }
         else
           switch (w)
             {

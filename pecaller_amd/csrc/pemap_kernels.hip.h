@@ -38,33 +38,57 @@ struct PmIndex
 };
 
 // The pileup counters (the reference's all_base_list: six unsigned short columns per genome position, pemapper.c:156, 1840-1870).
-// Plane-major, 16 bits each, two positions to a word: counter (pos, col) is half (pos & 1) of word col * plane_words + (pos >> 1).
-// A read's ~150 increments then fall into ~23 lines of 64 bytes (4 planes x 300 bytes) instead of 57 with six u32 counters per
-// position side by side -- and every touched line goes back to HBM once.  The arithmetic is the reference's: 16 bits, wrapping.
-// Both halves are incremented with 32-bit atomics; the high half wraps by itself, the low half's wrap would carry into its
-// neighbour, so increments of a low half return the old value and take the carry back when they see 0xFFFF.
+// Plane-major, 16 bits each, two positions to a word: plane q of position pos is half (pos & 1) of word q * plane_words + (pos >> 1).
+// WHICH plane holds column col of a position depends on the reference letter there: for A / C / G / T (codes 0..3) the four base
+// columns are rotated so that the column of the reference base itself is plane 0, q = (col - code) & 3; for every other letter, and
+// for the Del / Ins columns 4 and 5, q = col.  Reads mostly agree with the reference, so the ~150 increments of a read fall into
+// the ~5 lines of plane 0 under it plus a line per mismatch -- 7 lines instead of ~23 with a plane per base (and 57 with six u32
+// counters per position side by side) -- and every touched line goes back to HBM once.  The arithmetic is the reference's: 16
+// bits, wrapping.  Both halves are incremented with 32-bit atomics; the high half wraps by itself, the low half's wrap would carry
+// into its neighbour, so increments of a low half return the old value and take the carry back when they see 0xFFFF.  A rotation
+// per position is a bijection on that position's counters: sums over ranks, totals and resets do not see it; the export undoes it.
 struct PmPile
 {
   uint32_t *w;
   size_t plane_words;
+  const uint8_t *genome;        // the letters the rotation follows
 };
 
-__device__ __forceinline__ void pm_pile_inc (const PmPile & p, size_t pos, int col)
+__device__ __forceinline__ int pm_pile_plane (uint8_t ref, int col)
 {
-  uint32_t *q = p.w + (size_t) col * p.plane_words + (pos >> 1);
-  if (pos & 1)
-    atomicAdd (q, 0x10000u);
+  const int rc = (ref == 'A') ? 0 : (ref == 'C') ? 1 : (ref == 'G') ? 2 : (ref == 'T') ? 3 : -1;
+  return (col > 3 || rc < 0) ? col : ((col - rc) & 3);
+}
+
+// word of the counter of (pos, plane q), and what a 32-bit add must add to it
+__device__ __forceinline__ uint32_t *pm_pile_word (const PmPile & p, size_t pos, int q)
+{
+  return p.w + (size_t) q * p.plane_words + (pos >> 1);
+}
+
+// `add` = 1 (the low half), 0x10000 (the high half) or 0x10001 (both halves of a word: two neighbouring positions)
+__device__ __forceinline__ void pm_pile_add (uint32_t * q, uint32_t add)
+{
+  if (!(add & 1u))
+    atomicAdd (q, add);
   else
     {
-      const uint32_t old = atomicAdd (q, 1u);
+      const uint32_t old = atomicAdd (q, add);
       if ((old & 0xFFFFu) == 0xFFFFu)
         atomicSub (q, 0x10000u);
     }
 }
 
+__device__ __forceinline__ void pm_pile_inc (const PmPile & p, size_t pos, int col)
+{
+  const int q = col > 3 ? col : pm_pile_plane (p.genome[pos], col);
+  pm_pile_add (pm_pile_word (p, pos, q), (pos & 1) ? 0x10000u : 1u);
+}
+
 __device__ __forceinline__ uint16_t pm_pile_get (const PmPile & p, size_t pos, int col)
 {
-  return (uint16_t) (p.w[(size_t) col * p.plane_words + (pos >> 1)] >> (16 * (pos & 1)));
+  const int q = col > 3 ? col : pm_pile_plane (p.genome[pos], col);
+  return (uint16_t) (p.w[(size_t) q * p.plane_words + (pos >> 1)] >> (16 * (pos & 1)));
 }
 
 // counters shared by the kernels of one run (zeroed at the start of every run)

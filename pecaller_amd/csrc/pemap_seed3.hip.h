@@ -31,6 +31,12 @@
 #ifndef PM_S3_RCAP
 #define PM_S3_RCAP 160          // positions next to candidate anchors, both strands together
 #endif
+#ifndef PM_S3_GRAB
+#define PM_S3_GRAB 1            // consecutive read-ends a wave takes per fetch of the work counter
+#endif
+#ifndef PM_S3_BIGCAP
+#define PM_S3_BIGCAP 0          // 1: reads of up to 160 bases get the long reads' list capacity too (2,048 per strand, 256 near candidates)
+#endif
 
 template < int SMAX > struct __align__ (16) PmSeed3Shared
 {
@@ -38,11 +44,11 @@ template < int SMAX > struct __align__ (16) PmSeed3Shared
   // positions a strand's list holds: 1,024 for reads of up to 160 bases (10 segments x 49 look-ups, most of them empty or single);
   // twice that for longer reads, whose 13..19 segments gather in proportion (2 x 250 bp: 5 % of the ends passed 1,024 and took the slow
   // monolithic kernel, half of that configuration's seed time)
-  static constexpr int CAP = SMAX <= 10 ? PM_SEED_CAP : 2 * PM_SEED_CAP;
+  static constexpr int CAP = (SMAX <= 10 && !PM_S3_BIGCAP) ? PM_SEED_CAP : 2 * PM_SEED_CAP;
   // cells of the bin table and positions kept next to candidate anchors: more of both for the longer reads' fuller lists
   static constexpr int NH_LOG2 = SMAX <= 10 ? PM_S3_NH_LOG2 : PM_S3_NH_LOG2 + 1;
   static constexpr int NH = 1 << NH_LOG2;
-  static constexpr int RCAP = SMAX <= 10 ? PM_S3_RCAP : 256;
+  static constexpr int RCAP = (SMAX <= 10 && !PM_S3_BIGCAP) ? PM_S3_RCAP : 256;
   union
   {
     uint32_t lines[SMAX * 128];         // ONE strand's SMAX x 8 lines of 16 entries (the other strand's wait in registers) ...
@@ -151,7 +157,9 @@ extern __shared__ __align__ (16) uint8_t pm_seed3_lds[];
 // Cycle probes of the kernel's phases (a library built with -DPEMAP_TIMING_PROBES only): per wave the core-clock cycles between
 // the marks below, summed over the grid into pm_s3_probe[]; pemap_capi.hip prints and clears them after every run.
 #ifdef PEMAP_TIMING_PROBES
-__device__ unsigned long long pm_s3_probe[20];      // 16 phases; 16..18: segments decoded, dropped (a too-many bucket), dropped by the k-mer's own bucket
+__device__ unsigned long long pm_s3_probe[32];      // 16 phases; 16..18: segments decoded, dropped (a too-many bucket), dropped by the k-mer's own bucket;
+                                                    // 20: ends decoded; 21..23: left to the big-end kernel by the records' room, the list capacity, the candidates' capacity;
+                                                    // 24..27: records of 2-3, 4-7, 8-15, 16+ positions; 28..31: ends with a record of 8+, of 16+, of 4+, with any record
 #define PM_S3_T(i) do { const unsigned long long t_ = __builtin_readcyclecounter (); pacc[i] += t_ - plast; plast = t_; } while (0)
 #else
 #define PM_S3_T(i) do { } while (0)
@@ -184,13 +192,21 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
   // (the grid size is read from the dispatch packet with a vector load: brought to a scalar register here, before the loop, or the
   // loop's first use of it carries a "wait for every outstanding load" into every iteration)
   const int grid_n = __builtin_amdgcn_readfirstlane ((int) gridDim.x);
+  // (PM_S3_GRAB ends per fetch: the counter counts blocks of that many consecutive ends; block b = ends [b * GRAB, (b + 1) * GRAB))
+  int blkR = blockIdx.x, idxR = 0;
   auto next_end = [&] ()->int
   {
-    return grid_n + (int) __builtin_amdgcn_readfirstlane ((int) (lane == 0 ? atomicAdd (out.next_end, 1u) : 0u));
+    const int e = blkR * PM_S3_GRAB + idxR;
+    if (++idxR == PM_S3_GRAB)
+      {
+        idxR = 0;
+        blkR = grid_n + (int) __builtin_amdgcn_readfirstlane ((int) (lane == 0 ? atomicAdd (out.next_end, 1u) : 0u));
+      }
+    return e;
   };
-  int eQ = blockIdx.x;
+  int eQ = next_end ();
   int eP = next_end ();
-  int eR = next_end ();
+  int eR = blkR * PM_S3_GRAB + idxR;          // (the end after the next two: its block is known, the fetch of the block after it is the loop's)
 
   uint8_t rb[5];                // the bytes of the end whose k-mers are formed next
   int rlen = 0;
@@ -309,7 +325,10 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
     e_out = -1;
   };
 #ifdef PEMAP_TIMING_PROBES
-  unsigned long long pacc[20] = { 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull };
+  unsigned long long pacc[32];
+  for (int i_ = 0; i_ < 32; i_++)
+    pacc[i_] = 0ull;
+  bool p_any4 = false, p_any8 = false, p_any16 = false;
   unsigned long long plast = __builtin_readcyclecounter ();
 #endif
   while (eQ < n_ends)
@@ -421,11 +440,25 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
             constexpr int strand = decltype (ST)::value;
             int &nf = strand ? nf1 : nf0;
             const uint32_t c = valid ? hdr.x : 0u;
+#ifdef PEMAP_TIMING_PROBES
+            pacc[24] += (unsigned long long) __popcll (__ballot (valid && c <= 3u));
+            pacc[25] += (unsigned long long) __popcll (__ballot (valid && c > 3u && c <= 7u));
+            pacc[26] += (unsigned long long) __popcll (__ballot (valid && c > 7u && c <= 15u));
+            pacc[27] += (unsigned long long) __popcll (__ballot (valid && c > 15u));
+            p_any4 = p_any4 || __ballot (valid && c > 3u) != 0ull;
+            p_any8 = p_any8 || __ballot (valid && c > 7u) != 0ull;
+            p_any16 = p_any16 || __ballot (valid && c > 15u) != 0ull;
+#endif
             const uint32_t incl = pm_wave_incl_sum (c);
             const int dst = nf + (int) (incl - c);
             nf += __builtin_amdgcn_readlane ((int) incl, 63);
             if (nf > limit)
-              big = true;       // (wave-uniform) nothing more is written for this end: it goes to the big-end list
+              {
+#ifdef PEMAP_TIMING_PROBES
+                pacc[21] += big ? 0ull : 1ull;
+#endif
+                big = true;     // (wave-uniform) nothing more is written for this end: it goes to the big-end list
+              }
             const bool wr = valid && !big;
             const int off = (seg < cuts || cuts == 0) ? seg * idepth : last_off;
             const uint32_t bias = (uint32_t) (PM_DIAG_BIAS - off);
@@ -634,6 +667,15 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
           PM_S3_T (4);
           T0 = nf0;
           T1 = nf1;
+#ifdef PEMAP_TIMING_PROBES
+          pacc[20] += 1ull;
+          pacc[22] += (!big && (T0 > SH::CAP || T1 > SH::CAP)) ? 1ull : 0ull;
+          pacc[28] += p_any8 ? 1ull : 0ull;
+          pacc[29] += p_any16 ? 1ull : 0ull;
+          pacc[30] += p_any4 ? 1ull : 0ull;
+          pacc[31] += (nm0 + nm1 > 0) ? 1ull : 0ull;
+          p_any4 = p_any8 = p_any16 = false;
+#endif
           big = big || T0 > SH::CAP || T1 > SH::CAP;
           // pemapper.c:2200-2207: a strand is not searched when every one of its segments holds more than max_hits positions
           {
@@ -646,11 +688,11 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
       //      end after the next two.  Both are issued here, ahead of the loads below and with this end's vote between them and the
       //      next wait on the memory counter: at the bottom of the loop they made every iteration wait for an atomic's round trip.
       // (atomicInc: the compiler's wave-aggregation of atomicAdd reads the result back at once; only lane 0's value is ever read)
-      uint32_t raw_next;
+      uint32_t raw_next = 0u;
       auto out_and_next = [&] ()
       {
         flush_out ();
-        if (lane == 0)
+        if (lane == 0 && idxR == PM_S3_GRAB - 1)
           raw_next = atomicInc (out.next_end, 0xFFFFFFFFu);
       };
       // ---- P: the next end's k-mers and line requests (its bytes arrived during the previous iteration); R: the bytes of the end after
@@ -789,7 +831,12 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
           pm_wave_sync ();
           PM_S3_T (8);
           if (nR > SH::RCAP)
-            big = true;         // a repeat: left to the monolithic kernel
+            {
+#ifdef PEMAP_TIMING_PROBES
+              pacc[23] += 1ull;
+#endif
+              big = true;       // a repeat: left to the monolithic kernel
+            }
           else
             {
               // tot_found of every candidate (pemapper.c:2241-2249): 1 + the later segments with a position within max_off of its
@@ -949,11 +996,18 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
       PM_S3_T (11);
       eQ = eP;
       eP = eR;
-      const int raw_s = __builtin_amdgcn_readfirstlane ((int) raw_next);
-      eR = grid_n + raw_s;
-      // (pinned to a scalar register HERE: left alone the compiler defers the read of the atomic's result to eR's first use, which
-      // comes right behind the next line requests -- and the in-order memory counter then waits for those as well)
-      asm volatile ("; work counter read %0"::"s" (raw_s));
+      if (idxR == PM_S3_GRAB - 1)
+        {
+          const int raw_s = __builtin_amdgcn_readfirstlane ((int) raw_next);
+          blkR = grid_n + raw_s;
+          idxR = 0;
+          // (pinned to a scalar register HERE: left alone the compiler defers the read of the atomic's result to eR's first use, which
+          // comes right behind the next line requests -- and the in-order memory counter then waits for those as well)
+          asm volatile ("; work counter read %0"::"s" (raw_s));
+        }
+      else
+        idxR++;
+      eR = blkR * PM_S3_GRAB + idxR;
       SQ = SP;
       lenQ = lenP;
       kQ = kP;
@@ -961,7 +1015,7 @@ template < int SMAX > __global__ __launch_bounds__ (64, SMAX <= 10 ? PM_S3_WAVES
   flush_out ();
 #ifdef PEMAP_TIMING_PROBES
   if (lane == 0)
-    for (int i = 0; i < 20; i++)
+    for (int i = 0; i < 32; i++)
       atomicAdd (&pm_s3_probe[i], pacc[i]);
 #endif
   if (lane == 0 && n_pos)

@@ -137,12 +137,11 @@ template < bool DIRS > __device__ __forceinline__ void pm_cell (const double s0,
 }
 
 // value of lane - 1.  Alignment groups of 8 or 16 lanes never straddle a DPP row: row_shr:1 (the first lane of a row reads
-// 0).  Other group sizes (12) do: wave_shr:1.  The first lane of every group overrides what it receives either way.
+// 0).  The first lane of every group overrides what it receives.
 template < int LPA > __device__ __forceinline__ uint32_t pm_from_left (uint32_t v)
 {
-  if (LPA == 8 || LPA == 16)
-    return (uint32_t) __builtin_amdgcn_update_dpp (0, (int) v, 0x111, 0xF, 0xF, true);
-  return (uint32_t) __builtin_amdgcn_update_dpp (0, (int) v, 0x138, 0xF, 0xF, true);
+  static_assert (LPA == 8 || LPA == 16, "alignment groups are half a DPP row or a whole one");
+  return (uint32_t) __builtin_amdgcn_update_dpp (0, (int) v, 0x111, 0xF, 0xF, true);
 }
 
 template < int LPA > __device__ __forceinline__ double pm_from_left (double v)
@@ -908,13 +907,7 @@ template < int W, int PM_LPA > __global__ __launch_bounds__ (256) void pm_walk_k
       int i1 = 0, ins_len = 0;
       unsigned long long *pw = path + (size_t) w * path_words;
       if (k & PM_GAPLESS)
-        {
-          // decided by pm_gapless_kernel: mm diagonal steps (code 0) from (plane 0, row i, column mm), no direction slab
-          for (int q = 0; q < (mm + 31) / 32; q++)
-            pw[q] = 0ull;
-          n_steps[w] = (uint16_t) mm;
-          continue;
-        }
+        continue;               // decided by pm_gapless_kernel: mm diagonal steps from (plane 0, row i, column mm), which pm_pile_kernel knows
       unsigned long long acc = 0;
       int ns = 0;
       while (i > 0 && j > 0)
@@ -992,7 +985,10 @@ template < int W, int PM_LPA > __global__ __launch_bounds__ (256) void pm_walk_k
     atomicAdd (&ctr->n_ins, nins);
 }
 
-// second half: the recorded steps of every alignment applied to the pileup (pemapper.c:1840-1870), one wave per alignment
+// second half: the recorded steps of every alignment applied to the pileup (pemapper.c:1840-1870), one wave per alignment.
+// An alignment decided by pm_gapless_kernel has no recorded steps: it is mm diagonal steps from (row sti, column mm).
+// Lane = step, so neighbouring lanes usually hold neighbouring positions of the same plane (PmPile: the plane of the reference
+// base), i.e. the two halves of one word: the even position's lane then adds to both halves at once and its neighbour stays out.
 __global__ __launch_bounds__ (256) void pm_pile_kernel (PmBatch b, PmHits h, const uint32_t * wins, PmCounters * ctr, PmPile counts,
                                                        const unsigned long long *path, int path_words, const uint16_t * n_steps)
 {
@@ -1009,7 +1005,8 @@ __global__ __launch_bounds__ (256) void pm_pile_kernel (PmBatch b, PmHits h, con
       const uint8_t *read = pm_read_ptr (b, end, &mm);
       const int orient = h.orient[o];
       const uint32_t gpos = h.gpos[o];
-      const int ns = n_steps[w];
+      const bool gapless = (h.stk[o] & PM_GAPLESS) != 0;
+      const int ns = gapless ? mm : (int) n_steps[w];
       const unsigned long long *pw = path + (size_t) w * path_words;
       int i = h.sti[o], j = mm;
       for (int s0 = 0; s0 < ns; s0 += 64)
@@ -1017,22 +1014,30 @@ __global__ __launch_bounds__ (256) void pm_pile_kernel (PmBatch b, PmHits h, con
           const int s = s0 + lane;
           int code = 3;
           if (s < ns)
-            code = (int) ((pw[s >> 5] >> (2 * (s & 31))) & 3ull);
+            code = gapless ? 0 : (int) ((pw[s >> 5] >> (2 * (s & 31))) & 3ull);
           const unsigned long long mi = __ballot (code == 0 || code == 1), mj = __ballot (code == 0 || code == 2);
           const int ib = i - __popcll (mi & below), jb = j - __popcll (mj & below);      // row and column before this step
+          uint32_t *q = nullptr;
+          const size_t pos = (size_t) gpos + (size_t) (ib - 1);
           if (code == 0)
             {
               const uint8_t ch = pm_oriented (read, mm, orient, jb - 1);
               const int slot = (ch == 'A') ? 0 : (ch == 'C') ? 1 : (ch == 'G') ? 2 : (ch == 'T') ? 3 : -1;       // pemapper.c:1850-1857
               if (slot >= 0)
-                pm_pile_inc (counts, (size_t) gpos + (size_t) (ib - 1), slot);
-              incs += slot >= 0;
+                q = pm_pile_word (counts, pos, pm_pile_plane (counts.genome[pos], slot));
             }
           else if (code == 1)
-            {
-              pm_pile_inc (counts, (size_t) gpos + (size_t) (ib - 1), 4);
-              incs++;
-            }
+            q = pm_pile_word (counts, pos, 4);
+          incs += q != nullptr;
+          // the walk runs towards lower positions: lane + 1 holds pos - 1 after a diagonal or vertical step; with pos odd the two
+          // share a word, and this lane (the high half) leaves its increment to that one (the low half's, which reads the old value)
+          const unsigned long long qn = __shfl_down ((unsigned long long) (uintptr_t) q, 1);
+          const unsigned long long qp = __shfl_up ((unsigned long long) (uintptr_t) q, 1);
+          const int odd_n = __shfl_down ((int) (pos & 1), 1), odd_p = __shfl_up ((int) (pos & 1), 1);
+          const bool give = q != nullptr && (pos & 1) && lane < 63 && qn == (unsigned long long) (uintptr_t) q && !odd_n;
+          const bool take = q != nullptr && !(pos & 1) && lane > 0 && qp == (unsigned long long) (uintptr_t) q && odd_p;
+          if (q != nullptr && !give)
+            pm_pile_add (q, take ? 0x10001u : (pos & 1) ? 0x10000u : 1u);
           i -= __popcll (mi);
           j -= __popcll (mj);
         }

@@ -89,8 +89,10 @@ def counts_to_u16(counts_i32):
 
 
 def pack_counts(counts_u16):
-    """[positions][6] u16 columns -> the device's layout: six planes, two positions to a word, each plane padded to a whole number
-    of 256-byte blocks (pemap_capi.hip: pile_plane_words)"""
+    """[positions][6] u16 columns -> six planes, two positions to a word, each plane padded to a whole number of 256-byte blocks
+    (pemap_capi.hip: pile_plane_words).  The device's planes additionally rotate the four base columns by the reference letter
+    (PmPile, pemap_kernels.hip.h) -- a bijection per position that the element-wise sum over ranks does not see; host-side
+    rehearsals (tests/test_dist_gloo.py) use this unrotated form"""
     n = counts_u16.shape[0]
     plane_words = ((n + 2) // 2 + 63) & ~63
     out = np.zeros((6, 2 * plane_words), np.uint16)

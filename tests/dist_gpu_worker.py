@@ -41,7 +41,7 @@ def main():
     cnt = pd.device_tensor(torch, dev, 4)
     # the reference's counters are unsigned short and wrap (pemapper.c:53-58): every rank starts 600 of them at 40,000, so that
     # the sum of two ranks passes 65,535 and the writer's truncation is what a single u16 counter would have done
-    # (words 0 .. 599 of the first plane: the low halves are the A counters of positions 0, 2, .. 1198)
+    # (words 0 .. 599 of the first plane: the low halves are the counters of positions 0, 2, .. 1198 in the reference base's column)
     cnt[:600] += 40000
     torch.cuda.synchronize()
     m1, m2, mt = dev.map_batch(r1[lo:hi], l1[lo:hi], r2[lo:hi], l2[lo:hi])

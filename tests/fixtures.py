@@ -82,6 +82,13 @@ def ins_to_named(ins, names, contigs):
     return sorted(out)
 
 
+def plane0_column(positions):
+    """column of the reference's six that the device keeps in plane 0 at these positions (PmPile, pemap_kernels.hip.h): the
+    reference base's own column where the letter is A / C / G / T, column A elsewhere"""
+    g = index()["genome"][positions]
+    return np.select([g == ord("A"), g == ord("C"), g == ord("G"), g == ord("T")], [0, 1, 2, 3], 0)
+
+
 def check_pileup_against_golden(name, counts):
     """counts: [gsize][6] u16.  Compares with the md5 / record count / column sums / sampled records of the reference run."""
     m = meta()[name]

@@ -30,9 +30,11 @@ def test_two_device_ranks_equal_one_process(tmp_path):
     assert np.array_equal(z["m1"], fixtures.golden_m("r150", 1)) and np.array_equal(z["m2"], fixtures.golden_m("r150", 2))
     counts = z["counts"].copy()
     # take the two ranks' 40,000 out again, modulo 2^16: the worker bumped the low halves of the first 600 words of plane 0,
-    # i.e. the A counters of positions 0, 2, .. 1198
-    bumped = counts[0:1200:2, 0].copy()
-    counts[0:1200:2, 0] = (bumped.astype(np.uint32) - 2 * 40000).astype(np.uint16)
+    # i.e. the counters of positions 0, 2, .. 1198 in the column of the reference base there (PmPile's rotation)
+    rows = np.arange(0, 1200, 2)
+    col = fixtures.plane0_column(rows)
+    bumped = counts[rows, col].copy()
+    counts[rows, col] = (bumped.astype(np.uint32) - 2 * 40000).astype(np.uint16)
     fixtures.check_pileup_against_golden("r150", counts)
     names, contigs = fixtures.genome()
     ins = sorted((int(p), bytes(s)) for p, s in zip(z["ins_pos"], z["ins_seq"]))

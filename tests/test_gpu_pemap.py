@@ -354,10 +354,11 @@ print("alias ok")
 
 def test_pileup_counters_wrap_like_unsigned_short():
     """the device keeps the reference's unsigned short counters two to a 32-bit word (PmPile) and increments them with 32-bit
-    atomics: a low half that passes 65,535 must wrap to 0 WITHOUT carrying into the counter that shares its word.  The A counters
-    of the first 40,000 even positions start at 65,535 (words of plane 0 preset to 0x0000FFFF through the torch view of the
-    buffer), the reads are mapped, and every column must be the golden pileup modulo 2^16 -- the odd positions' A counters, in the
-    high halves of those words, exactly the golden."""
+    atomics: a low half that passes 65,535 must wrap to 0 WITHOUT carrying into the counter that shares its word.  The plane-0
+    counters of the first 40,000 even positions start at 65,535 (words of plane 0 preset to 0x0000FFFF through the torch view of
+    the buffer; plane 0 holds the column of the reference base itself, fixtures.plane0_column), the reads are mapped -- most of
+    their increments land exactly there, many of them as one add to both halves of a word -- and every column must be the golden
+    pileup modulo 2^16; the odd positions' counters, in the high halves of those words, exactly the golden."""
     import subprocess
     import sys
     code = r'''
@@ -375,9 +376,11 @@ cnt[:20000] = 0xFFFF
 torch.cuda.synchronize()
 dev.map_batch(r1, l1, r2, l2)
 counts, _ = dev.fetch_pileup()
-bumped = counts[0:40000:2, 0].copy()
-assert (bumped != 65535).sum() > 2000          # the positions whose base is A and that a read covers (~3x coverage): those low halves did wrap
-counts[0:40000:2, 0] = (bumped.astype(np.uint32) + 1).astype(np.uint16)        # 65,535 + n = n - 1 modulo 2^16
+rows = np.arange(0, 40000, 2)
+col = fixtures.plane0_column(rows)
+bumped = counts[rows, col].copy()
+assert (bumped != 65535).sum() > 8000          # the positions a read covers and agrees with (~3x coverage): those low halves did wrap
+counts[rows, col] = (bumped.astype(np.uint32) + 1).astype(np.uint16)        # 65,535 + n = n - 1 modulo 2^16
 fixtures.check_pileup_against_golden("r150", counts)
 dev.close()
 print("wrap ok")
@@ -415,7 +418,9 @@ for name in ("r150", "r100"):
     dev.set_params(paired=s["paired"], min_dist=0, max_dist=500, min_align=0.85)
     dev.reset_pileup()
     m1, m2, mt = dev.map_batch(r1, l1, r2, l2)
-    assert (dev.run_stats()[0]["gapless"] == 0) == (os.environ.get("PEMAP_GAPLESS") == "0")
+    st = dev.run_stats()[0]
+    assert (st["gapless"] == 0) == (os.environ.get("PEMAP_GAPLESS") == "0")
+    assert (st["banded"] == 0) == (os.environ.get("PEMAP_BAND") == "0" or os.environ.get("PEMAP_GAPLESS") == "0")
     assert np.array_equal(m1, fixtures.golden_m(name, 1))
     if s["paired"]:
         assert np.array_equal(m2, fixtures.golden_m(name, 2))
@@ -425,9 +430,10 @@ dev.close()
 print("full dp ok")
 '''
     here = os.path.dirname(os.path.abspath(__file__))
-    # the full DP in the default pipeline; and the one-stream form of the pipeline (monolithic seed kernel on the reference's
-    # table layout), which shares no launch code with the default
-    for extra in (dict(PEMAP_GAPLESS="0"), dict(PEMAP_PIPELINE="0", PEMAP_REPLICAS="0")):
+    # the full DP in the default pipeline (8 lanes x 19 columns per alignment for 150 bases); the gapless rule without the banded
+    # DP behind it (what the rule leaves goes to the full DP, 16 lanes x 10); the two-stream pipeline's kernels on ONE stream; and
+    # the one-stream form with the monolithic seed kernel on the reference's table layout, which shares no launch code with the default
+    for extra in (dict(PEMAP_GAPLESS="0"), dict(PEMAP_BAND="0"), dict(PEMAP_PIPELINE="2"), dict(PEMAP_PIPELINE="0", PEMAP_REPLICAS="0")):
         env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.dirname(here), here]), **extra)
         r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
         assert r.returncode == 0 and b"full dp ok" in r.stdout, (extra, r.stdout[-2000:])
