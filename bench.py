@@ -65,14 +65,18 @@ def mapper_leg(dev, a, L, B, steps, warmup, rank, world, barrier, allmax, indel_
     """K steps of the mapping path on batches of B pairs of L-base reads: at the seam (host buffers in, results out) and on
     resident reads.  -> dict of rates, per-step kernel times and counters of the seam run (or of the resident run if seam=False)"""
     n_batches = steps + warmup
-    first_read = rank * B * n_batches
+    # at most --host-batches distinct batches exist (generated on the device, staged on the host, pinned); step k maps batch k modulo
+    # that number.  (Every batch of a run was distinct until round 3: (steps + warm-up) x 1 M x 2 x 160 B = 8 GB of pinned host memory
+    # per rank with the driver's 20 + 5 steps, 64 GB on an 8-GPU node.)
+    NB = max(1, min(n_batches, a.host_batches))
+    first_read = rank * B * NB
 
     def synth():
         if indel_read_frac > 0:
-            dev.synth_reads_indel(a.seed + seed_off, B * n_batches, L, paired=True, sub_rate=a.sub_rate, indel_read_frac=indel_read_frac,
+            dev.synth_reads_indel(a.seed + seed_off, B * NB, L, paired=True, sub_rate=a.sub_rate, indel_read_frac=indel_read_frac,
                                   first_read=first_read)
         else:
-            dev.synth_reads(a.seed + seed_off, B * n_batches, L, paired=True, sub_rate=a.sub_rate, indel_rate=a.indel_rate, first_read=first_read)
+            dev.synth_reads(a.seed + seed_off, B * NB, L, paired=True, sub_rate=a.sub_rate, indel_rate=a.indel_rate, first_read=first_read)
 
     out = {}
     synth()
@@ -91,7 +95,7 @@ def mapper_leg(dev, a, L, B, steps, warmup, rank, world, barrier, allmax, indel_
         def run(k_from, k_to, depth=2):
             tick = []
             for k in range(k_from, k_to):
-                s = slice(k * B, (k + 1) * B)
+                s = slice((k % NB) * B, (k % NB + 1) * B)
                 ta = time.perf_counter()
                 tick.append((k, dev.submit_batch(r1[s], l1[s], r2[s], l2[s])))
                 tb = time.perf_counter()
@@ -110,7 +114,8 @@ def mapper_leg(dev, a, L, B, steps, warmup, rank, world, barrier, allmax, indel_
         barrier()
         t0 = time.perf_counter()
         run(warmup, n_batches)
-        dt = allmax(time.perf_counter() - t0)
+        out["seam_dt_local"] = time.perf_counter() - t0
+        dt = allmax(out["seam_dt_local"])
         st, tm = dev.run_stats()        # totals over the K timed steps
         if trace:
             print("seam trace (ms):", trace, file=sys.stderr)
@@ -123,17 +128,21 @@ def mapper_leg(dev, a, L, B, steps, warmup, rank, world, barrier, allmax, indel_
     # ---- resident: reads already in HBM, results left there; the K steps queued back to back and synchronised once (the library
     #      pipelines the look-ups of a step's first chunk under the previous step's last chunk)
     for w in range(warmup):
-        dev.run_slice(w * B, B, sync=True)
+        dev.run_slice((w % NB) * B, B, sync=True)
     barrier()
     t0 = time.perf_counter()
     for s in range(steps):
-        dev.run_slice((warmup + s) * B, B, sync=False)
+        dev.run_slice(((warmup + s) % NB) * B, B, sync=False)
     dev.sync()
-    out["resident_dt"] = allmax(time.perf_counter() - t0)
+    out["resident_dt_local"] = time.perf_counter() - t0
+    out["resident_dt"] = allmax(out["resident_dt_local"])
+    out.setdefault("seam_dt_local", out["resident_dt_local"])
+    out.setdefault("mapped_frac", 0.0)
     if not seam:
         st, tm = dev.run_stats()
         out.update(stats=st, times=tm)
     out["host"] = host
+    out["host_batches"] = NB
     return out
 
 
@@ -238,6 +247,9 @@ def main():
                     help="columns per launch of the PECaller leg (a launch ends with its slowest column: the few hundred-configuration "
                          "variant columns take ~50-90 ms each on one wave, so short launches measure that tail, not the rate)")
     ap.add_argument("--pecall-cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--host-batches", type=int, default=4, help="distinct batches staged (and pinned) on the host; the steps cycle through them")
+    ap.add_argument("--allow-fallback", action="store_true",
+                    help="N > 1: do not fail when a rank had no room for the look-up replicas and maps from the reference's table (slower, same results)")
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--index-mode", default="bcast", choices=["bcast", "build"],
                     help="bcast: rank 0 builds, RCCL broadcast; build: every rank builds its own replica (tests)")
@@ -264,6 +276,15 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group(backend=a.backend, rank=rank, world_size=world)
     on_gpu = a.backend == "nccl"
+    if world > 1 and on_gpu:
+        # one small device collective NOW: RCCL's communicator, its buffers and torch's context are allocated before the library takes
+        # ~290 of the device's 309 GB (index + 128 GiB of look-up replicas + work arrays); afterwards nothing of size is allocated
+        warm = torch.ones(1 << 20, dtype=torch.int32, device="cuda")
+        dist.all_reduce(warm)
+        dist.broadcast(warm, src=0)
+        torch.cuda.synchronize()
+        assert int(warm[0].item()) == world
+        del warm
 
     def barrier():
         torch.cuda.synchronize()
@@ -293,9 +314,10 @@ def main():
         timings["index_build_s"] = time.time() - t0
     if world > 1 and a.index_mode == "bcast":
         t0 = time.time()
-        info = [dev.index_info() if rank == 0 else None]
-        dist.broadcast_object_list(info, src=0)
-        n_mers, gs, n_contigs, idepth = info[0]
+        # (four numbers as a tensor: no pickled-object collective on the path)
+        it = torch.tensor(list(dev.index_info()) if rank == 0 else [0, 0, 0, 0], dtype=torch.int64, device="cuda" if on_gpu else "cpu")
+        dist.broadcast(it, src=0)
+        n_mers, gs, n_contigs, idepth = (int(x) for x in it.tolist())
         if rank != 0:
             dev.index_alloc(n_mers, gs, n_contigs, idepth)
         # torch views of the library's device buffers: RCCL writes straight into the index the kernels read (a gloo rehearsal on
@@ -310,6 +332,25 @@ def main():
     dev.set_params(paired=True, min_dist=0, max_dist=500, min_align=0.85)
     timings["setup_s"] = time.time() - t_setup
 
+    def gather_ranks(vals):
+        """one row of numbers per rank -> list of rows on every rank (tensor all_gather: works under RCCL and gloo alike)"""
+        t = torch.tensor([float(v) for v in vals], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
+        if world == 1:
+            return [t.tolist()]
+        rows = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(rows, t)
+        return [r.tolist() for r in rows]
+    # every rank's layout and what is left of its HBM after set-up: a rank that had no room for the replicas maps from the reference's
+    # table at ~0.6x the rate and would set the max-over-ranks time -- the run fails rather than print that as the node's number
+    free_b, total_b = torch.cuda.mem_get_info()
+    setup_rows = gather_ranks([n_rep, free_b / 2.0 ** 30, total_b / 2.0 ** 30, timings["setup_s"]])
+    fell_back = [r for r, row in enumerate(setup_rows) if int(row[0]) != 8]
+    if world > 1 and fell_back and len(fell_back) < world and not a.allow_fallback and os.environ.get("PEMAP_REPLICAS") != "0":
+        if rank == 0:
+            print("bench.py: rank(s) %s map without the look-up replicas (free HBM per rank after set-up, GiB: %s); --allow-fallback accepts that"
+                  % (fell_back, [round(row[1], 1) for row in setup_rows]), file=sys.stderr)
+        raise SystemExit(3)
+
     B = a.batch_pairs
     tsw_only = a.config == "tsw250"
     TSW_L = 245                     # 250-base reads after pemapper_tsw's trims of 3 / 2 (pemapper_tsw.c:693-704; the golden's values)
@@ -322,6 +363,13 @@ def main():
         sec_leg = mapper_leg(dev, a, TSW_L, B, k, w, rank, world, barrier, allmax, indel_read_frac=0.05, seed_off=11, seam=tsw_only)
         sec_leg["steps"] = k
 
+    leg0 = sec_leg if tsw_only else main_leg
+    step_rows = gather_ranks([leg0["seam_dt_local"] / a.steps * 1e3, leg0["resident_dt_local"] / a.steps * 1e3, leg0["mapped_frac"],
+                              leg0["stats"]["big_ends"] / a.steps])
+    ranks = [{"rank": r, "lookup_replicas": int(setup_rows[r][0]), "hbm_free_after_setup_GiB": round(setup_rows[r][1], 1),
+              "hbm_total_GiB": round(setup_rows[r][2], 1), "setup_s": round(setup_rows[r][3], 2), "ms_per_step": round(step_rows[r][0], 3),
+              "resident_ms_per_step": round(step_rows[r][1], 3), "mapped_frac": round(step_rows[r][2], 4), "big_ends_per_step": int(step_rows[r][3])}
+             for r in range(world)]
     # ---- end of the run: the per-GPU pileup partials are summed (the reference's one shared all_base_list, pemapper.c:156)
     if world > 1:
         cnt = pd.device_tensor(torch, dev, 4)
@@ -369,7 +417,9 @@ def main():
                                    "2x%dbp paired-end reads, %d pairs per step per GPU" % (gs / 1e9, n_contigs, int(a.repeat_frac * 100), L, B),
                        "genome_size": gs, "n_mers": n_mers, "batch_pairs": B, "read_len": L, "sub_rate": a.sub_rate,
                        "indel_rate": a.indel_rate, "sharding": "reads split by rank, index replica per GPU",
-                       "lookup_replicas": n_rep, "lookup_record_bytes": rec_bytes},
+                       "lookup_replicas": min(r["lookup_replicas"] for r in ranks), "lookup_record_bytes": rec_bytes,
+                       "host_batches": leg["host_batches"]},
+            "ranks": ranks,
             "roofline": roof, "cpu_baseline": cpu, "timings": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in timings.items()},
             "counters_per_step": {k: int(v / steps) for k, v in leg["stats"].items()},
         }
@@ -442,7 +492,7 @@ def cpu_baseline(dev, a, B, leg, warmup):
 
     def sample(threads, seconds, batch):
         """the oracle on the first pairs of timed batch `batch`, compared with what the GPU returned for them through the seam"""
-        first = (warmup + batch) * B
+        first = ((warmup + batch) % leg["host_batches"]) * B
         g1, g2, gt = leg["results"][warmup + batch]
         n = 4000
         done = 0
@@ -509,9 +559,25 @@ def pecaller_leg(a):
     t_gen = time.time() - t0
     pc = PecallDev(0)
     pc.call_sites(reads[:20000], dom[:20000])        # warm-up: tables, allocations
+    # the seam: the columns and the result arrays are the host program's tile buffers -- allocated once and page-locked once, as
+    # pecaller_hip does (pecall_dev_pin_host; the reference allocates its per-slot arrays once too, pecaller.c:1149-1206) -- and
+    # every call moves host columns in and calls + posteriors out
+    out = pc.out_arrays(n, S)
+    for arr in (reads, dom) + out:
+        pc.pin_host(arr)
+    pc.call_sites(reads, dom, out=out)               # (device arrays of the full size, staging: allocated here)
     t0 = time.perf_counter()
-    call, post, typ, ac, npass = pc.call_sites(reads, dom)
+    call, post, typ, ac, npass = pc.call_sites(reads, dom, out=out)
     seam_dt = time.perf_counter() - t0
+    for arr in (reads, dom) + out:
+        pc.unpin_host(arr)
+    # the same call from pageable memory (the library stages through its own pinned buffers)
+    out2 = pc.out_arrays(n, S)
+    t0 = time.perf_counter()
+    c3, p3 = pc.call_sites(reads, dom, out=out2)[:2]
+    seam_pageable_dt = time.perf_counter() - t0
+    assert np.array_equal(c3, call) and np.array_equal(p3, post)
+    del out2, c3, p3
     pc.sites_stage(reads, dom)
     kms = [pc.sites_run() for _ in range(3)]
     kernel_ms = float(np.mean(kms))
@@ -546,8 +612,9 @@ def pecaller_leg(a):
         types_eq = types_eq and bool(np.array_equal(typ[s], otyp))
     achieved = PECALL_BYTES_PER_SITE * n / (kernel_ms * 1e-3) / 1e9
     return {"metric": "M pileup columns called/sec, 64 samples, 30x", "value": round(n / (kernel_ms * 1e-3) / 1e6, 4), "unit": "M columns/s",
-            "timed_region": "pcs_fast_kernel + pcs_call_kernel on columns resident in HBM (HIP events on their stream, mean of 3 launches)",
-            "seam_value": round(n / seam_dt / 1e6, 4), "seam_timed_region": "pecall_dev_call_sites: host columns in, calls + posteriors out (PCIe included)",
+            "timed_region": "pcs_fast_kernel + pcs_call_kernel on columns resident in HBM, in chunks of 2^18 columns on two streams (HIP events around all of them, mean of 3 runs)",
+            "seam_value": round(n / seam_dt / 1e6, 4), "seam_timed_region": "pecall_dev_call_sites: host columns in, calls + posteriors out (PCIe included; the caller's buffers page-locked once, copies and kernels of neighbouring chunks side by side)",
+            "seam_pageable_value": round(n / seam_pageable_dt / 1e6, 4),
             "dtype": "f64", "data": "synthetic", "n_gpus": 1,
             "config": {"workload": "%d pileup columns x %d samples, 30x Poisson depth, 0.4%% error, 1 variant/kb under HWE, seed 777, "
                                    "prob_to_call 0.95, theta 0.001, diploid, no pedigree" % (n, S), "generated_in_s": round(t_gen, 1)},

@@ -230,10 +230,17 @@ int pecall_dev_collect (pecall_dev * dev, int n_sites, int indiv, double *like, 
  *   site_type[n_sites]  (may be NULL) 0 reference, 1 SNP, 2 DEL, 3 INS, 4 LOW, 5 MULTIALLELIC, 6 MESS
  *   allele_count[n_sites][6], n_pass[n_sites]  (may be NULL) Allele_Counts of the .snp row; passes run
  *   denovo[n_sites]     (may be NULL) d_count of the row (pecaller.c:1650-1671): > 0 = the type is printed as DENOVO_<type>
- * indiv <= 64 (one lane per sample).  Text formatting and the merge of the pileup streams stay on the host. */
+ * indiv <= 64 (one lane per sample).  Text formatting and the merge of the pileup streams stay on the host.
+ * The columns travel in chunks of 2^18 (PECALL_CHUNK_LOG2): the host-to-device copy of chunk k + 1, the kernels of chunk k and the
+ * device-to-host copy of chunk k - 1 run side by side.  Arrays the caller page-locked with pecall_dev_pin_host are copied from and
+ * to directly; the others pass through pinned staging buffers of the object (host copies on a few threads). */
 int pecall_dev_call_sites (pecall_dev * dev, const uint16_t * reads, const uint8_t * ref_base, const uint8_t * chrom_type, long n_sites,
                            int indiv, int haploid, double threshold, double theta, int8_t * call, double *posterior,
                            int8_t * site_type, int32_t * allele_count, int8_t * n_pass, int32_t * denovo);
+/* Page-lock a host range the caller will hand to pecall_dev_call_sites again and again (its tile buffers): the same table of
+ * ranges as pemap_dev_pin_host's; a range stays until its last unpin.  Unpin before freeing the memory. */
+int pecall_dev_pin_host (pecall_dev * dev, const void *host_ptr, uint64_t n_bytes);
+int pecall_dev_unpin_host (pecall_dev * dev, const void *host_ptr);
 /* the same call in three steps (host->device, kernel, device->host): bench.py times the kernel on resident columns with them.
  * kernel_ms (may be NULL) receives the kernel's duration from HIP events on the object's stream. */
 int pecall_dev_sites_stage (pecall_dev * dev, const uint16_t * reads, const uint8_t * ref_base, const uint8_t * chrom_type, long n_sites,

@@ -9,6 +9,13 @@
 #include "pecall_site.hip.h"
 
 static char g_pc_err[512] = "";
+#define PCS_SLOTS 3             // staging buffers of the seam's pipeline (chunks in flight between the two host copies)
+
+// host ranges page-locked by the caller (one table for the library: pemap_capi.hip)
+bool pm_host_pin_lookup (const void *p, size_t bytes);
+bool pm_host_pin_range (const void *p, size_t bytes, hipStream_t copy_stream);
+int pm_host_unpin (const void *host_ptr);
+void pm_par_memcpy (char *dst, const char *src, size_t bytes);
 
 struct pecall_dev
 {
@@ -43,8 +50,16 @@ struct pecall_dev
   long staged_sites;
   int staged_indiv;
   hipEvent_t ev_site[2];
-  unsigned long long *d_next_site;      // work counter of the per-site kernel; behind it the PCS_BUCKETS counts of listed columns
+  unsigned long long *d_next_site;      // per chunk: work counter of the per-site kernel; behind it the PCS_BUCKETS counts of listed columns
+  int cap_chunks;
   unsigned *d_slow;             // columns left to the beam search
+  // the caller in chunks of columns (pcs_run_chunk): the shortcut kernel of chunk k + 1 runs beside the beam search of chunk k, and at
+  // the seam (pecall_dev_call_sites) beside the copies of the chunks around them
+  long chunk_sites;
+  hipStream_t stream_call, stream_h2d, stream_d2h;
+  hipEvent_t *ev_h2d, *ev_fast, *ev_call, *ev_d2h;     // [cap_chunks]
+  char *h_in[PCS_SLOTS], *h_out[PCS_SLOTS];            // pinned staging for callers whose buffers are not pinned
+  size_t h_in_bytes, h_out_bytes;
 };
 
 static int pc_fail (pecall_dev * d, const char *fmt, ...)
@@ -155,6 +170,30 @@ extern "C" void pecall_dev_destroy (pecall_dev * d)
     {
       hipEventDestroy (d->ev_site[0]);
       hipEventDestroy (d->ev_site[1]);
+    }
+  for (int k = 0; k < d->cap_chunks; k++)
+    {
+      hipEventDestroy (d->ev_h2d[k]);
+      hipEventDestroy (d->ev_fast[k]);
+      hipEventDestroy (d->ev_call[k]);
+      hipEventDestroy (d->ev_d2h[k]);
+    }
+  free (d->ev_h2d);
+  free (d->ev_fast);
+  free (d->ev_call);
+  free (d->ev_d2h);
+  for (int i = 0; i < PCS_SLOTS; i++)
+    {
+      if (d->h_in[i])
+        hipHostFree (d->h_in[i]);
+      if (d->h_out[i])
+        hipHostFree (d->h_out[i]);
+    }
+  if (d->stream_call)
+    {
+      hipStreamDestroy (d->stream_call);
+      hipStreamDestroy (d->stream_h2d);
+      hipStreamDestroy (d->stream_d2h);
     }
   hipStreamDestroy (d->stream);
   free (d);
@@ -471,13 +510,9 @@ extern "C" int pecall_dev_sites_stage (pecall_dev * d, const uint16_t * reads, c
   return 0;
 }
 
-extern "C" int pecall_dev_sites_run (pecall_dev * d, int haploid, double threshold, double theta, float *kernel_ms)
+// the parameter block of a call, after the checks the reference makes on its command line
+static int pcs_params (pecall_dev * d, int indiv, int haploid, double threshold, double theta, PcsParams & P)
 {
-  PCCHK (d, hipSetDevice (d->device));
-  const long n_sites = d->staged_sites;
-  const int indiv = d->staged_indiv;
-  if (n_sites <= 0)
-    return pc_fail (d, "sites_run: nothing staged");
   if (!(theta >= 1e-10 && theta <= 0.5))
     return pc_fail (d, "call_sites: theta %g outside [1e-10, 0.5] (pecaller.c:305-309)", theta);
   int rc;
@@ -487,7 +522,6 @@ extern "C" int pecall_dev_sites_run (pecall_dev * d, int haploid, double thresho
     return pc_fail (d, "call_sites: de-novo mutation rate %g above theta %g (pecaller.c:381-385)", d->denovo_rate, theta);
   if (d->ped_indiv && (rc = pcs_ensure_ped (d, haploid ? 1 : 0)))
     return rc;
-  PcsParams P;
   P.indiv = indiv;
   P.haploid = haploid ? 1 : 0;
   P.max_gen = haploid ? 6 : PCS_NG;     // pecaller.c:326-336
@@ -506,29 +540,101 @@ extern "C" int pecall_dev_sites_run (pecall_dev * d, int haploid, double thresho
   P.kid_list = (const uint8_t *) d->d_ped + 3 * PCS_MAXN + 72;
   P.dyad = d->d_dyad;
   P.trio = d->d_trio;
-  long grid = n_sites < d->site_grid ? n_sites : d->site_grid;
+  return 0;
+}
+
+// streams, per-chunk events and counters for n_sites columns
+static int pcs_ensure_chunks (pecall_dev * d, long n_sites)
+{
+  if (!d->chunk_sites)
+    {
+      const char *e = getenv ("PECALL_CHUNK_LOG2");
+      int lg = (e && *e) ? atoi (e) : 18;
+      if (lg < 8) lg = 8;
+      if (lg > 24) lg = 24;
+      d->chunk_sites = 1L << lg;
+    }
+  if (!d->stream_call)
+    {
+      PCCHK (d, hipStreamCreateWithFlags (&d->stream_call, hipStreamNonBlocking));
+      PCCHK (d, hipStreamCreateWithFlags (&d->stream_h2d, hipStreamNonBlocking));
+      PCCHK (d, hipStreamCreateWithFlags (&d->stream_d2h, hipStreamNonBlocking));
+      PCCHK (d, hipFuncSetAttribute ((const void *) pcs_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PCS_FAST_LDS_BYTES));
+    }
   if (!d->ev_site[0])
     {
       PCCHK (d, hipEventCreate (&d->ev_site[0]));
       PCCHK (d, hipEventCreate (&d->ev_site[1]));
     }
-  if (!d->d_next_site)
+  const int nch = (int) ((n_sites + d->chunk_sites - 1) / d->chunk_sites);
+  if (nch > d->cap_chunks)
     {
-      PCCHK (d, hipMalloc ((void **) &d->d_next_site, 4 * sizeof (unsigned long long)));
-      PCCHK (d, hipFuncSetAttribute ((const void *) pcs_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PCS_FAST_LDS_BYTES));
+      PCCHK (d, hipDeviceSynchronize ());
+      hipFree (d->d_next_site);
+      d->d_next_site = nullptr;
+      PCCHK (d, hipMalloc ((void **) &d->d_next_site, (size_t) nch * 4 * sizeof (unsigned long long)));
+      d->ev_h2d = (hipEvent_t *) realloc (d->ev_h2d, sizeof (hipEvent_t) * nch);
+      d->ev_fast = (hipEvent_t *) realloc (d->ev_fast, sizeof (hipEvent_t) * nch);
+      d->ev_call = (hipEvent_t *) realloc (d->ev_call, sizeof (hipEvent_t) * nch);
+      d->ev_d2h = (hipEvent_t *) realloc (d->ev_d2h, sizeof (hipEvent_t) * nch);
+      for (int k = d->cap_chunks; k < nch; k++)
+        {
+          PCCHK (d, hipEventCreateWithFlags (&d->ev_h2d[k], hipEventDisableTiming));
+          PCCHK (d, hipEventCreateWithFlags (&d->ev_fast[k], hipEventDisableTiming));
+          PCCHK (d, hipEventCreateWithFlags (&d->ev_call[k], hipEventDisableTiming));
+          PCCHK (d, hipEventCreateWithFlags (&d->ev_d2h[k], hipEventDisableTiming));
+        }
+      d->cap_chunks = nch;
     }
-  PCCHK (d, hipMemsetAsync (d->d_next_site, 0, 4 * sizeof (unsigned long long), d->stream));
-  PCCHK (d, hipEventRecord (d->ev_site[0], d->stream));
-  // the columns every sample agrees on are settled by pcs_fast_kernel; the rest, listed by it, go through the beam search
-  unsigned *n_slow = (unsigned *) (d->d_next_site + 1);
-  long fgrid = (n_sites + PCS_FAST_BLOCK / 64 - 1) / (PCS_FAST_BLOCK / 64);
+  return 0;
+}
+
+// the two kernels of chunk k = columns [off, off + m): the shortcut kernel (with the small beam) on the object's stream, the beam
+// search of the columns it lists on a stream of its own, so that it runs beside the next chunk's shortcut kernel
+static int pcs_run_chunk (pecall_dev * d, const PcsParams & P, int k, long off, long m)
+{
+  const int N = P.indiv;
+  unsigned long long *ctr = d->d_next_site + (size_t) k * 4;
+  unsigned *n_slow = (unsigned *) (ctr + 1);
+  unsigned *slow = d->d_slow + (size_t) PCS_BUCKETS * off;
+  PCCHK (d, hipMemsetAsync (ctr, 0, 4 * sizeof (unsigned long long), d->stream));
+  long fgrid = (m + PCS_FAST_BLOCK / 64 - 1) / (PCS_FAST_BLOCK / 64);
   if (fgrid > d->grid / 2)
     fgrid = d->grid / 2;        // one workgroup per CU: the ln n! table takes half its LDS
-  hipLaunchKernelGGL (pcs_fast_kernel, dim3 ((unsigned) fgrid), dim3 (PCS_FAST_BLOCK), PCS_FAST_LDS_BYTES, d->stream, P, d->d_sreads, d->d_dom, d->d_chromy,
-                      n_sites, d->d_call, d->d_post, d->d_type, d->d_ac, d->d_npass, d->d_den, d->d_slow, n_slow);
-  hipLaunchKernelGGL (pcs_call_kernel, dim3 ((unsigned) grid), dim3 (64), 0, d->stream, P, d->d_sreads, d->d_dom, d->d_chromy, n_sites, d->d_call,
-                      d->d_post, d->d_type, d->d_ac, d->d_npass, d->d_den, d->d_scratch, d->d_next_site, d->d_slow, n_slow);
+  hipLaunchKernelGGL (pcs_fast_kernel, dim3 ((unsigned) fgrid), dim3 (PCS_FAST_BLOCK), PCS_FAST_LDS_BYTES, d->stream, P, d->d_sreads + off * N * PCS_NA,
+                      d->d_dom + off, d->d_chromy + off, m, d->d_call + off * N, d->d_post + off * N, d->d_type + off, d->d_ac + off * PCS_NA, d->d_npass + off,
+                      d->d_den + off, slow, n_slow);
+  PCCHK (d, hipEventRecord (d->ev_fast[k], d->stream));
+  PCCHK (d, hipStreamWaitEvent (d->stream_call, d->ev_fast[k], 0));
+  const long grid = m < d->site_grid ? m : d->site_grid;
+  hipLaunchKernelGGL (pcs_call_kernel, dim3 ((unsigned) grid), dim3 (64), 0, d->stream_call, P, d->d_sreads + off * N * PCS_NA, d->d_dom + off, d->d_chromy + off,
+                      m, d->d_call + off * N, d->d_post + off * N, d->d_type + off, d->d_ac + off * PCS_NA, d->d_npass + off, d->d_den + off, d->d_scratch, ctr,
+                      slow, n_slow);
   PCCHK (d, hipGetLastError ());
+  PCCHK (d, hipEventRecord (d->ev_call[k], d->stream_call));
+  return 0;
+}
+
+extern "C" int pecall_dev_sites_run (pecall_dev * d, int haploid, double threshold, double theta, float *kernel_ms)
+{
+  PCCHK (d, hipSetDevice (d->device));
+  const long n_sites = d->staged_sites;
+  const int indiv = d->staged_indiv;
+  if (n_sites <= 0)
+    return pc_fail (d, "sites_run: nothing staged");
+  PcsParams P;
+  int rc = pcs_params (d, indiv, haploid, threshold, theta, P);
+  if (rc)
+    return rc;
+  if ((rc = pcs_ensure_chunks (d, n_sites)))
+    return rc;
+  PCCHK (d, hipEventRecord (d->ev_site[0], d->stream));
+  int k = 0;
+  for (long off = 0; off < n_sites; off += d->chunk_sites, k++)
+    if ((rc = pcs_run_chunk (d, P, k, off, n_sites - off < d->chunk_sites ? n_sites - off : d->chunk_sites)))
+      return rc;
+  // (the object's stream ends behind the last beam search: ev_site[1] closes the interval of both streams)
+  PCCHK (d, hipStreamWaitEvent (d->stream, d->ev_call[k - 1], 0));
   PCCHK (d, hipEventRecord (d->ev_site[1], d->stream));
   PCCHK (d, hipStreamSynchronize (d->stream));
   if (kernel_ms)
@@ -536,9 +642,15 @@ extern "C" int pecall_dev_sites_run (pecall_dev * d, int haploid, double thresho
   if (getenv ("PECALL_LIST_STATS"))
     {
       // how many columns the shortcut left to the beam search, by part of the list
-      unsigned c[PCS_BUCKETS];
-      if (hipMemcpy (c, n_slow, sizeof c, hipMemcpyDeviceToHost) == hipSuccess)
-        fprintf (stderr, "[pecall] %ld columns, listed for the beam by unsettled samples <3 / <8 / <20 / more: %u %u %u %u\n", n_sites, c[0], c[1], c[2], c[3]);
+      unsigned long long tot[PCS_BUCKETS] = { 0ull, 0ull, 0ull, 0ull };
+      for (int q = 0; q < k; q++)
+        {
+          unsigned c[PCS_BUCKETS];
+          if (hipMemcpy (c, (unsigned *) (d->d_next_site + (size_t) q * 4 + 1), sizeof c, hipMemcpyDeviceToHost) == hipSuccess)
+            for (int b = 0; b < PCS_BUCKETS; b++)
+              tot[b] += c[b];
+        }
+      fprintf (stderr, "[pecall] %ld columns, listed for the beam by unsettled samples <3 / <8 / <20 / more: %llu %llu %llu %llu\n", n_sites, tot[0], tot[1], tot[2], tot[3]);
     }
   return 0;
 }
@@ -565,16 +677,170 @@ extern "C" int pecall_dev_sites_collect (pecall_dev * d, int8_t * call, double *
   return 0;
 }
 
+extern "C" int pecall_dev_pin_host (pecall_dev * d, const void *host_ptr, uint64_t n_bytes)
+{
+  PCCHK (d, hipSetDevice (d->device));
+  if (!host_ptr || !n_bytes)
+    return pc_fail (d, "pin_host: empty range");
+  if (!pm_host_pin_range (host_ptr, (size_t) n_bytes, d->stream_h2d))
+    return pc_fail (d, "pin_host: hipHostRegister of %llu bytes failed", (unsigned long long) n_bytes);
+  return 0;
+}
+
+extern "C" int pecall_dev_unpin_host (pecall_dev * d, const void *host_ptr)
+{
+  PCCHK (d, hipSetDevice (d->device));
+  if (d->stream_h2d)
+    {
+      PCCHK (d, hipStreamSynchronize (d->stream_h2d));
+      PCCHK (d, hipStreamSynchronize (d->stream_d2h));
+    }
+  const int rc = pm_host_unpin (host_ptr);
+  if (rc == 1)
+    return pc_fail (d, "unpin_host: %p is not inside a range pinned through pecall_dev_pin_host", host_ptr);
+  if (rc == 2)
+    return pc_fail (d, "unpin_host: hipHostUnregister failed");
+  return 0;
+}
+
+// The seam: host columns in, calls and posteriors out.  The columns travel in chunks: the host-to-device copy of chunk k + 1, the
+// kernels of chunk k and the device-to-host copy of chunk k - 1 run side by side (three streams behind each other through events).
+// Buffers the caller pinned (pecall_dev_pin_host) are copied from and to directly; others pass through PCS_SLOTS pinned staging
+// buffers, filled and emptied by a few host threads (one core moves ~10 GB/s; a 64-sample column is 768 bytes in, ~620 out).
 extern "C" int pecall_dev_call_sites (pecall_dev * d, const uint16_t * reads, const uint8_t * ref_base, const uint8_t * chrom_type, long n_sites,
                                       int indiv, int haploid, double threshold, double theta, int8_t * call, double *posterior,
                                       int8_t * site_type, int32_t * allele_count, int8_t * n_pass, int32_t * denovo)
 {
-  if (!(theta >= 1e-10 && theta <= 0.5))
-    return pc_fail (d, "call_sites: theta %g outside [1e-10, 0.5] (pecaller.c:305-309)", theta);
-  int rc = pecall_dev_sites_stage (d, reads, ref_base, chrom_type, n_sites, indiv);
-  if (!rc)
-    rc = pecall_dev_sites_run (d, haploid, threshold, theta, nullptr);
-  if (!rc)
-    rc = pecall_dev_sites_collect (d, call, posterior, site_type, allele_count, n_pass, denovo);
-  return rc;
+  PCCHK (d, hipSetDevice (d->device));
+  if (n_sites <= 0 || indiv <= 0 || indiv > PCS_MAXN)
+    return pc_fail (d, "call_sites: n_sites %ld, indiv %d (1..%d samples per call)", n_sites, indiv, PCS_MAXN);
+  if (!reads || !ref_base || !call || !posterior)
+    return pc_fail (d, "call_sites: a required pointer is NULL");
+  // (the tables first: the parameter block carries their device addresses)
+  int rc = pcs_ensure (d, n_sites, indiv);
+  if (rc)
+    return rc;
+  PcsParams P;
+  if ((rc = pcs_params (d, indiv, haploid, threshold, theta, P)))
+    return rc;
+  if ((rc = pcs_ensure_chunks (d, n_sites)))
+    return rc;
+  d->staged_sites = n_sites;
+  d->staged_indiv = indiv;
+  const long C = d->chunk_sites;
+  const int nch = (int) ((n_sites + C - 1) / C);
+  const size_t N = (size_t) indiv;
+  // per column: in = reads + reference base + chromosome class; out = calls + posteriors + type + passes + allele counts + de-novo count
+  const size_t in_col = N * PCS_NA * 2 + 2, out_col = N * 9 + 2 + PCS_NA * 4 + 4;
+  const bool in_direct = pm_host_pin_lookup (reads, (size_t) n_sites * N * PCS_NA * 2) && pm_host_pin_lookup (ref_base, (size_t) n_sites)
+    && (!chrom_type || pm_host_pin_lookup (chrom_type, (size_t) n_sites));
+  const bool out_direct = pm_host_pin_lookup (call, (size_t) n_sites * N) && pm_host_pin_lookup (posterior, (size_t) n_sites * N * 8)
+    && (!site_type || pm_host_pin_lookup (site_type, (size_t) n_sites)) && (!allele_count || pm_host_pin_lookup (allele_count, (size_t) n_sites * PCS_NA * 4))
+    && (!n_pass || pm_host_pin_lookup (n_pass, (size_t) n_sites)) && (!denovo || pm_host_pin_lookup (denovo, (size_t) n_sites * 4));
+  const long cmax = n_sites < C ? n_sites : C;
+  if (!in_direct && d->h_in_bytes < (size_t) cmax * in_col)
+    for (int i = 0; i < PCS_SLOTS; i++)
+      {
+        if (d->h_in[i])
+          hipHostFree (d->h_in[i]);
+        d->h_in[i] = nullptr;
+        d->h_in_bytes = 0;
+        PCCHK (d, hipHostMalloc ((void **) &d->h_in[i], (size_t) C * in_col, hipHostMallocDefault));
+        if (i == PCS_SLOTS - 1)
+          d->h_in_bytes = (size_t) C * in_col;
+      }
+  if (!out_direct && d->h_out_bytes < (size_t) cmax * out_col)
+    for (int i = 0; i < PCS_SLOTS; i++)
+      {
+        if (d->h_out[i])
+          hipHostFree (d->h_out[i]);
+        d->h_out[i] = nullptr;
+        d->h_out_bytes = 0;
+        PCCHK (d, hipHostMalloc ((void **) &d->h_out[i], (size_t) C * out_col, hipHostMallocDefault));
+        if (i == PCS_SLOTS - 1)
+          d->h_out_bytes = (size_t) C * out_col;
+      }
+  // staging layout of a chunk of m columns: [reads][ref][chrom] and [call][posterior][type][passes][allele counts][de-novo]
+  auto finish = [&] (int j) -> int
+  {
+    // chunk j's results are on the host: from the staging slot to the caller's arrays
+    PCCHK (d, hipEventSynchronize (d->ev_d2h[j]));
+    if (out_direct)
+      return 0;
+    const long off = (long) j * C, m = n_sites - off < C ? n_sites - off : C;
+    const char *o = d->h_out[j % PCS_SLOTS];
+    pm_par_memcpy ((char *) (call + off * N), o, (size_t) m * N);
+    o += (size_t) m * N;
+    pm_par_memcpy ((char *) (posterior + off * N), o, (size_t) m * N * 8);
+    o += (size_t) m * N * 8;
+    if (site_type)
+      memcpy (site_type + off, o, (size_t) m);
+    o += m;
+    if (n_pass)
+      memcpy (n_pass + off, o, (size_t) m);
+    o += m;
+    if (allele_count)
+      memcpy (allele_count + off * PCS_NA, o, (size_t) m * PCS_NA * 4);
+    o += (size_t) m * PCS_NA * 4;
+    if (denovo)
+      memcpy (denovo + off, o, (size_t) m * 4);
+    return 0;
+  };
+  for (int k = 0; k < nch; k++)
+    {
+      const long off = (long) k * C, m = n_sites - off < C ? n_sites - off : C;
+      // ---- in: (a staging slot is free again when the chunk that used it PCS_SLOTS chunks ago has been copied to the device, and
+      //      its results have left the slot of the same number: finish (k - PCS_SLOTS) below ran before this)
+      const uint16_t *src_r = reads + off * N * PCS_NA;
+      const uint8_t *src_b = ref_base + off, *src_c = chrom_type ? chrom_type + off : nullptr;
+      if (!in_direct)
+        {
+          if (k >= PCS_SLOTS)
+            PCCHK (d, hipEventSynchronize (d->ev_h2d[k - PCS_SLOTS]));
+          char *st = d->h_in[k % PCS_SLOTS];
+          pm_par_memcpy (st, (const char *) src_r, (size_t) m * N * PCS_NA * 2);
+          src_r = (const uint16_t *) st;
+          st += (size_t) m * N * PCS_NA * 2;
+          memcpy (st, src_b, (size_t) m);
+          src_b = (const uint8_t *) st;
+          st += m;
+          if (src_c)
+            {
+              memcpy (st, src_c, (size_t) m);
+              src_c = (const uint8_t *) st;
+            }
+        }
+      PCCHK (d, hipMemcpyAsync (d->d_sreads + off * N * PCS_NA, src_r, (size_t) m * N * PCS_NA * 2, hipMemcpyHostToDevice, d->stream_h2d));
+      PCCHK (d, hipMemcpyAsync (d->d_dom + off, src_b, (size_t) m, hipMemcpyHostToDevice, d->stream_h2d));
+      if (src_c)
+        PCCHK (d, hipMemcpyAsync (d->d_chromy + off, src_c, (size_t) m, hipMemcpyHostToDevice, d->stream_h2d));
+      else
+        PCCHK (d, hipMemsetAsync (d->d_chromy + off, 0, (size_t) m, d->stream_h2d));
+      PCCHK (d, hipEventRecord (d->ev_h2d[k], d->stream_h2d));
+      // ---- the kernels
+      PCCHK (d, hipStreamWaitEvent (d->stream, d->ev_h2d[k], 0));
+      if ((rc = pcs_run_chunk (d, P, k, off, m)))
+        return rc;
+      // ---- out: behind the chunk's beam search (which follows its shortcut kernel)
+      PCCHK (d, hipStreamWaitEvent (d->stream_d2h, d->ev_call[k], 0));
+      if (!out_direct && k >= PCS_SLOTS && (rc = finish (k - PCS_SLOTS)))
+        return rc;
+      char *o = out_direct ? nullptr : d->h_out[k % PCS_SLOTS];
+#define PCS_OUT(dst_host, dev_ptr, bytes) do { void *dst_ = out_direct ? (void *) (dst_host) : (void *) o; if (out_direct ? (dst_host) != nullptr : true) \
+    PCCHK (d, hipMemcpyAsync (dst_, dev_ptr, bytes, hipMemcpyDeviceToHost, d->stream_d2h)); if (!out_direct) o += (bytes); } while (0)
+      PCS_OUT (call + off * N, d->d_call + off * N, (size_t) m * N);
+      PCS_OUT (posterior + off * N, d->d_post + off * N, (size_t) m * N * 8);
+      PCS_OUT (site_type ? site_type + off : nullptr, d->d_type + off, (size_t) m);
+      PCS_OUT (n_pass ? n_pass + off : nullptr, d->d_npass + off, (size_t) m);
+      PCS_OUT (allele_count ? allele_count + off * PCS_NA : nullptr, d->d_ac + off * PCS_NA, (size_t) m * PCS_NA * 4);
+      PCS_OUT (denovo ? denovo + off : nullptr, d->d_den + off, (size_t) m * 4);
+#undef PCS_OUT
+      PCCHK (d, hipEventRecord (d->ev_d2h[k], d->stream_d2h));
+    }
+  for (int j = (out_direct || nch < PCS_SLOTS) ? 0 : nch - PCS_SLOTS; j < nch; j++)
+    if ((rc = finish (j)))
+      return rc;
+  PCCHK (d, hipStreamSynchronize (d->stream));
+  PCCHK (d, hipStreamSynchronize (d->stream_call));
+  return 0;
 }

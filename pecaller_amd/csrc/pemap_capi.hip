@@ -122,7 +122,7 @@ static void read_knobs (PmKnobs & k)
   k.band = env_int ("PEMAP_BAND", 1);
   k.gapless_blocks_per_cu = env_int ("PEMAP_GAPLESS_BLOCKS_PER_CU", 16);
   if (k.gapless_blocks_per_cu < 1) k.gapless_blocks_per_cu = 1;
-  k.band_waves_per_cu = env_int ("PEMAP_BAND_WAVES_PER_CU", 12);
+  k.band_waves_per_cu = env_int ("PEMAP_BAND_WAVES_PER_CU", 16);
   if (k.band_waves_per_cu < 1) k.band_waves_per_cu = 1;
   k.seed_phase = 0;
 #ifdef PEMAP_TIMING_PROBES
@@ -1131,9 +1131,9 @@ static void launch_lookup (pemap_dev * d, const RunCtx & c, int slot, PmChunkCtr
   // kernel makes the stamp the moment the look-up kernel can start, so that ev[0]..ev[1] is the kernel's own duration)
   hipLaunchKernelGGL (pm_nop_kernel, dim3 (1), dim3 (1), 0, st);
   hipEventRecord (ev[0], st);
-  // PEMAP_LOOKUP_WAVES=n: n persistent one-wave workgroups per CU.  Default 5 for the fused kernel (the faster kernel at 6 or 7
-  // makes the slower step: DESIGN.md section 5), 6 for the reference's layout
-  const int lw = d->kn.lookup_waves > 0 ? d->kn.lookup_waves : (c.ix.n_rep == 8 ? 5 : 6);
+  // PEMAP_LOOKUP_WAVES=n: n persistent one-wave workgroups per CU.  Default 6 (the fused kernel alone is fastest with the 8 its LDS
+  // admits, the step with 6: what the seed waves gain beyond that the other stream's kernels lose)
+  const int lw = d->kn.lookup_waves > 0 ? d->kn.lookup_waves : 6;
   int lgrid = lw * d->n_cus;
   if (lgrid > c.b.n_ends)
     lgrid = c.b.n_ends;
@@ -1281,8 +1281,8 @@ template < int W, int LPA > static void launch_chunk (pemap_dev * d, const RunCt
       if (tasks_band)
         {
           // the problems the rule left open whose best diagonal has few mismatches: the DP restricted to a band of 32 diagonals,
-          // one lane per problem (pemap_band.hip.h); what is left for pm_sw_kernel are mostly the reads with a real indel
-          int bgrid = (n_ends + 63) / 64;
+          // four lanes per problem (pemap_band.hip.h); what is left for pm_sw_kernel are mostly the reads with a real indel
+          int bgrid = (n_ends + 15) / 16;
           if (bgrid > d->n_cus * d->kn.band_waves_per_cu)
             bgrid = d->n_cus * d->kn.band_waves_per_cu;
           hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_band_kernel < true >), dim3 (bgrid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, H, tasks_band,
@@ -1844,7 +1844,7 @@ static void fold_summary (pemap_dev * d, int first, int n, const uint32_t * m1, 
 }
 
 // is [p, p + bytes) inside a range pinned by the caller?
-static bool pin_lookup (const void *p, size_t bytes)
+bool pm_host_pin_lookup (const void *p, size_t bytes)
 {
   std::lock_guard < std::mutex > lk (g_pin_mu);
   const char *c = (const char *) p;
@@ -1857,7 +1857,7 @@ static bool pin_lookup (const void *p, size_t bytes)
 // register a host range for DMA on behalf of pemap_dev_pin_host.  Registered ranges that share pages with the new one are
 // replaced by the union of all of them (a copy must lie inside one registration); the calling object's copy stream is drained
 // before a registration is dropped, copies out of it may be queued.
-static bool pin_range (const void *p, size_t bytes, hipStream_t copy_stream)
+bool pm_host_pin_range (const void *p, size_t bytes, hipStream_t copy_stream)
 {
   std::lock_guard < std::mutex > lk (g_pin_mu);
   const size_t page = 4096;
@@ -1900,7 +1900,7 @@ static bool pin_range (const void *p, size_t bytes, hipStream_t copy_stream)
 }
 
 // host copy into a pinned staging buffer, on a few threads when it is large (one core moves ~10 GB/s: 330 MB per million pairs)
-static void par_memcpy (char *dst, const char *src, size_t bytes)
+void pm_par_memcpy (char *dst, const char *src, size_t bytes)
 {
   const size_t piece = (size_t) 4 << 20;
   if (bytes < 2 * piece)
@@ -1925,9 +1925,29 @@ extern "C" int pemap_dev_pin_host (pemap_dev * d, const void *host_ptr, uint64_t
   HIPCHK (d, hipSetDevice (d->device));
   if (!host_ptr || !n_bytes)
     return fail (d, "pin_host: empty range");
-  if (!pin_range (host_ptr, (size_t) n_bytes, d->stream_h2d))
+  if (!pm_host_pin_range (host_ptr, (size_t) n_bytes, d->stream_h2d))
     return fail (d, "pin_host: hipHostRegister of %llu bytes failed", (unsigned long long) n_bytes);
   return 0;
+}
+
+// undo one pm_host_pin_range of the range that holds host_ptr: 0 done, 1 not a pinned range, 2 the runtime refused
+int pm_host_unpin (const void *host_ptr)
+{
+  std::lock_guard < std::mutex > lk (g_pin_mu);
+  const char *c = (const char *) host_ptr;
+  for (size_t i = 0; i < g_pinned.size (); i++)
+    if (c >= g_pinned[i].base && c < g_pinned[i].base + g_pinned[i].bytes && g_pinned[i].users > 0)
+      {
+        if (--g_pinned[i].users == 0)
+          {
+            const hipError_t e = hipHostUnregister (g_pinned[i].base);
+            g_pinned.erase (g_pinned.begin () + i);
+            if (e != hipSuccess)
+              return 2;
+          }
+        return 0;
+      }
+  return 1;
 }
 
 extern "C" int pemap_dev_unpin_host (pemap_dev * d, const void *host_ptr)
@@ -1939,19 +1959,12 @@ extern "C" int pemap_dev_unpin_host (pemap_dev * d, const void *host_ptr)
     if (d->stream_h2d)
       HIPCHK (d, hipStreamSynchronize (d->stream_h2d));
   }
-  std::lock_guard < std::mutex > lk (g_pin_mu);
-  const char *c = (const char *) host_ptr;
-  for (size_t i = 0; i < g_pinned.size (); i++)
-    if (c >= g_pinned[i].base && c < g_pinned[i].base + g_pinned[i].bytes && g_pinned[i].users > 0)
-      {
-        if (--g_pinned[i].users == 0)
-          {
-            HIPCHK (d, hipHostUnregister (g_pinned[i].base));
-            g_pinned.erase (g_pinned.begin () + i);
-          }
-        return 0;
-      }
-  return fail (d, "unpin_host: %p is not inside a range pinned through pemap_dev_pin_host", host_ptr);
+  const int rc = pm_host_unpin (host_ptr);
+  if (rc == 1)
+    return fail (d, "unpin_host: %p is not inside a range pinned through pemap_dev_pin_host", host_ptr);
+  if (rc == 2)
+    return fail (d, "unpin_host: hipHostUnregister failed");
+  return 0;
 }
 
 // wait for the batch in `slot` and deliver it (mu held through lk; released while the host blocks on the event)
@@ -2098,8 +2111,8 @@ extern "C" int pemap_dev_submit_batch (pemap_dev * d, const char *reads1, const 
     }
   // the rows move by DMA straight out of the caller's buffers when the caller pinned them (pemap_dev_pin_host); otherwise they
   // are copied, slice by slice, into the slot's pinned staging buffer first (the DMA of slice k runs beside the host copy of k + 1)
-  const bool direct1 = pin_lookup (reads1, (size_t) n * stride);
-  const bool direct2 = d->paired ? pin_lookup (reads2, (size_t) n * stride) : true;
+  const bool direct1 = pm_host_pin_lookup (reads1, (size_t) n * stride);
+  const bool direct2 = d->paired ? pm_host_pin_lookup (reads2, (size_t) n * stride) : true;
   if (!direct1 || !direct2)
     {
       const size_t need = (size_t) d->ring_cap * stride * 2;
@@ -2132,13 +2145,13 @@ extern "C" int pemap_dev_submit_batch (pemap_dev * d, const char *reads1, const 
       if (!direct1)
         {
           char *stg = r.h_rows + (size_t) off * stride;
-          par_memcpy (stg, src1, (size_t) m * stride);
+          pm_par_memcpy (stg, src1, (size_t) m * stride);
           src1 = stg;
         }
       if (d->paired && !direct2)
         {
           char *stg = r.h_rows + ((size_t) d->ring_cap + off) * stride;
-          par_memcpy (stg, src2, (size_t) m * stride);
+          pm_par_memcpy (stg, src2, (size_t) m * stride);
           src2 = stg;
         }
       HIPCHK (d, hipMemcpyAsync (d->d_reads1 + (size_t) (first + off) * stride, src1, (size_t) m * stride, hipMemcpyHostToDevice, d->stream_h2d));

@@ -32,7 +32,10 @@
 #define PM_S3_RCAP 160          // positions next to candidate anchors, both strands together
 #endif
 #ifndef PM_S3_GRAB
-#define PM_S3_GRAB 1            // consecutive read-ends a wave takes per fetch of the work counter
+// Read-ends are handed out through ONE counter in HBM.  Fetched once per end, that single address bounded the kernel: 85 M fetches per
+// second is what it delivers, and the launch took 6.1 ms with 5, 6, 7 or 8 waves per CU alike.  A wave now takes 4 consecutive ends per
+// fetch: 4.3 ms per launch with 8 waves per CU alone on the GPU (6.65 with 5: per wave the kernel is latency-bound as before).
+#define PM_S3_GRAB 4            // consecutive read-ends a wave takes per fetch of the work counter
 #endif
 #ifndef PM_S3_BIGCAP
 #define PM_S3_BIGCAP 0          // 1: reads of up to 160 bases get the long reads' list capacity too (2,048 per strand, 256 near candidates)

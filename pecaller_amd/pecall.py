@@ -29,6 +29,8 @@ class PecallDev:
         L.pecall_dev_sites_stage.argtypes = [vp, vp, vp, vp, C.c_long, i]
         L.pecall_dev_sites_run.argtypes = [vp, i, dbl, dbl, C.POINTER(C.c_float)]
         L.pecall_dev_sites_collect.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+        L.pecall_dev_pin_host.argtypes = [vp, vp, C.c_uint64]
+        L.pecall_dev_unpin_host.argtypes = [vp, vp]
         self.L = L
         h = vp()
         if L.pecall_dev_create(C.byref(h), device_id):
@@ -108,20 +110,32 @@ class PecallDev:
         self._ck(self.L.pecall_dev_sites_collect(self.h, _p(call), _p(post), _p(typ), _p(ac), _p(npass), _p(self.denovo)))
         return call, post, typ, ac, npass
 
-    def call_sites(self, reads, ref_base, threshold=0.95, theta=0.001, haploid=False, chrom=None):
+    def pin_host(self, a):
+        self._ck(self.L.pecall_dev_pin_host(self.h, a.ctypes.data, a.nbytes))
+
+    def unpin_host(self, a):
+        self._ck(self.L.pecall_dev_unpin_host(self.h, a.ctypes.data))
+
+    @staticmethod
+    def out_arrays(n_sites, indiv):
+        """the six result arrays of call_sites, touched (np.zeros leaves the pages to the first write)"""
+        out = (np.zeros((n_sites, indiv), np.int8), np.zeros((n_sites, indiv)), np.zeros(n_sites, np.int8), np.zeros((n_sites, ALLELES), np.int32),
+               np.zeros(n_sites, np.int8), np.zeros(n_sites, np.int32))
+        for a in out:
+            a.fill(0)
+        return out
+
+    def call_sites(self, reads, ref_base, threshold=0.95, theta=0.001, haploid=False, chrom=None, out=None):
         """the whole per-site caller (pecaller.c:1207-1691): reads [n_sites][indiv][6] u16, ref_base [n_sites] (0..3 = ACGT, else
         skipped), chrom [n_sites] 0 autosome / 1 X / 2 Y / 3 MT -> call [n_sites][indiv] (0..13, 14 = 'N'), posterior, site_type,
-        allele_count, n_pass; self.denovo = d_count per site (with a pedigree)"""
+        allele_count, n_pass; self.denovo = d_count per site (with a pedigree).  out: the arrays of out_arrays(), reused by a
+        caller that keeps (and may have pinned) its buffers"""
         reads = np.ascontiguousarray(reads, np.uint16)
         ref_base = np.ascontiguousarray(ref_base, np.uint8)
         n_sites, indiv = reads.shape[:2]
         cy = None if chrom is None else np.ascontiguousarray(chrom, np.uint8)
-        call = np.zeros((n_sites, indiv), np.int8)
-        post = np.zeros((n_sites, indiv))
-        typ = np.zeros(n_sites, np.int8)
-        ac = np.zeros((n_sites, ALLELES), np.int32)
-        npass = np.zeros(n_sites, np.int8)
-        self.denovo = np.zeros(n_sites, np.int32)
+        call, post, typ, ac, npass, den = out if out is not None else self.out_arrays(n_sites, indiv)
+        self.denovo = den
         self._ck(self.L.pecall_dev_call_sites(self.h, _p(reads), _p(ref_base), _p(cy), n_sites, indiv, int(haploid), float(threshold),
-                                              float(theta), _p(call), _p(post), _p(typ), _p(ac), _p(npass), _p(self.denovo)))
+                                              float(theta), _p(call), _p(post), _p(typ), _p(ac), _p(npass), _p(den)))
         return call, post, typ, ac, npass

@@ -55,3 +55,10 @@ def test_bench_two_ranks_runs_the_broadcast_and_the_reduction(tmp_path):
     assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["resident_value"] > 0
     assert rec["timings"]["pileup_reduce_s"] > 0 and rec["timings"]["pileup_reduce_checked_total"] > 0
     assert rec["counters_per_step"]["ends"] == 200000
+    # every rank reports its own layout, memory and step time (a rank that fell back to the reference's table, or ran out of HBM, shows)
+    assert [r["rank"] for r in rec["ranks"]] == [0, 1]
+    for r in rec["ranks"]:
+        assert r["lookup_replicas"] == 0 and r["hbm_free_after_setup_GiB"] > 1 and r["ms_per_step"] > 0 and r["resident_ms_per_step"] > 0
+        assert 0.3 < r["mapped_frac"] <= 1.0
+    assert rec["ms_per_step"] >= max(r["ms_per_step"] for r in rec["ranks"]) - 1e-6
+    assert rec["config"]["lookup_replicas"] == 0 and rec["config"]["host_batches"] == 3
