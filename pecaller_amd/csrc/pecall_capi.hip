@@ -10,6 +10,7 @@
 
 static char g_pc_err[512] = "";
 #define PCS_SLOTS 3             // staging buffers of the seam's pipeline (chunks in flight between the two host copies)
+#define PCS_CALL_STREAMS 4       // streams the beam searches of consecutive chunks alternate on (each with a quarter of the waves and of the scratch)
 
 // host ranges page-locked by the caller (one table for the library: pemap_capi.hip)
 bool pm_host_pin_lookup (const void *p, size_t bytes);
@@ -56,7 +57,7 @@ struct pecall_dev
   // the caller in chunks of columns (pcs_run_chunk): the shortcut kernel of chunk k + 1 runs beside the beam search of chunk k, and at
   // the seam (pecall_dev_call_sites) beside the copies of the chunks around them
   long chunk_sites;
-  hipStream_t stream_call, stream_h2d, stream_d2h;
+  hipStream_t stream_call[PCS_CALL_STREAMS], stream_h2d, stream_d2h;
   hipEvent_t *ev_h2d, *ev_fast, *ev_call, *ev_d2h;     // [cap_chunks]
   char *h_in[PCS_SLOTS], *h_out[PCS_SLOTS];            // pinned staging for callers whose buffers are not pinned
   size_t h_in_bytes, h_out_bytes;
@@ -189,9 +190,10 @@ extern "C" void pecall_dev_destroy (pecall_dev * d)
       if (d->h_out[i])
         hipHostFree (d->h_out[i]);
     }
-  if (d->stream_call)
+  if (d->stream_h2d)
     {
-      hipStreamDestroy (d->stream_call);
+      for (int i = 0; i < PCS_CALL_STREAMS; i++)
+        hipStreamDestroy (d->stream_call[i]);
       hipStreamDestroy (d->stream_h2d);
       hipStreamDestroy (d->stream_d2h);
     }
@@ -554,12 +556,13 @@ static int pcs_ensure_chunks (pecall_dev * d, long n_sites)
       if (lg > 24) lg = 24;
       d->chunk_sites = 1L << lg;
     }
-  if (!d->stream_call)
+  if (!d->stream_h2d)
     {
-      PCCHK (d, hipStreamCreateWithFlags (&d->stream_call, hipStreamNonBlocking));
+      for (int i = 0; i < PCS_CALL_STREAMS; i++)
+        PCCHK (d, hipStreamCreateWithFlags (&d->stream_call[i], hipStreamNonBlocking));
       PCCHK (d, hipStreamCreateWithFlags (&d->stream_h2d, hipStreamNonBlocking));
       PCCHK (d, hipStreamCreateWithFlags (&d->stream_d2h, hipStreamNonBlocking));
-      PCCHK (d, hipFuncSetAttribute ((const void *) pcs_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PCS_FAST_LDS_BYTES));
+      PCCHK (d, hipFuncSetAttribute ((const void *) pcs_fast_kernel < PC_TABLE >, hipFuncAttributeMaxDynamicSharedMemorySize, PCS_FAST_LDS_BYTES_OF (PC_TABLE)));
     }
   if (!d->ev_site[0])
     {
@@ -598,20 +601,47 @@ static int pcs_run_chunk (pecall_dev * d, const PcsParams & P, int k, long off, 
   unsigned *n_slow = (unsigned *) (ctr + 1);
   unsigned *slow = d->d_slow + (size_t) PCS_BUCKETS * off;
   PCCHK (d, hipMemsetAsync (ctr, 0, 4 * sizeof (unsigned long long), d->stream));
-  long fgrid = (m + PCS_FAST_BLOCK / 64 - 1) / (PCS_FAST_BLOCK / 64);
-  if (fgrid > d->grid / 2)
-    fgrid = d->grid / 2;        // one workgroup per CU: the ln n! table takes half its LDS
-  hipLaunchKernelGGL (pcs_fast_kernel, dim3 ((unsigned) fgrid), dim3 (PCS_FAST_BLOCK), PCS_FAST_LDS_BYTES, d->stream, P, d->d_sreads + off * N * PCS_NA,
-                      d->d_dom + off, d->d_chromy + off, m, d->d_call + off * N, d->d_post + off * N, d->d_type + off, d->d_ac + off * PCS_NA, d->d_npass + off,
-                      d->d_den + off, slow, n_slow);
+  // the deepest sample of the chunk picks the form of the shortcut kernel (the other one returns at once)
+  unsigned *depth_max = (unsigned *) (ctr + 3);
+  {
+    long dgrid = (m * N + 255) / 256;
+    if (dgrid > d->grid * 4)
+      dgrid = d->grid * 4;
+    hipLaunchKernelGGL (pcs_depth_kernel, dim3 ((unsigned) dgrid), dim3 (256), 0, d->stream, d->d_sreads + off * N * PCS_NA, m * N, depth_max);
+  }
+  {
+    constexpr int B = PCS_FAST_BLOCK_OF (PCS_FAST_TAB);
+    long fgrid = (m + B / 64 - 1) / (B / 64);
+    if (fgrid > (long) d->grid / 2 * 3)
+      fgrid = (long) d->grid / 2 * 3;     // three workgroups of 4 waves per CU
+    hipLaunchKernelGGL (HIP_KERNEL_NAME (pcs_fast_kernel < PCS_FAST_TAB >), dim3 ((unsigned) fgrid), dim3 (B), PCS_FAST_LDS_BYTES_OF (PCS_FAST_TAB), d->stream, P,
+                        d->d_sreads + off * N * PCS_NA, d->d_dom + off, d->d_chromy + off, m, d->d_call + off * N, d->d_post + off * N, d->d_type + off,
+                        d->d_ac + off * PCS_NA, d->d_npass + off, d->d_den + off, slow, n_slow, depth_max);
+  }
+  {
+    constexpr int B = PCS_FAST_BLOCK_OF (PC_TABLE);
+    long fgrid = (m + B / 64 - 1) / (B / 64);
+    if (fgrid > d->grid / 2)
+      fgrid = d->grid / 2;        // one workgroup per CU: the whole ln n! table takes half its LDS
+    hipLaunchKernelGGL (HIP_KERNEL_NAME (pcs_fast_kernel < PC_TABLE >), dim3 ((unsigned) fgrid), dim3 (B), PCS_FAST_LDS_BYTES_OF (PC_TABLE), d->stream, P,
+                        d->d_sreads + off * N * PCS_NA, d->d_dom + off, d->d_chromy + off, m, d->d_call + off * N, d->d_post + off * N, d->d_type + off,
+                        d->d_ac + off * PCS_NA, d->d_npass + off, d->d_den + off, slow, n_slow, depth_max);
+  }
   PCCHK (d, hipEventRecord (d->ev_fast[k], d->stream));
-  PCCHK (d, hipStreamWaitEvent (d->stream_call, d->ev_fast[k], 0));
-  const long grid = m < d->site_grid ? m : d->site_grid;
-  hipLaunchKernelGGL (pcs_call_kernel, dim3 ((unsigned) grid), dim3 (64), 0, d->stream_call, P, d->d_sreads + off * N * PCS_NA, d->d_dom + off, d->d_chromy + off,
-                      m, d->d_call + off * N, d->d_post + off * N, d->d_type + off, d->d_ac + off * PCS_NA, d->d_npass + off, d->d_den + off, d->d_scratch, ctr,
+  // (a chunk lists a few hundred columns for the beam search, a handful of them heavy -- milliseconds on one wave: behind each other
+  // on one stream the chunks' searches were the caller's time, 8 x 5.5 ms.  They alternate on PCS_CALL_STREAMS streams.)
+  hipStream_t sc = d->stream_call[k % PCS_CALL_STREAMS];
+  const long cgrid = d->site_grid / PCS_CALL_STREAMS;
+  PCCHK (d, hipStreamWaitEvent (sc, d->ev_fast[k], 0));
+  if (k >= PCS_CALL_STREAMS)
+    PCCHK (d, hipStreamWaitEvent (sc, d->ev_call[k - PCS_CALL_STREAMS], 0));     // (same stream: in order anyway)
+  const long grid = m < cgrid ? m : cgrid;
+  char *scratch = d->d_scratch + (size_t) (k % PCS_CALL_STREAMS) * (size_t) cgrid * (2 * PCS_BIG_BYTES + PCS_BIGCAP);
+  hipLaunchKernelGGL (pcs_call_kernel, dim3 ((unsigned) grid), dim3 (64), 0, sc, P, d->d_sreads + off * N * PCS_NA, d->d_dom + off, d->d_chromy + off,
+                      m, d->d_call + off * N, d->d_post + off * N, d->d_type + off, d->d_ac + off * PCS_NA, d->d_npass + off, d->d_den + off, scratch, ctr,
                       slow, n_slow);
   PCCHK (d, hipGetLastError ());
-  PCCHK (d, hipEventRecord (d->ev_call[k], d->stream_call));
+  PCCHK (d, hipEventRecord (d->ev_call[k], sc));
   return 0;
 }
 
@@ -633,8 +663,9 @@ extern "C" int pecall_dev_sites_run (pecall_dev * d, int haploid, double thresho
   for (long off = 0; off < n_sites; off += d->chunk_sites, k++)
     if ((rc = pcs_run_chunk (d, P, k, off, n_sites - off < d->chunk_sites ? n_sites - off : d->chunk_sites)))
       return rc;
-  // (the object's stream ends behind the last beam search: ev_site[1] closes the interval of both streams)
-  PCCHK (d, hipStreamWaitEvent (d->stream, d->ev_call[k - 1], 0));
+  // (the object's stream ends behind the last beam searches: ev_site[1] closes the interval of all streams)
+  for (int q = k > PCS_CALL_STREAMS ? k - PCS_CALL_STREAMS : 0; q < k; q++)
+    PCCHK (d, hipStreamWaitEvent (d->stream, d->ev_call[q], 0));
   PCCHK (d, hipEventRecord (d->ev_site[1], d->stream));
   PCCHK (d, hipStreamSynchronize (d->stream));
   if (kernel_ms)
@@ -841,6 +872,7 @@ extern "C" int pecall_dev_call_sites (pecall_dev * d, const uint16_t * reads, co
     if ((rc = finish (j)))
       return rc;
   PCCHK (d, hipStreamSynchronize (d->stream));
-  PCCHK (d, hipStreamSynchronize (d->stream_call));
+  for (int i = 0; i < PCS_CALL_STREAMS; i++)
+    PCCHK (d, hipStreamSynchronize (d->stream_call[i]));
   return 0;
 }

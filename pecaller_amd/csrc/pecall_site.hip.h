@@ -1409,19 +1409,47 @@ __device__ bool pcs_mini_beam (const PcsParams & P, const double *tab_unused, co
 // by more than 2.31 nats.  Then the column's result is known -- every such sample is called the reference base with
 // posterior 1 after one pass, site type REF -- and is written here; so are the columns the site filters drop (every call N,
 // zero passes) and the ones whose reference base is not A/C/G/T.  Everything else goes to slow_list for pcs_call_kernel.
-#define PCS_FAST_BLOCK 512
 #define PCS_FAST_WAVE_BYTES (64 + PCS_NG * 8 + 16)        // per wave: the samples' order, one sample's likelihoods (pcs_mini_beam)
-#define PCS_FAST_LDS_BYTES ((PC_TABLE + 1 + 4 * PCS_NG * PCS_NA) * 8 + (PCS_FAST_BLOCK / 64) * PCS_FAST_WAVE_BYTES)
+// The ln n! table in LDS comes in two sizes.  Pass 1 looks up n <= 600 + the sample's depth (ta <= 100 per allele): when no sample of
+// the columns at hand is deeper than ~1,400 reads (pcs_depth_kernel finds out), 2,048 entries serve, a workgroup is 4 waves with 20 KB
+// and 12 waves per CU run (the registers' limit) beside whatever else is resident; otherwise the whole table (80 KB) is staged by
+// workgroups of 8 waves, one per CU, as before round 3.  Both forms are launched; the one the depth does not select returns at once.
+#define PCS_FAST_TAB 2048
+#define PCS_FAST_WAVE_BYTES (64 + PCS_NG * 8 + 16)        // per wave: the samples' order, one sample's likelihoods (pcs_mini_beam)
+#define PCS_FAST_BLOCK_OF(TABN) ((TABN) == PCS_FAST_TAB ? 256 : 512)
+#define PCS_FAST_LDS_BYTES_OF(TABN) (((TABN) + 1 + 4 * PCS_NG * PCS_NA) * 8 + (PCS_FAST_BLOCK_OF (TABN) / 64) * PCS_FAST_WAVE_BYTES)
 
-__global__ __launch_bounds__ (PCS_FAST_BLOCK) void pcs_fast_kernel (PcsParams P, const uint16_t * reads, const uint8_t * dom_of, const uint8_t * chrom_of,
-                                                                    long n_sites, int8_t * call, double *post_out, int8_t * type_out,
-                                                                    int32_t * allele_count, int8_t * n_pass, int32_t * denovo_out,
-                                                                    unsigned *slow_list, unsigned *n_slow)
+// the deepest sample of a range of columns: max of A + C + G + T + Del + Ins over (column, sample)
+__global__ __launch_bounds__ (256) void pcs_depth_kernel (const uint16_t * reads, long n_items, unsigned *depth_max)
 {
+  unsigned m = 0;
+  for (long it = (long) blockIdx.x * blockDim.x + threadIdx.x; it < n_items; it += (long) gridDim.x * blockDim.x)
+    {
+      const uint32_t *w = (const uint32_t *) (reads + it * PCS_NA);      // six u16 = three words
+      const uint32_t a = w[0], b = w[1], c = w[2];
+      m = max (m, (a & 0xFFFFu) + (a >> 16) + (b & 0xFFFFu) + (b >> 16) + (c & 0xFFFFu) + (c >> 16));
+    }
+  for (int o = 32; o; o >>= 1)
+    m = max (m, (unsigned) __shfl_xor ((int) m, o));
+  if ((threadIdx.x & 63) == 0 && m)
+    atomicMax (depth_max, m);
+}
+
+template < int TABN > __global__ __launch_bounds__ (PCS_FAST_BLOCK_OF (TABN), TABN == PCS_FAST_TAB ? 3 : 2)
+void pcs_fast_kernel (PcsParams P, const uint16_t * reads, const uint8_t * dom_of, const uint8_t * chrom_of,
+                      long n_sites, int8_t * call, double *post_out, int8_t * type_out,
+                      int32_t * allele_count, int8_t * n_pass, int32_t * denovo_out,
+                      unsigned *slow_list, unsigned *n_slow, const unsigned *depth_max)
+{
+  constexpr int PCS_FAST_BLOCK = PCS_FAST_BLOCK_OF (TABN);
+  // (every n the columns look up: <= 6 x 100 + depth; the form with the table's head serves when that stays inside it)
+  const bool head_serves = *depth_max + 6u * 100u + 1u < (unsigned) PCS_FAST_TAB;
+  if (head_serves != (TABN == PCS_FAST_TAB))
+    return;
   extern __shared__ double pcs_fast_lds[];
   double *tab = pcs_fast_lds;
-  double *mean = pcs_fast_lds + PC_TABLE + 1;           // [4][PCS_NG][PCS_NA]
-  for (int i = threadIdx.x; i < PC_TABLE; i += PCS_FAST_BLOCK)
+  double *mean = pcs_fast_lds + TABN + 1;               // [4][PCS_NG][PCS_NA]
+  for (int i = threadIdx.x; i < TABN; i += PCS_FAST_BLOCK)
     tab[i] = P.tab[i];
   const int N = P.indiv, G = P.max_gen, md = P.min_depth;
   if ((int) threadIdx.x < 4 * G)
@@ -1456,10 +1484,6 @@ __global__ __launch_bounds__ (PCS_FAST_BLOCK) void pcs_fast_kernel (PcsParams P,
           for (int a = 0; a < PCS_NA; a++)
             r[a] = lane < N ? (int) reads[(site * N + lane) * PCS_NA + a] : 0;
           tot = r[0] + r[1] + r[2] + r[3] + r[4];
-          double coef = pc_factln (tab, tot);
-#pragma unroll
-          for (int a = 0; a < PCS_NA; a++)
-            coef -= pc_factln (tab, r[a]);
           int tsum = tot;
           for (int o = 32; o; o >>= 1)
             tsum += __shfl_xor (tsum, o);
@@ -1474,51 +1498,59 @@ __global__ __launch_bounds__ (PCS_FAST_BLOCK) void pcs_fast_kernel (PcsParams P,
               bool ok = true;
               double lk[PCS_NG], margin = 0.0;
               int best = PCS_NG;
+              auto likelihoods = [&] (const double *tb)
+              {
+                double coef = pc_factln (tb, tot);
+#pragma unroll
+                for (int a = 0; a < PCS_NA; a++)
+                  coef -= pc_factln (tb, r[a]);
+                const double sc0 = (double) min (tot, 100);   // norm of pass 1 is 1
+                const double sc1 = (10 > sc0) ? 10 : sc0;
+                const double scale = (1000 < sc1) ? 1000 : sc1;
+                const double *mrow = mean + dom * PCS_NG * PCS_NA;
+                double mx = -1e100;
+#pragma unroll
+                for (int g = 0; g < PCS_NG; g++)
+                  {
+                    lk[g] = 0.0;
+                    if (g < G)
+                      {
+                        int tot_a = 0, tot_tot = 0;
+                        double cf = coef, l = 0.0;
+#pragma unroll
+                        for (int a = 0; a < PCS_NA; a++)
+                          {
+                            const double cv = ceil (scale * mrow[g * PCS_NA + a]);
+                            const int ta = (int) ((1 > cv) ? 1 : cv);
+                            tot_a += ta;
+                            tot_tot += ta + r[a];
+                            cf -= pc_factln (tb, ta - 1);
+                            l += pc_factln (tb, ta + r[a] - 1);
+                          }
+                        cf += pc_factln (tb, tot_a - 1);
+                        l += cf;
+                        l -= pc_factln (tb, tot_tot - 1);
+                        lk[g] = l;
+                        if (l > mx)
+                          {
+                            best = g;
+                            mx = l;
+                          }
+                      }
+                  }
+                // initial_p: the margin of the best genotype over every other one (pecaller.c:2494-2504)
+                margin = 1e100;
+#pragma unroll
+                for (int g = 0; g < PCS_NG; g++)
+                  if (g < G && g != best)
+                    {
+                      const double dlt = mx - lk[g];
+                      margin = (dlt < margin) ? dlt : margin;
+                    }
+              };
               if (deep)
                 {
-                  const double sc0 = (double) min (tot, 100);   // norm of pass 1 is 1
-                  const double sc1 = (10 > sc0) ? 10 : sc0;
-                  const double scale = (1000 < sc1) ? 1000 : sc1;
-                  const double *mrow = mean + dom * PCS_NG * PCS_NA;
-                  double mx = -1e100;
-#pragma unroll
-                  for (int g = 0; g < PCS_NG; g++)
-                    {
-                      lk[g] = 0.0;
-                      if (g < G)
-                        {
-                          int tot_a = 0, tot_tot = 0;
-                          double cf = coef, l = 0.0;
-#pragma unroll
-                          for (int a = 0; a < PCS_NA; a++)
-                            {
-                              const double cv = ceil (scale * mrow[g * PCS_NA + a]);
-                              const int ta = (int) ((1 > cv) ? 1 : cv);
-                              tot_a += ta;
-                              tot_tot += ta + r[a];
-                              cf -= pc_factln (tab, ta - 1);
-                              l += pc_factln (tab, ta + r[a] - 1);
-                            }
-                          cf += pc_factln (tab, tot_a - 1);
-                          l += cf;
-                          l -= pc_factln (tab, tot_tot - 1);
-                          lk[g] = l;
-                          if (l > mx)
-                            {
-                              best = g;
-                              mx = l;
-                            }
-                        }
-                    }
-                  // initial_p: the margin of the best genotype over every other one (pecaller.c:2494-2504)
-                  margin = 1e100;
-#pragma unroll
-                  for (int g = 0; g < PCS_NG; g++)
-                    if (g < G && g != best)
-                      {
-                        const double dlt = mx - lk[g];
-                        margin = (dlt < margin) ? dlt : margin;
-                      }
+                  likelihoods (tab);
                   // best genotype the reference homozygote, and its margin above 2.31
                   ok = best == dom && margin > 2.31;
                   my_call = dom;

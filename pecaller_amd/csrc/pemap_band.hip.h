@@ -133,20 +133,32 @@ template < bool DIRS > __global__ __launch_bounds__ (64, PM_BAND_WAVES_PER_EU) v
         if (valid && 4 * g <= mm)
           slab[4 * g + q] = stage[(prob * 2 + (g & 1)) * 4 + q];
       };
+      // the read letter and the 8 window bytes of a step are requested a step ahead (no branch around the loads: columns outside
+      // 1 .. mm read column 1's or mm's bytes again, unused) -- loaded where they are needed, every step began with a trip to L2
+      auto fetch = [&] (int jj, uint8_t & qr_out, uint64_t & w_out)
+      {
+        const int jc = jj < 1 ? 1 : (jj > mm ? (mm > 0 ? mm : 1) : jj);
+        qr_out = read[orient ? (mm - jc) : (jc - 1)];
+        w_out = *(const pm_u64_unaligned *) (ref + (jc - K - 1 + 8 * q));
+      };
+      uint8_t qr_nx;
+      uint64_t w_nx;
+      fetch (1 - q, qr_nx, w_nx);
       for (int t = 1; t <= mm_max + 3; t++)
         {
           const int j = t - q;                  // this lane's column
           const bool act = valid && j >= 1 && j <= mm;
+          const uint8_t qr = qr_nx;
+          const uint64_t v = w_nx;
+          fetch (j + 1, qr_nx, w_nx);
           uint8_t qc = (uint8_t) 'A';
           uint32_t w_lo = 0u, w_hi = 0u;
           if (act)
             {
-              const uint8_t qr = read[orient ? (mm - j) : (j - 1)];
               qc = orient ? pm_rc (qr) : qr;
               // the window's 8 bytes under this lane's cells: byte c = reference base of row i = j + 8 q + c - K.  (In the first
               // columns the address starts up to K + 1 bytes before the window, in the last ones it ends behind it: the genome buffer is
               // padded on both sides, pemap_dev_index_alloc; what is computed from those bytes is never used, see below.)
-              const uint64_t v = *(const pm_u64_unaligned *) (ref + (j - K - 1 + 8 * q));
               w_lo = (uint32_t) v;
               w_hi = (uint32_t) (v >> 32);
               // For a plain read letter without bisulfite, pm_match (r, q) is r == q except that a reference N matches T

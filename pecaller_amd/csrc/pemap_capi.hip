@@ -120,7 +120,7 @@ static void read_knobs (PmKnobs & k)
   k.chunk_pairs = env_int ("PEMAP_CHUNK_PAIRS", 262144);
   k.d2h_stream = env_int ("PEMAP_D2H_STREAM", 0);
   k.band = env_int ("PEMAP_BAND", 1);
-  k.gapless_blocks_per_cu = env_int ("PEMAP_GAPLESS_BLOCKS_PER_CU", 16);
+  k.gapless_blocks_per_cu = env_int ("PEMAP_GAPLESS_BLOCKS_PER_CU", 24);     // one-wave workgroups of pm_gapless_kernel launched per CU at most
   if (k.gapless_blocks_per_cu < 1) k.gapless_blocks_per_cu = 1;
   k.band_waves_per_cu = env_int ("PEMAP_BAND_WAVES_PER_CU", 16);
   if (k.band_waves_per_cu < 1) k.band_waves_per_cu = 1;
@@ -1273,10 +1273,10 @@ template < int W, int LPA > static void launch_chunk (pemap_dev * d, const RunCt
     {
       uint32_t *tasks_dp = tasks_s + d->cap_ends;
       uint32_t *tasks_band = d->kn.band ? tasks_s + 2 * (size_t) d->cap_ends : nullptr;
-      int ggrid = (n_ends + 7) / 8;
+      int ggrid = (n_ends + PM_GL_PER_BLOCK - 1) / PM_GL_PER_BLOCK;
       if (ggrid > d->n_cus * d->kn.gapless_blocks_per_cu)
         ggrid = d->n_cus * d->kn.gapless_blocks_per_cu;
-      hipLaunchKernelGGL (pm_gapless_kernel, dim3 (ggrid), dim3 (256), 0, d->stream, c.ix, c.b, c.prm, H, tasks_s, &ctr->n_tasks_s, tasks_dp,
+      hipLaunchKernelGGL (pm_gapless_kernel, dim3 (ggrid), dim3 (PM_GL_BLOCK), 0, d->stream, c.ix, c.b, c.prm, H, tasks_s, &ctr->n_tasks_s, tasks_dp,
                           &ctr->n_tasks_dp, pm_gapless_max_x (d), tasks_band, &ctr->n_band[0]);
       if (tasks_band)
         {
@@ -1301,7 +1301,7 @@ template < int W, int LPA > static void launch_chunk (pemap_dev * d, const RunCt
       // sw_next[3] counts what is left to the DP
       uint32_t *tasks_mdp = tasks_m + (size_t) d->cap_ends * PM_MAX_HITS;
       uint32_t *tasks_mband = d->kn.band ? tasks_m + 2 * (size_t) d->cap_ends * PM_MAX_HITS : nullptr;
-      hipLaunchKernelGGL (pm_gapless_kernel, dim3 (d->n_cus * 16), dim3 (256), 0, d->stream, c.ix, c.b, c.prm, H, tasks_m, &ctr->n_tasks_m, tasks_mdp,
+      hipLaunchKernelGGL (pm_gapless_kernel, dim3 (d->n_cus * 16), dim3 (PM_GL_BLOCK), 0, d->stream, c.ix, c.b, c.prm, H, tasks_m, &ctr->n_tasks_m, tasks_mdp,
                           &ctr->sw_next[3], pm_gapless_max_x (d), tasks_mband, &ctr->n_band[1]);
       if (tasks_mband)
         hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_band_kernel < false >), dim3 (d->n_cus * d->kn.band_waves_per_cu), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, H,

@@ -376,6 +376,38 @@ __device__ __forceinline__ void pm_sw_forward (const PmSwTask & tk, int bis, int
   bi = __shfl (i_b, srcl);
 }
 
+// y + 1.0 + 1.0 + ... (n times), every addition rounded as the DP rounds it -- without n additions.  While y >= 1 stays inside its
+// binade [2^e, 2^(e+1)) an addition of 1.0 is exact (y and 1.0 are multiples of ulp (y), the sum is below 2^(e+1)), so k such steps
+// are ONE exact addition of k; only the step that crosses into the next binade rounds, and it is taken on its own with the same
+// operands the step-by-step fold has there.  Below 1 (the first steps of a fold that starts at -1/3 or 2/3) every step is taken
+// singly.  At most two additions per binade instead of one per read base.
+__device__ __forceinline__ double pm_add_ones (double y, int n)
+{
+  while (n > 0 && y < 1.0)
+    {
+      y = y + 1.0;
+      n--;
+    }
+  while (n > 0)
+    {
+      // y >= 1: the steps that stay below the next power of two
+      const int e = (int) ((__double2hiint (y) >> 20) & 0x7FF) - 1023;          // 2^e <= y < 2^(e+1); e <= 9 for these scores
+      const int top = (2 << e) - 1;                                             // the largest integer part inside the binade
+      const int k = min (n, top - (int) y);
+      if (k > 0)
+        {
+          y = y + (double) k;
+          n -= k;
+        }
+      if (n > 0)
+        {
+          y = y + 1.0;          // into the next binade: the one step that rounds
+          n--;
+        }
+    }
+  return y;
+}
+
 // ============================================================================================================
 // K3a: the gapless rule.  For most reads the affine-gap DP only confirms what a comparison along the window's
 // nn - mm + 1 diagonals already shows, and those cases can be decided exactly without it.  Scores (pemapper.c:2006-2095):
@@ -402,6 +434,7 @@ __device__ __forceinline__ void pm_sw_forward (const PmSwTask & tk, int bis, int
 // bases.
 // ============================================================================================================
 #define PM_GAPLESS 4            // flag in PmHits::stk beside the plane number
+#define PM_GL_QUEUE 32           // problems a wave of pm_gapless_kernel collects before it fetches a list's counter
 
 // problems the rule leaves open go to tasks_band (pm_band_kernel, pemap_band.hip.h) when the best diagonal has at most
 // PM_BAND_MAXX_ mismatches -- the condition under which the banded DP is exact -- and to tasks_dp (the full DP) otherwise
@@ -413,62 +446,231 @@ __device__ __forceinline__ void pm_sw_forward (const PmSwTask & tk, int bis, int
 #define PM_BAND_W (22 + 2 * PM_BAND_K)
 #define PM_BAND_MAXX_ (PM_BAND_K >= 5 ? 6 : PM_BAND_K + 1)
 static_assert (PM_BAND_K >= 2 && PM_BAND_K <= 5, "the band holds at most 32 diagonals");
-__global__ __launch_bounds__ (256) void pm_gapless_kernel (PmIndex ix, PmBatch b, PmParams prm, PmHits h, const uint32_t * tasks,
+// (one-wave workgroups: a wave goes wherever a SIMD has room beside the seed kernel's waves; four to a workgroup waited for room for four)
+#define PM_GL_BLOCK 64
+#define PM_GL_PER_BLOCK (PM_GL_BLOCK / 32)     // problems a workgroup works on at a time: one per half-wave
+__global__ __launch_bounds__ (PM_GL_BLOCK, 6) void pm_gapless_kernel (PmIndex ix, PmBatch b, PmParams prm, PmHits h, const uint32_t * tasks,
                                                           const unsigned *n_tasks_p, uint32_t * tasks_dp, unsigned *n_tasks_dp, int max_x,
                                                           uint32_t * tasks_band, unsigned *n_tasks_band)
 {
-  __shared__ __align__ (8) uint8_t rd[8][320];
+  __shared__ __align__ (8) uint8_t rd[PM_GL_PER_BLOCK][320];
+  __shared__ __align__ (8) uint8_t win[PM_GL_PER_BLOCK][352];         // the window: nn <= 299 bytes, read in 8-byte pieces up to 8 bytes past 8-byte boundaries
+  __shared__ uint32_t q_band[PM_GL_BLOCK / 64][PM_GL_QUEUE], q_dp[PM_GL_BLOCK / 64][PM_GL_QUEUE];       // per wave: problems on their way to the two DP lists
+  const int wv = threadIdx.x >> 6;
+  int n_qb = 0, n_qd = 0;
+  auto flush_queue = [&] (const uint32_t * q, int &n, uint32_t * dst, unsigned *counter)
+  {
+    if (n == 0)
+      return;
+    const unsigned base = (unsigned) __builtin_amdgcn_readfirstlane ((int) ((threadIdx.x & 63) == 0 ? atomicAdd (counter, (unsigned) n) : 0u));
+    __builtin_amdgcn_fence (__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier ();
+    if ((int) (threadIdx.x & 63) < n)
+      dst[base + (threadIdx.x & 63)] = q[threadIdx.x & 63];
+    n = 0;
+    __builtin_amdgcn_fence (__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier ();
+  };
   const int lane = threadIdx.x & 63, l = lane & 31, half = lane & 32;
   const int slot = threadIdx.x >> 5;            // half-wave of the block
   const unsigned n_tasks = *n_tasks_p;
   const int bis = prm.bisulfite;
   const double miss = __hiloint2double ((int) 0xBFD55555u, (int) 0x55555555u);     // -1/3 as the reference's double (pemapper.c:2011-2019)
-  for (unsigned t0 = blockIdx.x * 8u; t0 < n_tasks; t0 += gridDim.x * 8u)
+  // A problem is a chain of dependent trips to memory: its task word, the hit's record (length, window, strand), the read and the
+  // window.  The first two are fetched one and two rounds ahead (registers), the last two arrive together and are compared out of
+  // LDS: one exposed trip per round instead of four plus one per eight bases of the window.
+  const unsigned stride = gridDim.x * (unsigned) PM_GL_PER_BLOCK;
+  struct Meta
+  {
+    size_t o;
+    int mm, nn, orient;
+    const uint8_t *read, *ref;
+  };
+  // (no branches around these loads: past the list's end they read its last entry again.  A load under a condition makes the
+  // compiler wait for every outstanding load where the paths join, which is at once -- and the round ahead is gone)
+  auto load_meta = [&] (uint32_t task_word)->Meta
+  {
+    Meta m;
+    m.o = task_word;
+    m.read = pm_read_ptr (b, (int) (m.o / PM_MAX_HITS), &m.mm);
+    m.nn = h.nn[m.o];
+    m.orient = h.orient[m.o];
+    m.ref = ix.genome + h.gpos[m.o];
+    return m;
+  };
+  auto load_task = [&] (unsigned tt)->uint32_t
+  {
+    return tasks[tt < n_tasks ? tt : n_tasks - 1u];
+  };
+  if (blockIdx.x * (unsigned) PM_GL_PER_BLOCK >= n_tasks)
+    return;
+  unsigned t_cur = blockIdx.x * (unsigned) PM_GL_PER_BLOCK + (unsigned) slot;
+  Meta nx = load_meta (load_task (t_cur));
+  uint32_t task2 = load_task (t_cur + stride);
+  for (unsigned t0 = blockIdx.x * (unsigned) PM_GL_PER_BLOCK; t0 < n_tasks; t0 += stride)
     {
       const unsigned t = t0 + (unsigned) slot;
       const bool valid = t < n_tasks;
-      size_t o = 0;
-      int mm = 0, nn = 0, orient = 0;
-      const uint8_t *read = b.reads1, *ref = ix.genome;
-      if (valid)
-        {
-          o = tasks[t];
-          read = pm_read_ptr (b, (int) (o / PM_MAX_HITS), &mm);
-          nn = h.nn[o];
-          orient = h.orient[o];
-          ref = ix.genome + h.gpos[o];
-        }
-      // the oriented read, padded with zeros to a multiple of 8
-      for (int jz = l; jz < ((mm + 7) & ~7); jz += 32)
-        rd[slot][jz] = (jz < mm) ? pm_oriented (read, mm, orient, jz) : (uint8_t) 0;
+      const Meta cur = nx;
+      const size_t o = cur.o;
+      const int mm = cur.mm, nn = cur.nn, orient = cur.orient;
+      const uint8_t *read = cur.read, *ref = cur.ref;
+      // the next round's record and the task word of the round after it: in flight while this round is compared
+      nx = load_meta (task2);
+      task2 = load_task (t + 2u * stride);
+      // the oriented read, padded with zeros to a multiple of 8, and the window, both in 8-byte pieces (two of each per lane at most:
+      // 8 x 64 = 512 bytes) whose loads are ALL issued before the first is waited for.  (The genome buffer and the read rows are
+      // padded: reading a few bytes past a window or a read is safe.)  A piece of the reverse strand is the piece of the read that
+      // mirrors it, bytes swapped end for end and complemented (reverse_transcribe, pemapper.c:2303-2337); where that piece would
+      // start before the read (its last one, when the length is no multiple of 8) it starts at the read and is shifted up.
+      {
+        uint64_t rq[2] = { 0ull, 0ull }, wq[2] = { 0ull, 0ull };
+        int sh_up[2] = { 0, 0 };
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+          {
+            const int c = l + 32 * u;
+            if (8 * c < mm)
+              {
+                int s0 = orient ? mm - 8 - 8 * c : 8 * c;
+                if (s0 < 0)
+                  {
+                    sh_up[u] = -8 * s0;
+                    s0 = 0;
+                  }
+                rq[u] = *(const pm_u64_unaligned *) (read + s0);
+              }
+            if (valid && 8 * c < nn + 16)
+              wq[u] = *(const pm_u64_unaligned *) (ref + 8 * c);
+          }
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+          {
+            const int c = l + 32 * u;
+            if (8 * c < ((mm + 7) & ~7))
+              {
+                uint64_t v = rq[u];
+                const int nb = mm - 8 * c < 8 ? mm - 8 * c : 8;
+                if (orient)
+                  {
+                    v <<= sh_up[u];
+                    uint64_t w = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; k++)
+                      w |= (uint64_t) pm_rc_flat ((uint8_t) (v >> (8 * (7 - k)))) << (8 * k);
+                    v = w;
+                  }
+                if (nb < 8)
+                  v &= (1ull << (8 * nb)) - 1ull;
+                *(uint64_t *) &rd[slot][8 * c] = v;
+              }
+            if (valid && 8 * c < nn + 16)
+              *(uint64_t *) &win[slot][8 * c] = wq[u];
+          }
+      }
       __builtin_amdgcn_fence (__ATOMIC_SEQ_CST, "wavefront");
       __builtin_amdgcn_wave_barrier ();
       const int ndiag = valid ? nn - mm + 1 : 0;         // diagonals on which the whole read lies inside the window
       const bool mine = l < ndiag;
-      const uint8_t *rp = ref + l;
-      // forward: mismatches up to the seventh (three decide the rule, PM_BAND_MAXX_ the banded DP), the positions of the first two
-      int mism = 99, m1 = mm, m2 = mm;
+      // Which bases of an 8-base piece of the read mismatch the window on diagonal d: piece c = read bases 8 c .. 8 c + 7 against
+      // window bytes d + 8 c ..., two aligned pieces of the window shifted together.  Bit k = base 8 c + k mismatches (pm_match's
+      // rule: bytes that differ are looked at one by one).
+      const int nch = (mm + 7) >> 3;
+      auto piece_mask = [&] (int d, int c)->unsigned
+      {
+        const uint64_t q = *(const uint64_t *) &rd[slot][8 * c];
+        const int off = d + 8 * c, sh = 8 * (off & 7);
+        const uint64_t *wq = (const uint64_t *) &win[slot][off & ~7];
+        const uint64_t lo = wq[0], hi = wq[1];
+        const uint64_t r = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+        const int nb = mm - 8 * c < 8 ? mm - 8 * c : 8;
+        uint64_t x = q ^ r;
+        if (nb < 8)
+          x &= (1ull << (8 * nb)) - 1ull;
+        unsigned m = 0u;
+        if (x != 0ull)
+          for (int k = 0; k < nb; k++)
+            if (((x >> (8 * k)) & 0xFFull) && !pm_match ((uint8_t) (r >> (8 * k)), (uint8_t) (q >> (8 * k)), bis))
+              m |= 1u << k;
+        return m;
+      };
+      // Forward: the mismatches of every diagonal, exactly up to PM_BAND_MAXX_ (three decide the rule, PM_BAND_MAXX_ the banded DP),
+      // the positions of the first two and of the last one.  Lane = diagonal walking its ~19 pieces, as round 2 had it, was the
+      // kernel's instruction count: a wrong diagonal is out after a piece or two, the right one kept the whole half-wave in its loop.
+      // Now every diagonal looks at its first two pieces (16 bases; a read has at least 16); the few that have at most
+      // PM_BAND_MAXX_ mismatches there are finished one at a time with lane = PIECE, all their pieces in one step.
+      int mism = 99, m1 = mm, m2 = mm, mlast = -1;      // mlast: the last mismatch's position, -1 = none; known for the finished ones
+      bool finished = false;
+      unsigned head = 0u;
       if (mine)
         {
-          mism = 0;
-          for (int j = 0; j < mm && mism <= PM_BAND_MAXX_; j += 8)
+          head = piece_mask (l, 0) | (nch > 1 ? piece_mask (l, 1) << 8 : 0u);
+          mism = __popc (head);
+          if (head)
             {
-              const uint64_t q = *(const uint64_t *) &rd[slot][j];
-              const uint64_t r = *(const pm_u64_unaligned *) (rp + j);      // (the genome buffer is padded: reading past the window is safe)
-              const int nb = mm - j < 8 ? mm - j : 8;
-              uint64_t x = q ^ r;
-              if (nb < 8)
-                x &= (1ull << (8 * nb)) - 1ull;
-              if (x != 0ull)
-                for (int k = 0; k < nb; k++)
-                  if (((x >> (8 * k)) & 0xFFull) && !pm_match ((uint8_t) (r >> (8 * k)), (uint8_t) (q >> (8 * k)), bis))
-                    {
-                      if (mism == 0)
-                        m1 = j + k;
-                      else if (mism == 1)
-                        m2 = j + k;
-                      mism++;
-                    }
+              m1 = __ffs ((int) head) - 1;
+              mlast = 31 - __clz ((int) head);
+              const unsigned h2 = head & (head - 1u);
+              if (h2)
+                m2 = __ffs ((int) h2) - 1;
+            }
+        }
+      unsigned todo = (unsigned) (__ballot (mine && mism <= PM_BAND_MAXX_) >> half);
+      while (__any (todo != 0u))
+        {
+          const bool go = todo != 0u;           // (per half-wave)
+          const int d = go ? __ffs ((int) todo) - 1 : 0;
+          todo &= todo - 1u;
+          // what diagonal d's lane knows from its first 16 bases, in every lane of the half
+          const int d_cnt = __shfl (mism, half + d), d_m1 = __shfl (m1, half + d), d_m2 = __shfl (m2, half + d), d_last = __shfl (mlast, half + d);
+          int tot = d_cnt, f1 = d_m1, f2 = d_m2, flast = d_last;
+          for (int cb = 2; cb < nch; cb += 32)
+            {
+              const int c = cb + l;
+              const unsigned mk = (go && c < nch) ? piece_mask (d, c) : 0u;
+              const int cnt = __popc (mk);
+              // inclusive prefix count over the lanes of the half-wave (DPP: row shifts, then row 0 -> 1 and row 2 -> 3)
+              int inc = cnt;
+              inc += pm_dpp_or < 0x111, 0xF > (0, inc);
+              inc += pm_dpp_or < 0x112, 0xF > (0, inc);
+              inc += pm_dpp_or < 0x114, 0xF > (0, inc);
+              inc += pm_dpp_or < 0x118, 0xF > (0, inc);
+              inc += pm_dpp_or < 0x142, 0xA > (0, inc);
+              const int exc = inc - cnt;
+              const int here = __shfl (inc, half + 31);
+              // the first and the second mismatch of the read, if they lie in these pieces: the lane whose pieces hold number
+              // (1 or 2) - (mismatches before these pieces) of them
+              const int want1 = 1 - tot, want2 = 2 - tot;        // 1-based rank among this pass's mismatches
+              const unsigned own1 = (unsigned) (__ballot (want1 >= 1 && exc < want1 && inc >= want1) >> half);
+              const unsigned own2 = (unsigned) (__ballot (want2 >= 1 && exc < want2 && inc >= want2) >> half);
+              auto nth = [&] (int rank)->int      // position of the rank-th (1-based, <= cnt) set bit of mk
+              {
+                unsigned t = mk;
+                for (int i = 1; i < rank; i++)
+                  t &= t - 1u;
+                return 8 * c + __ffs ((int) t) - 1;
+              };
+              const int v1 = nth (want1 - exc > 0 ? want1 - exc : 1), v2 = nth (want2 - exc > 0 ? want2 - exc : 1);
+              if (own1)
+                f1 = __shfl (v1, half + __ffs ((int) own1) - 1);
+              if (own2)
+                f2 = __shfl (v2, half + __ffs ((int) own2) - 1);
+              const unsigned any = (unsigned) (__ballot (cnt > 0) >> half);
+              if (any)
+                {
+                  const int top = 31 - __clz ((int) any);
+                  const int vl = 8 * c + 31 - __clz ((int) (mk ? mk : 1u));
+                  flast = __shfl (vl, half + top);
+                }
+              tot += here;
+            }
+          if (go && l == d)
+            {
+              mism = tot;
+              m1 = f1;
+              m2 = f2;
+              mlast = flast;
+              finished = true;
             }
         }
       const unsigned c1 = (unsigned) (__ballot (mism <= 1) >> half);      // this half-wave's diagonals with x <= 1
@@ -480,21 +682,17 @@ __global__ __launch_bounds__ (256) void pm_gapless_kernel (PmIndex ix, PmBatch b
             {
               // case (2): is there a one-deletion alignment without mismatch?  suf[d] by a scan from the read's end
               int suf = 0;
-              if (mine)
+              if (mine && finished)
+                suf = mlast < 0 ? mm : mm - 1 - mlast;
+              else if (mine)
                 {
+                  // (a diagonal with seven or more mismatches in its first 16 bases: its perfect suffix is scanned from the end)
                   suf = mm;
-                  for (int j = (mm - 1) & ~7; j >= 0 && suf == mm; j -= 8)
+                  for (int c = nch - 1; c >= 0 && suf == mm; c--)
                     {
-                      const uint64_t q = *(const uint64_t *) &rd[slot][j];
-                      const uint64_t r = *(const pm_u64_unaligned *) (rp + j);
-                      const int nb = mm - j < 8 ? mm - j : 8;
-                      uint64_t x = q ^ r;
-                      if (nb < 8)
-                        x &= (1ull << (8 * nb)) - 1ull;
-                      if (x != 0ull)
-                        for (int k = nb - 1; k >= 0 && suf == mm; k--)
-                          if (((x >> (8 * k)) & 0xFFull) && !pm_match ((uint8_t) (r >> (8 * k)), (uint8_t) (q >> (8 * k)), bis))
-                            suf = mm - 1 - (j + k);
+                      const unsigned mk = piece_mask (l, c);
+                      if (mk)
+                        suf = mm - 1 - (8 * c + 31 - __clz ((int) mk));
                     }
                 }
               // pmax = the longest perfect prefix among the earlier diagonals
@@ -517,40 +715,45 @@ __global__ __launch_bounds__ (256) void pm_gapless_kernel (PmIndex ix, PmBatch b
       double sc = 0.0;
       if ((cmask >> l) & 1u)
         {
-          int k = 0;
           if (mism >= 1)
             {
               sc = (double) m1 + miss;
-              k = m1 + 1;
               if (mism == 2)
                 {
-                  for (; k < m2; k++)
-                    sc = sc + 1.0;
+                  sc = pm_add_ones (sc, m2 - m1 - 1);
                   sc = sc + miss;
-                  k = m2 + 1;
+                  sc = pm_add_ones (sc, mm - m2 - 1);
                 }
-              for (; k < mm; k++)
-                sc = sc + 1.0;
+              else
+                sc = pm_add_ones (sc, mm - m1 - 1);
             }
           else
             sc = (double) mm;
         }
+      // what the rule leaves open goes to the banded DP's list or to the full DP's, through a queue of the wave in LDS: one fetch of
+      // the list's counter per PM_GL_QUEUE problems.  (One per problem -- 70 K same-address atomics per launch, each a round trip
+      // that the next one waits behind -- was the kernel's time: the single-address rate is ~85 M per second.)
+      {
+        int xmin = mism;
+        for (int s = 16; s; s >>= 1)
+          xmin = min (xmin, __shfl_xor (xmin, s));      // (within the half-wave)
+        const bool open = valid && cmask == 0u && l == 0;
+        const bool to_band = open && tasks_band && xmin <= PM_BAND_MAXX_, to_dp = open && !to_band;
+        const unsigned long long mb = __ballot (to_band), md = __ballot (to_dp);
+        if (to_band)
+          q_band[wv][n_qb + (int) __popcll (mb & ((1ull << lane) - 1ull))] = (uint32_t) o;
+        if (to_dp)
+          q_dp[wv][n_qd + (int) __popcll (md & ((1ull << lane) - 1ull))] = (uint32_t) o;
+        n_qb += (int) __popcll (mb);
+        n_qd += (int) __popcll (md);
+        if (n_qb > PM_GL_QUEUE - 2)
+          flush_queue (q_band[wv], n_qb, tasks_band, n_tasks_band);
+        if (n_qd > PM_GL_QUEUE - 2)
+          flush_queue (q_dp[wv], n_qd, tasks_dp, n_tasks_dp);
+      }
       if (valid)
         {
-          if (cmask == 0u)
-            {
-              int xmin = mism;
-              for (int s = 16; s; s >>= 1)
-                xmin = min (xmin, __shfl_xor (xmin, s));      // (within the half-wave)
-              if (l == 0)
-                {
-                  if (tasks_band && xmin <= PM_BAND_MAXX_)
-                    tasks_band[atomicAdd (n_tasks_band, 1u)] = (uint32_t) o;
-                  else
-                    tasks_dp[atomicAdd (n_tasks_dp, 1u)] = (uint32_t) o;
-                }
-            }
-          else
+          if (cmask != 0u)
             {
               // ascending rows, strict '>' (pemapper.c:1724-1741)
               double best = 0.0;
@@ -578,6 +781,8 @@ __global__ __launch_bounds__ (256) void pm_gapless_kernel (PmIndex ix, PmBatch b
       __builtin_amdgcn_fence (__ATOMIC_SEQ_CST, "wavefront");
       __builtin_amdgcn_wave_barrier ();
     }
+  flush_queue (q_band[wv], n_qb, tasks_band, n_tasks_band);
+  flush_queue (q_dp[wv], n_qd, tasks_dp, n_tasks_dp);
 }
 
 __device__ __forceinline__ int pm_wave_max (int v)
@@ -997,18 +1202,49 @@ __global__ __launch_bounds__ (256) void pm_pile_kernel (PmBatch b, PmHits h, con
   const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
   const unsigned long long below = (1ull << lane) - 1ull;
   unsigned long long incs = 0;
+  // an alignment's record (winner -> read, strand, window, start cell, steps) is fetched one round ahead, the winner's word two
+  // rounds ahead: the round itself waits for the steps, then the read and reference bytes, then nothing (the adds return nothing)
+  struct Rec
+  {
+    int mm, orient, ns, sti;
+    uint32_t gpos;
+    bool gapless;
+    const uint8_t *read;
+  };
+  // (no branches around these loads -- past the end they read the last winner again: a load under a condition makes the compiler wait
+  // for every outstanding load where the paths join)
+  if (n_wins == 0u)
+    return;
+  auto load_win = [&] (unsigned ww)->uint32_t
+  {
+    return wins[ww < n_wins ? ww : n_wins - 1u];
+  };
+  auto load_rec = [&] (unsigned ww, uint32_t win_word)->Rec
+  {
+    Rec r;
+    const size_t o = win_word;
+    r.read = pm_read_ptr (b, (int) (o / PM_MAX_HITS), &r.mm);
+    r.orient = h.orient[o];
+    r.gpos = h.gpos[o];
+    r.gapless = (h.stk[o] & PM_GAPLESS) != 0;
+    r.ns = n_steps[ww < n_wins ? ww : n_wins - 1u];
+    r.sti = h.sti[o];
+    return r;
+  };
+  Rec nx = load_rec (wave, load_win (wave));
+  uint32_t win2 = load_win (wave + n_waves);
   for (unsigned w = wave; w < n_wins; w += n_waves)
     {
-      const size_t o = wins[w];
-      const int end = (int) (o / PM_MAX_HITS);
-      int mm;
-      const uint8_t *read = pm_read_ptr (b, end, &mm);
-      const int orient = h.orient[o];
-      const uint32_t gpos = h.gpos[o];
-      const bool gapless = (h.stk[o] & PM_GAPLESS) != 0;
-      const int ns = gapless ? mm : (int) n_steps[w];
+      const Rec cur = nx;
+      nx = load_rec (w + n_waves, win2);
+      win2 = load_win (w + 2u * n_waves);
+      const int mm = cur.mm, orient = cur.orient;
+      const uint8_t *read = cur.read;
+      const uint32_t gpos = cur.gpos;
+      const bool gapless = cur.gapless;
+      const int ns = gapless ? mm : cur.ns;
       const unsigned long long *pw = path + (size_t) w * path_words;
-      int i = h.sti[o], j = mm;
+      int i = cur.sti, j = mm;
       for (int s0 = 0; s0 < ns; s0 += 64)
         {
           const int s = s0 + lane;

@@ -93,6 +93,42 @@ def test_gpu_site_caller_64_samples_and_haploid():
 
 
 @pytest.mark.gpu
+def test_gpu_site_caller_deep_columns():
+    """columns with samples thousands of reads deep: the shortcut kernel then stages the whole ln n! table instead of its head
+    (pcs_depth_kernel picks the form per chunk), and counts above 10,000 take the table's log formula; mixed with ordinary columns
+    in the same call, a second call with only shallow columns (the head serves again)"""
+    from pecaller_amd.pecall import PecallDev
+    rng = np.random.default_rng(11)
+    n_sites, n = 3000, 24
+    dom = rng.integers(0, 4, n_sites).astype(np.uint8)
+    depth = np.where(rng.random((n_sites, n)) < 0.1, rng.integers(1500, 12000, (n_sites, n)), rng.poisson(30, (n_sites, n)))
+    err = rng.binomial(depth, 0.004)
+    reads = np.zeros((n_sites, n, 6), np.int64)
+    idx = np.arange(n_sites)
+    is_var = rng.random(n_sites) < 0.05
+    alt = (dom + rng.integers(1, 4, n_sites)) % 4
+    for i in range(n):
+        dose = np.where(is_var, rng.binomial(2, 0.3, n_sites), 0)
+        good = depth[:, i] - err[:, i]
+        ar = rng.binomial(good, dose / 2.0)
+        reads[idx, i, dom] += good - ar
+        reads[idx, i, alt] += ar
+        reads[idx, i, rng.integers(0, 4, n_sites)] += err[:, i]
+    reads = np.minimum(reads, 65535).astype(np.uint16)
+    dev = PecallDev(0)
+    for sl in (slice(0, n_sites), slice(0, 1)):
+        r = reads[sl] if sl.stop > 1 else np.minimum(reads[:500], 40)
+        dm = dom[sl] if sl.stop > 1 else dom[:500]
+        got = dev.call_sites(r, dm)
+        exp = oracle_py.call_sites(r, dm)
+        assert np.array_equal(got[0], exp[0])
+        assert np.max(np.abs(got[1] - exp[1])) <= 1e-6
+        for a, b in zip(got[2:], exp[2:]):
+            assert np.array_equal(a, b)
+    dev.close()
+
+
+@pytest.mark.gpu
 def test_gpu_site_caller_with_pedigree():
     """two trios, a second child and a child without a sampled father: calls, posteriors, types and DENOVO_ counts"""
     from pecaller_amd.pecall import PecallDev
