@@ -27,8 +27,10 @@ typedef struct
   pthread_cond_t cv;
   char *ring[ZR_RING];
   int ring_len[ZR_RING];
-  int head, count, done, stop;
-  int pos;                      /* bytes of ring[head] already consumed */
+  int head, count, done, stop, error;     /* shared: only under mu */
+  int pos;                      /* consumer's own: bytes of ring[head] already consumed */
+  int cur_len;                  /* consumer's own: length of ring[head] once it holds the block (0 = no block held) */
+  const char *path;
 } zreader;
 
 static void *
@@ -51,7 +53,17 @@ zr_inflate (void *arg)
       if (stop)
         return NULL;
       int got = gzread (r->f, r->ring[tail], ZR_BLOCK);
+      int bad = 0;
+      if (got <= 0)
+        {
+          /* a short or corrupt stream is an error, not an end (gzread gives 0 after a truncated member and keeps Z_BUF_ERROR) */
+          int en = Z_OK;
+          gzerror (r->f, &en);
+          bad = got < 0 || (en != Z_OK && en != Z_STREAM_END);
+        }
       pthread_mutex_lock (&r->mu);
+      if (bad)
+        r->error = 1;
       if (got <= 0)
         r->done = 1;
       else
@@ -75,6 +87,7 @@ zr_open (zreader * r, const char *path)
   r->f = gzopen (path, "rb");
   if (!r->f)
     return -1;
+  r->path = path;
   gzbuffer (r->f, 1 << 20);
   for (int i = 0; i < ZR_RING; i++)
     r->ring[i] = (char *) malloc (ZR_BLOCK);
@@ -85,6 +98,33 @@ zr_open (zreader * r, const char *path)
   return 0;
 }
 
+/* Let go of the block that has been read to its end and take hold of the next one: afterwards cur_len/pos describe ring[head], or
+ * cur_len is 0 at the end of the stream.  The ring's shared fields are touched under the lock only; between two calls the consumer
+ * works on cur_len and pos, which are its own.  A stream that ended in an inflate error ends the program: calling on the part
+ * that could be read would look like a result. */
+__attribute__ ((unused)) static void
+zr_next_block (zreader * r)
+{
+  pthread_mutex_lock (&r->mu);
+  if (r->cur_len > 0)
+    {
+      r->head = (r->head + 1) % ZR_RING;
+      r->count--;
+      pthread_cond_broadcast (&r->cv);
+    }
+  while (r->count == 0 && !r->done)
+    pthread_cond_wait (&r->cv, &r->mu);
+  r->cur_len = r->count > 0 ? r->ring_len[r->head] : 0;
+  const int failed = r->count == 0 && r->error;
+  pthread_mutex_unlock (&r->mu);
+  r->pos = 0;
+  if (failed)
+    {
+      fprintf (stderr, "\n %s is truncated or not a valid gzip stream \n", r->path ? r->path : "input");
+      exit (1);
+    }
+}
+
 /* copy up to n bytes to dst; returns the bytes copied (less than n only at the end of the stream) */
 __attribute__ ((unused)) static size_t
 zr_read (zreader * r, void *dst, size_t n)
@@ -92,25 +132,13 @@ zr_read (zreader * r, void *dst, size_t n)
   size_t got = 0;
   while (got < n)
     {
-      if (r->count == 0 || r->pos == r->ring_len[r->head])
+      if (r->pos == r->cur_len)
         {
-          pthread_mutex_lock (&r->mu);
-          if (r->count > 0 && r->pos == r->ring_len[r->head])
-            {
-              r->head = (r->head + 1) % ZR_RING;
-              r->count--;
-              r->pos = 0;
-              pthread_cond_broadcast (&r->cv);
-            }
-          while (r->count == 0 && !r->done)
-            pthread_cond_wait (&r->cv, &r->mu);
-          const int empty = r->count == 0;
-          pthread_mutex_unlock (&r->mu);
-          if (empty)
+          zr_next_block (r);
+          if (r->cur_len == 0)
             break;
-          continue;
         }
-      size_t m = (size_t) (r->ring_len[r->head] - r->pos);
+      size_t m = (size_t) (r->cur_len - r->pos);
       if (m > n - got)
         m = n - got;
       memcpy ((char *) dst + got, r->ring[r->head] + r->pos, m);
@@ -225,10 +253,12 @@ pgz_write (pgz * p, const void *buf, size_t bytes)
   if ((size_t) nt > j.n_pieces)
     nt = (int) j.n_pieces;
   pthread_t th[64];
+  int started = 0;              /* the pieces are handed out by a counter: fewer workers than asked for still do all of them */
   for (int t = 1; t < nt; t++)
-    pthread_create (&th[t], NULL, pgz_worker, &j);
+    if (pthread_create (&th[started], NULL, pgz_worker, &j) == 0)
+      started++;
   pgz_worker (&j);
-  for (int t = 1; t < nt; t++)
+  for (int t = 0; t < started; t++)
     pthread_join (th[t], NULL);
   pthread_mutex_destroy (&j.mu);
   int rc = j.failed ? -1 : 0;

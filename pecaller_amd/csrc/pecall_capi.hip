@@ -4,6 +4,7 @@
 #include <string.h>
 #include <stdarg.h>
 #include <math.h>
+#include <chrono>
 #include "../../include/pemap_hip.h"
 #include "pecall_kernels.hip.h"
 #include "pecall_site.hip.h"
@@ -44,9 +45,12 @@ struct pecall_dev
   // pedigree
   int ped_indiv, ped_haploid;
   double denovo_rate;
-  int8_t h_dad[PCS_MAXN], h_mom[PCS_MAXN], h_sex[PCS_MAXN];
-  uint8_t h_kid_off[PCS_MAXN + 1], h_kid_list[2 * PCS_MAXN];
-  int8_t *d_ped;                // dad[64] mom[64] sex[64] kid_off[65 -> 72] kid_list[128]
+  int16_t h_dad[PCS_MAXN], h_mom[PCS_MAXN];
+  int8_t h_sex[PCS_MAXN];
+  uint16_t h_kid_off[PCS_MAXN + 1], h_kid_list[2 * PCS_MAXN];
+  int16_t *d_ped;               // int16: dad[MAXN] mom[MAXN] kid_off[MAXN + 8] kid_list[2 MAXN]; then bytes: sex[MAXN]
+  int scratch_row;              // calls-row width (64 per chunk of samples) d_scratch was sized for
+  uint32_t *d_ta;               // pass 1's integer Dirichlet parameters (pcs_ta_table)
   short *d_dyad, *d_trio;
   long staged_sites;
   int staged_indiv;
@@ -58,7 +62,8 @@ struct pecall_dev
   // the seam (pecall_dev_call_sites) beside the copies of the chunks around them
   long chunk_sites;
   hipStream_t stream_call[PCS_CALL_STREAMS], stream_h2d, stream_d2h;
-  hipEvent_t *ev_h2d, *ev_fast, *ev_call, *ev_d2h;     // [cap_chunks]
+  hipEvent_t *ev_h2d, *ev_fast, *ev_call, *ev_d2h, *ev_depth;  // [cap_chunks]
+  unsigned *h_depth;            // [cap_chunks], pinned: the deepest sample of every chunk (pcs_depth_kernel), read by the host
   char *h_in[PCS_SLOTS], *h_out[PCS_SLOTS];            // pinned staging for callers whose buffers are not pinned
   size_t h_in_bytes, h_out_bytes;
 };
@@ -133,6 +138,13 @@ extern "C" int pecall_dev_create (pecall_dev ** out, int device_id)
   PCCHK (nullptr, hipMalloc ((void **) &d->d_tab, sizeof (double) * PC_TABLE));
   PCCHK (nullptr, hipMemcpy (d->d_tab, tab, sizeof (double) * PC_TABLE, hipMemcpyHostToDevice));
   free (tab);
+  {
+    uint32_t *ta = (uint32_t *) malloc (PCS_TA_BYTES);
+    pcs_ta_table (ta);
+    PCCHK (nullptr, hipMalloc ((void **) &d->d_ta, PCS_TA_BYTES));
+    PCCHK (nullptr, hipMemcpy (d->d_ta, ta, PCS_TA_BYTES, hipMemcpyHostToDevice));
+    free (ta);
+  }
   PCCHK (nullptr, hipFuncSetAttribute ((const void *) pc_site_like_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PC_TABLE * 8));
   *out = d;
   return 0;
@@ -163,6 +175,7 @@ extern "C" void pecall_dev_destroy (pecall_dev * d)
   hipFree (d->d_ac);
   hipFree (d->d_den);
   hipFree (d->d_ped);
+  hipFree (d->d_ta);
   hipFree (d->d_dyad);
   hipFree (d->d_trio);
   hipFree (d->d_slow);
@@ -178,7 +191,11 @@ extern "C" void pecall_dev_destroy (pecall_dev * d)
       hipEventDestroy (d->ev_fast[k]);
       hipEventDestroy (d->ev_call[k]);
       hipEventDestroy (d->ev_d2h[k]);
+      hipEventDestroy (d->ev_depth[k]);
     }
+  free (d->ev_depth);
+  if (d->h_depth)
+    hipHostFree (d->h_depth);
   free (d->ev_h2d);
   free (d->ev_fast);
   free (d->ev_call);
@@ -343,10 +360,15 @@ static int pcs_ensure (pecall_dev * d, long n_sites, int indiv)
       free (off);
       d->hw_indiv = indiv;
     }
-  if (!d->d_scratch)
+  const int row = 64 * ((indiv + 63) / 64 > 2 ? 4 : (indiv + 63) / 64);
+  if (!d->d_scratch || row > d->scratch_row)
     {
+      PCCHK (d, hipDeviceSynchronize ());
+      hipFree (d->d_scratch);
+      d->d_scratch = nullptr;
       d->site_grid = d->grid * 4;       // 8 waves per CU; LDS admits 4 resident, the rest queue
-      PCCHK (d, hipMalloc ((void **) &d->d_scratch, (size_t) d->site_grid * (2 * PCS_BIG_BYTES + PCS_BIGCAP)));
+      PCCHK (d, hipMalloc ((void **) &d->d_scratch, (size_t) d->site_grid * (2 * PCS_BIG_BYTES_OF (row) + PCS_BIGCAP)));
+      d->scratch_row = row;
     }
   long items = n_sites * indiv;
   if (n_sites > d->cap_ssites || items > d->cap_sitems)
@@ -448,14 +470,14 @@ extern "C" int pecall_dev_set_pedigree (pecall_dev * d, int indiv, const int *da
     {
       if (dad[i] >= indiv || mom[i] >= indiv)
         return pc_fail (d, "set_pedigree: parent index out of range for sample %d", i);
-      d->h_dad[i] = (int8_t) (dad[i] < 0 ? -1 : dad[i]);
-      d->h_mom[i] = (int8_t) (mom[i] < 0 ? -1 : mom[i]);
+      d->h_dad[i] = (int16_t) (dad[i] < 0 ? -1 : dad[i]);
+      d->h_mom[i] = (int16_t) (mom[i] < 0 ? -1 : mom[i]);
       d->h_sex[i] = (int8_t) sex[i];
     }
   for (int i = 0; i <= indiv; i++)
-    d->h_kid_off[i] = (uint8_t) kid_off[i];
+    d->h_kid_off[i] = (uint16_t) kid_off[i];
   for (int i = 0; i < kid_off[indiv]; i++)
-    d->h_kid_list[i] = (uint8_t) kid_list[i];
+    d->h_kid_list[i] = (uint16_t) kid_list[i];
   d->ped_indiv = indiv;
   d->denovo_rate = denovo_rate;
   d->ped_haploid = -1;          // tables are made at the next call, for its ploidy
@@ -466,7 +488,7 @@ static int pcs_ensure_ped (pecall_dev * d, int haploid)
 {
   if (!d->d_ped)
     {
-      PCCHK (d, hipMalloc ((void **) &d->d_ped, 3 * PCS_MAXN + 72 + 2 * PCS_MAXN));
+      PCCHK (d, hipMalloc ((void **) &d->d_ped, sizeof (int16_t) * (5 * PCS_MAXN + 8) + PCS_MAXN));
       PCCHK (d, hipMalloc ((void **) &d->d_dyad, sizeof (short) * 4 * 225));
       PCCHK (d, hipMalloc ((void **) &d->d_trio, sizeof (short) * 4 * 3375));
     }
@@ -478,11 +500,11 @@ static int pcs_ensure_ped (pecall_dev * d, int haploid)
       PCCHK (d, hipMemcpy (d->d_trio, tr, sizeof (short) * 4 * 3375, hipMemcpyHostToDevice));
       free (dy);
       free (tr);
-      PCCHK (d, hipMemcpy (d->d_ped, d->h_dad, PCS_MAXN, hipMemcpyHostToDevice));
-      PCCHK (d, hipMemcpy (d->d_ped + PCS_MAXN, d->h_mom, PCS_MAXN, hipMemcpyHostToDevice));
-      PCCHK (d, hipMemcpy (d->d_ped + 2 * PCS_MAXN, d->h_sex, PCS_MAXN, hipMemcpyHostToDevice));
-      PCCHK (d, hipMemcpy (d->d_ped + 3 * PCS_MAXN, d->h_kid_off, PCS_MAXN + 1, hipMemcpyHostToDevice));
-      PCCHK (d, hipMemcpy (d->d_ped + 3 * PCS_MAXN + 72, d->h_kid_list, 2 * PCS_MAXN, hipMemcpyHostToDevice));
+      PCCHK (d, hipMemcpy (d->d_ped, d->h_dad, sizeof (int16_t) * PCS_MAXN, hipMemcpyHostToDevice));
+      PCCHK (d, hipMemcpy (d->d_ped + PCS_MAXN, d->h_mom, sizeof (int16_t) * PCS_MAXN, hipMemcpyHostToDevice));
+      PCCHK (d, hipMemcpy (d->d_ped + 2 * PCS_MAXN, d->h_kid_off, sizeof (uint16_t) * (PCS_MAXN + 1), hipMemcpyHostToDevice));
+      PCCHK (d, hipMemcpy (d->d_ped + 3 * PCS_MAXN + 8, d->h_kid_list, sizeof (uint16_t) * 2 * PCS_MAXN, hipMemcpyHostToDevice));
+      PCCHK (d, hipMemcpy (d->d_ped + 5 * PCS_MAXN + 8, d->h_sex, PCS_MAXN, hipMemcpyHostToDevice));
       d->ped_haploid = haploid;
     }
   return 0;
@@ -537,9 +559,9 @@ static int pcs_params (pecall_dev * d, int indiv, int haploid, double threshold,
   P.ln_denovo = d->ped_indiv ? log (d->denovo_rate) : 0.0;
   P.dad = d->d_ped;
   P.mom = d->d_ped + PCS_MAXN;
-  P.sex = d->d_ped + 2 * PCS_MAXN;
-  P.kid_off = (const uint8_t *) d->d_ped + 3 * PCS_MAXN;
-  P.kid_list = (const uint8_t *) d->d_ped + 3 * PCS_MAXN + 72;
+  P.kid_off = (const uint16_t *) (d->d_ped + 2 * PCS_MAXN);
+  P.kid_list = (const uint16_t *) (d->d_ped + 3 * PCS_MAXN + 8);
+  P.sex = (const int8_t *) (d->d_ped + 5 * PCS_MAXN + 8);
   P.dyad = d->d_dyad;
   P.trio = d->d_trio;
   return 0;
@@ -563,6 +585,7 @@ static int pcs_ensure_chunks (pecall_dev * d, long n_sites)
       PCCHK (d, hipStreamCreateWithFlags (&d->stream_h2d, hipStreamNonBlocking));
       PCCHK (d, hipStreamCreateWithFlags (&d->stream_d2h, hipStreamNonBlocking));
       PCCHK (d, hipFuncSetAttribute ((const void *) pcs_fast_kernel < PC_TABLE >, hipFuncAttributeMaxDynamicSharedMemorySize, PCS_FAST_LDS_BYTES_OF (PC_TABLE)));
+      PCCHK (d, hipFuncSetAttribute ((const void *) pcs_call_kernel < 4 >, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof (PcsShared < 4 >)));
     }
   if (!d->ev_site[0])
     {
@@ -580,66 +603,103 @@ static int pcs_ensure_chunks (pecall_dev * d, long n_sites)
       d->ev_fast = (hipEvent_t *) realloc (d->ev_fast, sizeof (hipEvent_t) * nch);
       d->ev_call = (hipEvent_t *) realloc (d->ev_call, sizeof (hipEvent_t) * nch);
       d->ev_d2h = (hipEvent_t *) realloc (d->ev_d2h, sizeof (hipEvent_t) * nch);
+      d->ev_depth = (hipEvent_t *) realloc (d->ev_depth, sizeof (hipEvent_t) * nch);
+      if (d->h_depth)
+        hipHostFree (d->h_depth);
+      d->h_depth = nullptr;
+      PCCHK (d, hipHostMalloc ((void **) &d->h_depth, sizeof (unsigned) * nch, hipHostMallocDefault));
       for (int k = d->cap_chunks; k < nch; k++)
         {
           PCCHK (d, hipEventCreateWithFlags (&d->ev_h2d[k], hipEventDisableTiming));
           PCCHK (d, hipEventCreateWithFlags (&d->ev_fast[k], hipEventDisableTiming));
           PCCHK (d, hipEventCreateWithFlags (&d->ev_call[k], hipEventDisableTiming));
           PCCHK (d, hipEventCreateWithFlags (&d->ev_d2h[k], hipEventDisableTiming));
+          PCCHK (d, hipEventCreateWithFlags (&d->ev_depth[k], hipEventDisableTiming));
         }
       d->cap_chunks = nch;
     }
   return 0;
 }
 
-// the two kernels of chunk k = columns [off, off + m): the shortcut kernel (with the small beam) on the object's stream, the beam
-// search of the columns it lists on a stream of its own, so that it runs beside the next chunk's shortcut kernel
-static int pcs_run_chunk (pecall_dev * d, const PcsParams & P, int k, long off, long m)
+// Chunk k = columns [off, off + m), first half: its counters, and the deepest sample of its columns on its way to the host -- the
+// host picks the form of the shortcut kernel by it (the table's head in LDS, or the whole table: a workgroup of that form needs 112 KB
+// of a CU's LDS and is not even started where it would only return).
+static int pcs_chunk_depth (pecall_dev * d, const PcsParams & P, int k, long off, long m)
+{
+  const int N = P.indiv;
+  unsigned long long *ctr = d->d_next_site + (size_t) k * 4;
+  PCCHK (d, hipMemsetAsync (ctr, 0, 4 * sizeof (unsigned long long), d->stream));
+  d->h_depth[k] = 0u;
+  if (N <= 64)
+    {
+      unsigned *depth_max = (unsigned *) (ctr + 3);
+      long dgrid = (m * N + 255) / 256;
+      if (dgrid > d->grid * 4)
+        dgrid = d->grid * 4;
+      hipLaunchKernelGGL (pcs_depth_kernel, dim3 ((unsigned) dgrid), dim3 (256), 0, d->stream, d->d_sreads + off * N * PCS_NA, m * N, depth_max);
+      PCCHK (d, hipMemcpyAsync (&d->h_depth[k], depth_max, sizeof (unsigned), hipMemcpyDeviceToHost, d->stream));
+    }
+  PCCHK (d, hipEventRecord (d->ev_depth[k], d->stream));
+  return 0;
+}
+
+// second half: the shortcut kernel (with the small beam) on the object's stream, the beam search of the columns it lists on one of
+// PCS_CALL_STREAMS streams, so that it runs beside the next chunks' shortcut kernels
+static int pcs_chunk_kernels (pecall_dev * d, const PcsParams & P, int k, long off, long m)
 {
   const int N = P.indiv;
   unsigned long long *ctr = d->d_next_site + (size_t) k * 4;
   unsigned *n_slow = (unsigned *) (ctr + 1);
   unsigned *slow = d->d_slow + (size_t) PCS_BUCKETS * off;
-  PCCHK (d, hipMemsetAsync (ctr, 0, 4 * sizeof (unsigned long long), d->stream));
-  // the deepest sample of the chunk picks the form of the shortcut kernel (the other one returns at once)
-  unsigned *depth_max = (unsigned *) (ctr + 3);
-  {
-    long dgrid = (m * N + 255) / 256;
-    if (dgrid > d->grid * 4)
-      dgrid = d->grid * 4;
-    hipLaunchKernelGGL (pcs_depth_kernel, dim3 ((unsigned) dgrid), dim3 (256), 0, d->stream, d->d_sreads + off * N * PCS_NA, m * N, depth_max);
-  }
-  {
-    constexpr int B = PCS_FAST_BLOCK_OF (PCS_FAST_TAB);
-    long fgrid = (m + B / 64 - 1) / (B / 64);
-    if (fgrid > (long) d->grid / 2 * 3)
-      fgrid = (long) d->grid / 2 * 3;     // three workgroups of 4 waves per CU
-    hipLaunchKernelGGL (HIP_KERNEL_NAME (pcs_fast_kernel < PCS_FAST_TAB >), dim3 ((unsigned) fgrid), dim3 (B), PCS_FAST_LDS_BYTES_OF (PCS_FAST_TAB), d->stream, P,
-                        d->d_sreads + off * N * PCS_NA, d->d_dom + off, d->d_chromy + off, m, d->d_call + off * N, d->d_post + off * N, d->d_type + off,
-                        d->d_ac + off * PCS_NA, d->d_npass + off, d->d_den + off, slow, n_slow, depth_max);
-  }
-  {
-    constexpr int B = PCS_FAST_BLOCK_OF (PC_TABLE);
-    long fgrid = (m + B / 64 - 1) / (B / 64);
-    if (fgrid > d->grid / 2)
-      fgrid = d->grid / 2;        // one workgroup per CU: the whole ln n! table takes half its LDS
-    hipLaunchKernelGGL (HIP_KERNEL_NAME (pcs_fast_kernel < PC_TABLE >), dim3 ((unsigned) fgrid), dim3 (B), PCS_FAST_LDS_BYTES_OF (PC_TABLE), d->stream, P,
-                        d->d_sreads + off * N * PCS_NA, d->d_dom + off, d->d_chromy + off, m, d->d_call + off * N, d->d_post + off * N, d->d_type + off,
-                        d->d_ac + off * PCS_NA, d->d_npass + off, d->d_den + off, slow, n_slow, depth_max);
-  }
+  const int nch = N <= 64 ? 1 : N <= 128 ? 2 : 4;
+  if (nch == 1)
+    {
+      unsigned *depth_max = (unsigned *) (ctr + 3);
+      PCCHK (d, hipEventSynchronize (d->ev_depth[k]));
+      // (every n the columns look up: <= 6 x 100 + depth; the form with the table's head serves when that stays inside it -- the
+      // kernels test the same and return when launched in the wrong form)
+      if (d->h_depth[k] + 6u * 100u + 1u < (unsigned) PCS_FAST_TAB)
+        {
+          constexpr int B = PCS_FAST_BLOCK_OF (PCS_FAST_TAB);
+          long fgrid = (m + B / 64 - 1) / (B / 64);
+          if (fgrid > (long) d->grid / 2 * 3)
+            fgrid = (long) d->grid / 2 * 3;     // three workgroups of 4 waves per CU
+          hipLaunchKernelGGL (HIP_KERNEL_NAME (pcs_fast_kernel < PCS_FAST_TAB >), dim3 ((unsigned) fgrid), dim3 (B), PCS_FAST_LDS_BYTES_OF (PCS_FAST_TAB), d->stream, P,
+                              d->d_sreads + off * N * PCS_NA, d->d_dom + off, d->d_chromy + off, m, d->d_call + off * N, d->d_post + off * N, d->d_type + off,
+                              d->d_ac + off * PCS_NA, d->d_npass + off, d->d_den + off, slow, n_slow, depth_max, d->d_ta);
+        }
+      else
+        {
+          constexpr int B = PCS_FAST_BLOCK_OF (PC_TABLE);
+          long fgrid = (m + B / 64 - 1) / (B / 64);
+          if (fgrid > d->grid / 2)
+            fgrid = d->grid / 2;        // one workgroup per CU: the whole ln n! table takes half its LDS
+          hipLaunchKernelGGL (HIP_KERNEL_NAME (pcs_fast_kernel < PC_TABLE >), dim3 ((unsigned) fgrid), dim3 (B), PCS_FAST_LDS_BYTES_OF (PC_TABLE), d->stream, P,
+                              d->d_sreads + off * N * PCS_NA, d->d_dom + off, d->d_chromy + off, m, d->d_call + off * N, d->d_post + off * N, d->d_type + off,
+                              d->d_ac + off * PCS_NA, d->d_npass + off, d->d_den + off, slow, n_slow, depth_max, d->d_ta);
+        }
+    }
+  // (more than 64 samples: no shortcut kernel; the beam search's kernel takes every column of the chunk, a lane standing for a
+  // sample of each chunk of 64 -- the reference's range, any INDIV (pecaller.c:251-257), not this library's fast case)
   PCCHK (d, hipEventRecord (d->ev_fast[k], d->stream));
   // (a chunk lists a few hundred columns for the beam search, a handful of them heavy -- milliseconds on one wave: behind each other
   // on one stream the chunks' searches were the caller's time, 8 x 5.5 ms.  They alternate on PCS_CALL_STREAMS streams.)
   hipStream_t sc = d->stream_call[k % PCS_CALL_STREAMS];
   const long cgrid = d->site_grid / PCS_CALL_STREAMS;
   PCCHK (d, hipStreamWaitEvent (sc, d->ev_fast[k], 0));
-  if (k >= PCS_CALL_STREAMS)
-    PCCHK (d, hipStreamWaitEvent (sc, d->ev_call[k - PCS_CALL_STREAMS], 0));     // (same stream: in order anyway)
   const long grid = m < cgrid ? m : cgrid;
-  char *scratch = d->d_scratch + (size_t) (k % PCS_CALL_STREAMS) * (size_t) cgrid * (2 * PCS_BIG_BYTES + PCS_BIGCAP);
-  hipLaunchKernelGGL (pcs_call_kernel, dim3 ((unsigned) grid), dim3 (64), 0, sc, P, d->d_sreads + off * N * PCS_NA, d->d_dom + off, d->d_chromy + off,
-                      m, d->d_call + off * N, d->d_post + off * N, d->d_type + off, d->d_ac + off * PCS_NA, d->d_npass + off, d->d_den + off, scratch, ctr,
-                      slow, n_slow);
+  const int row = 64 * nch;
+  char *scratch = d->d_scratch + (size_t) (k % PCS_CALL_STREAMS) * (size_t) cgrid * (2 * PCS_BIG_BYTES_OF (row) + PCS_BIGCAP);
+#define PCS_CALL(NCH_, LIST, NLIST) hipLaunchKernelGGL (HIP_KERNEL_NAME (pcs_call_kernel < NCH_ >), dim3 ((unsigned) grid), dim3 (64), sizeof (PcsShared < NCH_ >), sc, P, \
+    d->d_sreads + off * N * PCS_NA, d->d_dom + off, d->d_chromy + off, m, d->d_call + off * N, d->d_post + off * N, d->d_type + off, d->d_ac + off * PCS_NA, \
+    d->d_npass + off, d->d_den + off, scratch, ctr, LIST, NLIST)
+  if (nch == 1)
+    PCS_CALL (1, slow, n_slow);
+  else if (nch == 2)
+    PCS_CALL (2, (const unsigned *) nullptr, (const unsigned *) nullptr);
+  else
+    PCS_CALL (4, (const unsigned *) nullptr, (const unsigned *) nullptr);
+#undef PCS_CALL
   PCCHK (d, hipGetLastError ());
   PCCHK (d, hipEventRecord (d->ev_call[k], sc));
   return 0;
@@ -661,7 +721,11 @@ extern "C" int pecall_dev_sites_run (pecall_dev * d, int haploid, double thresho
   PCCHK (d, hipEventRecord (d->ev_site[0], d->stream));
   int k = 0;
   for (long off = 0; off < n_sites; off += d->chunk_sites, k++)
-    if ((rc = pcs_run_chunk (d, P, k, off, n_sites - off < d->chunk_sites ? n_sites - off : d->chunk_sites)))
+    if ((rc = pcs_chunk_depth (d, P, k, off, n_sites - off < d->chunk_sites ? n_sites - off : d->chunk_sites)))
+      return rc;
+  k = 0;
+  for (long off = 0; off < n_sites; off += d->chunk_sites, k++)
+    if ((rc = pcs_chunk_kernels (d, P, k, off, n_sites - off < d->chunk_sites ? n_sites - off : d->chunk_sites)))
       return rc;
   // (the object's stream ends behind the last beam searches: ev_site[1] closes the interval of all streams)
   for (int q = k > PCS_CALL_STREAMS ? k - PCS_CALL_STREAMS : 0; q < k; q++)
@@ -817,9 +881,40 @@ extern "C" int pecall_dev_call_sites (pecall_dev * d, const uint16_t * reads, co
       memcpy (denovo + off, o, (size_t) m * 4);
     return 0;
   };
+  // chunk j's kernels, and its results on their way out behind its beam search (which follows its shortcut kernel)
+  auto kernels_and_out = [&] (int j) -> int
+  {
+    const long off = (long) j * C, m = n_sites - off < C ? n_sites - off : C;
+    int rc2 = pcs_chunk_kernels (d, P, j, off, m);
+    if (rc2)
+      return rc2;
+    PCCHK (d, hipStreamWaitEvent (d->stream_d2h, d->ev_call[j], 0));
+    if (!out_direct && j >= PCS_SLOTS && (rc2 = finish (j - PCS_SLOTS)))
+      return rc2;
+    char *o = out_direct ? nullptr : d->h_out[j % PCS_SLOTS];
+#define PCS_OUT(dst_host, dev_ptr, bytes) do { void *dst_ = out_direct ? (void *) (dst_host) : (void *) o; if (out_direct ? (dst_host) != nullptr : true) \
+    PCCHK (d, hipMemcpyAsync (dst_, dev_ptr, bytes, hipMemcpyDeviceToHost, d->stream_d2h)); if (!out_direct) o += (bytes); } while (0)
+    PCS_OUT (call + off * N, d->d_call + off * N, (size_t) m * N);
+    PCS_OUT (posterior + off * N, d->d_post + off * N, (size_t) m * N * 8);
+    PCS_OUT (site_type ? site_type + off : nullptr, d->d_type + off, (size_t) m);
+    PCS_OUT (n_pass ? n_pass + off : nullptr, d->d_npass + off, (size_t) m);
+    PCS_OUT (allele_count ? allele_count + off * PCS_NA : nullptr, d->d_ac + off * PCS_NA, (size_t) m * PCS_NA * 4);
+    PCS_OUT (denovo ? denovo + off : nullptr, d->d_den + off, (size_t) m * 4);
+#undef PCS_OUT
+    PCCHK (d, hipEventRecord (d->ev_d2h[j], d->stream_d2h));
+    return 0;
+  };
+  const bool trace = getenv ("PECALL_SEAM_TRACE") != nullptr;
+  const auto t_start = std::chrono::steady_clock::now ();
+  auto since = [&] () { return std::chrono::duration < double, std::milli > (std::chrono::steady_clock::now () - t_start).count (); };
   for (int k = 0; k < nch; k++)
     {
       const long off = (long) k * C, m = n_sites - off < C ? n_sites - off : C;
+      const double t0 = since ();
+      // ---- the kernels of the chunk before (its depth has reached the host by now, or soon): they run while this chunk is staged and
+      //      travels
+      if (k >= 1 && (rc = kernels_and_out (k - 1)))
+        return rc;
       // ---- in: (a staging slot is free again when the chunk that used it PCS_SLOTS chunks ago has been copied to the device, and
       //      its results have left the slot of the same number: finish (k - PCS_SLOTS) below ran before this)
       const uint16_t *src_r = reads + off * N * PCS_NA;
@@ -848,31 +943,25 @@ extern "C" int pecall_dev_call_sites (pecall_dev * d, const uint16_t * reads, co
       else
         PCCHK (d, hipMemsetAsync (d->d_chromy + off, 0, (size_t) m, d->stream_h2d));
       PCCHK (d, hipEventRecord (d->ev_h2d[k], d->stream_h2d));
-      // ---- the kernels
+      // ---- the chunk's counters and its depth (the host needs it for the kernels' launch: it launches them one chunk behind,
+      //      while this chunk's columns travel)
       PCCHK (d, hipStreamWaitEvent (d->stream, d->ev_h2d[k], 0));
-      if ((rc = pcs_run_chunk (d, P, k, off, m)))
+      if ((rc = pcs_chunk_depth (d, P, k, off, m)))
         return rc;
-      // ---- out: behind the chunk's beam search (which follows its shortcut kernel)
-      PCCHK (d, hipStreamWaitEvent (d->stream_d2h, d->ev_call[k], 0));
-      if (!out_direct && k >= PCS_SLOTS && (rc = finish (k - PCS_SLOTS)))
-        return rc;
-      char *o = out_direct ? nullptr : d->h_out[k % PCS_SLOTS];
-#define PCS_OUT(dst_host, dev_ptr, bytes) do { void *dst_ = out_direct ? (void *) (dst_host) : (void *) o; if (out_direct ? (dst_host) != nullptr : true) \
-    PCCHK (d, hipMemcpyAsync (dst_, dev_ptr, bytes, hipMemcpyDeviceToHost, d->stream_d2h)); if (!out_direct) o += (bytes); } while (0)
-      PCS_OUT (call + off * N, d->d_call + off * N, (size_t) m * N);
-      PCS_OUT (posterior + off * N, d->d_post + off * N, (size_t) m * N * 8);
-      PCS_OUT (site_type ? site_type + off : nullptr, d->d_type + off, (size_t) m);
-      PCS_OUT (n_pass ? n_pass + off : nullptr, d->d_npass + off, (size_t) m);
-      PCS_OUT (allele_count ? allele_count + off * PCS_NA : nullptr, d->d_ac + off * PCS_NA, (size_t) m * PCS_NA * 4);
-      PCS_OUT (denovo ? denovo + off : nullptr, d->d_den + off, (size_t) m * 4);
-#undef PCS_OUT
-      PCCHK (d, hipEventRecord (d->ev_d2h[k], d->stream_d2h));
+      if (trace)
+        fprintf (stderr, "[pecall seam] chunk %d: host at %.2f ms, enqueued by %.2f ms (direct in %d out %d)\n", k, t0, since (), (int) in_direct, (int) out_direct);
     }
+  if ((rc = kernels_and_out (nch - 1)))
+    return rc;
+  if (trace)
+    fprintf (stderr, "[pecall seam] last kernels enqueued by %.2f ms\n", since ());
   for (int j = (out_direct || nch < PCS_SLOTS) ? 0 : nch - PCS_SLOTS; j < nch; j++)
     if ((rc = finish (j)))
       return rc;
   PCCHK (d, hipStreamSynchronize (d->stream));
   for (int i = 0; i < PCS_CALL_STREAMS; i++)
     PCCHK (d, hipStreamSynchronize (d->stream_call[i]));
+  if (trace)
+    fprintf (stderr, "[pecall seam] done at %.2f ms\n", since ());
   return 0;
 }

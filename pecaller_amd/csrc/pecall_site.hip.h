@@ -22,7 +22,8 @@
 #include <stdint.h>
 #include "pecall_kernels.hip.h"
 
-#define PCS_MAXN 64
+#define PCS_MAXN 256            // samples per call at most: one lane per sample and chunk of 64 (NCH = 1, 2 or 4 chunks)
+#define PCS_ROW(NCH) (64 * (NCH))
 #define PCS_NA 6
 #define PCS_NG 14
 #define PCS_MAXCFG 514          // max_configs, pecaller.c:1180
@@ -40,8 +41,9 @@ struct PcsParams
   // pedigree (use_ped = y): parents (-1 = none), sex, each sample's kids in ped-file order, the de-novo tables of main
   int use_ped;
   double ln_denovo;
-  const int8_t *dad, *mom, *sex;        // [64]
-  const uint8_t *kid_off, *kid_list;    // [65], [128]
+  const int16_t *dad, *mom;             // [PCS_MAXN]
+  const int8_t *sex;                    // [PCS_MAXN]
+  const uint16_t *kid_off, *kid_list;   // [PCS_MAXN + 1], [2 * PCS_MAXN]
   const short *dyad;            // [4][15][15]
   const short *trio;            // [4][15][15][15]
 };
@@ -57,12 +59,13 @@ struct PcsPool
   uint16_t *ord;                // list position -> slot
   uint16_t *ord2;               // scratch of the sort
   int cap;                      // longest list
+  int row;                      // bytes of a calls row: 64 per chunk of samples
 };
 
-struct __align__ (16) PcsSmallPool
+template < int NCH > struct __align__ (16) PcsSmallPool
 {
   double like[PCS_SMALLCAP], prior[PCS_SMALLCAP], post[PCS_SMALLCAP];
-  int8_t calls[PCS_SMALLCAP][PCS_MAXN];
+  int8_t calls[PCS_SMALLCAP][PCS_ROW (NCH)];
   int16_t acount[PCS_SMALLCAP][PCS_NA];
   int16_t hets[PCS_SMALLCAP], nden[PCS_SMALLCAP];
   uint16_t ord[PCS_SMALLCAP], ord2[PCS_SMALLCAP];
@@ -70,19 +73,51 @@ struct __align__ (16) PcsSmallPool
 };
 
 // bytes of one per-wave pool in HBM
-#define PCS_BIG_BYTES ((size_t) PCS_BIGCAP * (3 * 8 + PCS_MAXN + 2 * PCS_NA + 2 + 2 + 2 + 2 + 1 + 5))
+#define PCS_BIG_BYTES_OF(ROW) ((size_t) PCS_BIGCAP * (3 * 8 + (ROW) + 2 * PCS_NA + 2 + 2 + 2 + 2 + 1 + 5))
 
-struct __align__ (16) PcsShared
+template < int NCH > struct __align__ (16) PcsShared
 {
-  PcsSmallPool pool[2];
-  double like[PCS_MAXN][PCS_NG + 1];    // per-sample genotype log-likelihoods of the pass
+  PcsSmallPool < NCH > pool[2];
+  double like[PCS_ROW (NCH)][PCS_NG + 1];       // per-sample genotype log-likelihoods of the pass
   double mean[PCS_NG][PCS_NA], var[PCS_NG][PCS_NA], wt[PCS_NG][PCS_NA], fr[PCS_NG][PCS_NA];
   int al[PCS_NG][PCS_NA], first[PCS_NG][PCS_NA];
-  int reads[PCS_MAXN][PCS_NA];
-  int tot[PCS_MAXN];
-  uint8_t sord[PCS_MAXN];               // samples by margin, descending
+  int reads[PCS_ROW (NCH)][PCS_NA];
+  int tot[PCS_ROW (NCH)];
+  uint8_t sord[PCS_ROW (NCH)];          // samples by margin, descending
   uint8_t dup[PCS_SMALLCAP];
 };
+
+// one bit per sample, 64 to a word: the samples above the depth floor, the settled ones ...
+template < int NCH > struct PcsMask
+{
+  unsigned long long w[NCH];
+  __device__ __forceinline__ bool test (int i) const
+  {
+    unsigned long long v = w[0];
+#pragma unroll
+    for (int c = 1; c < NCH; c++)
+      v = ((i >> 6) == c) ? w[c] : v;
+    return (v >> (i & 63)) & 1ull;
+  }
+  __device__ __forceinline__ int count () const
+  {
+    int n = 0;
+#pragma unroll
+    for (int c = 0; c < NCH; c++)
+      n += (int) __popcll (w[c]);
+    return n;
+  }
+};
+
+// element (chunk i >> 6) of a per-chunk register array, i the same in every lane
+template < int NCH, class T > __device__ __forceinline__ T pcs_chunk_of (const T (&x)[NCH], int i)
+{
+  T v = x[0];
+#pragma unroll
+  for (int c = 1; c < NCH; c++)
+    v = ((i >> 6) == c) ? x[c] : v;
+  return v;
+}
 
 __device__ __forceinline__ void pcs_sync ()
 {
@@ -101,7 +136,7 @@ __device__ __forceinline__ double pcs_bcast (double v, int l)
   return __hiloint2double (__builtin_amdgcn_readlane (__double2hiint (v), l), __builtin_amdgcn_readlane (__double2loint (v), l));
 }
 
-__device__ __forceinline__ void pcs_pool_small (PcsPool & p, PcsSmallPool * s)
+template < int NCH > __device__ __forceinline__ void pcs_pool_small (PcsPool & p, PcsSmallPool < NCH > *s)
 {
   p.like = s->like;
   p.prior = s->prior;
@@ -114,25 +149,27 @@ __device__ __forceinline__ void pcs_pool_small (PcsPool & p, PcsSmallPool * s)
   p.ord = s->ord;
   p.ord2 = s->ord2;
   p.cap = PCS_SMALL;
+  p.row = PCS_ROW (NCH);
 }
 
-__device__ __forceinline__ void pcs_pool_big (PcsPool & p, char *base)
+__device__ __forceinline__ void pcs_pool_big (PcsPool & p, char *base, int row)
 {
   p.like = (double *) base;
   p.prior = p.like + PCS_BIGCAP;
   p.post = p.prior + PCS_BIGCAP;
   p.calls = (int8_t *) (p.post + PCS_BIGCAP);
-  p.acount = (int16_t *) (p.calls + (size_t) PCS_BIGCAP * PCS_MAXN);
+  p.acount = (int16_t *) (p.calls + (size_t) PCS_BIGCAP * row);
   p.hets = p.acount + (size_t) PCS_BIGCAP * PCS_NA;
   p.ord = (uint16_t *) (p.hets + PCS_BIGCAP);
   p.ord2 = p.ord + PCS_BIGCAP;
   p.nden = (int16_t *) (p.ord2 + PCS_BIGCAP);
   p.nall = (int8_t *) (p.nden + PCS_BIGCAP);
   p.cap = PCS_BIGCAP - 8;
+  p.row = row;
 }
 
 // get_het_alleles, pecaller.c:2191-2245
-__device__ __forceinline__ void pcs_het (int g, int &a, int &b, int ref)
+__host__ __device__ __forceinline__ void pcs_het (int g, int &a, int &b, int ref)
 {
   if (g < PCS_NA)
     a = b = g;
@@ -171,11 +208,11 @@ __device__ __forceinline__ int pcs_order (int ref, int jj, int haploid)
 
 // fill_alpha_prior, pecaller.c:3043-3139: the integer Dirichlet pseudo-counts of genotype row g for reference base dom
 // (normal_factor 300: hom = 300, het = 150)
-__device__ __forceinline__ void pcs_alpha_prior_row (int g, int dom, int (&row)[PCS_NA])
+__host__ __device__ __forceinline__ void pcs_alpha_prior_row (int g, int dom, int (&row)[PCS_NA])
 {
   const int normal_factor = 300;
   const int hom = normal_factor, het = normal_factor / 2;
-  const int hom_err = max (1, hom / 300), err = max (1, (2 * het) / 300);
+  const int hom_err = hom / 300 > 1 ? hom / 300 : 1, err = (2 * het) / 300 > 1 ? (2 * het) / 300 : 1;
   for (int k = 0; k < PCS_NA; k++)
     row[k] = err;
   if (g < 4)
@@ -195,7 +232,7 @@ __device__ __forceinline__ void pcs_alpha_prior_row (int g, int dom, int (&row)[
       if (a == dom || b == dom)
         {
           for (int k = 0; k < PCS_NA; k++)
-            row[k] = (k == dom) ? (51 * het) / 50 : (k == (a == dom ? b : a)) ? (49 * het) / 50 : (k == 4) ? max (1, het / 20) : err;
+            row[k] = (k == dom) ? (51 * het) / 50 : (k == (a == dom ? b : a)) ? (49 * het) / 50 : (k == 4) ? (het / 20 > 1 ? het / 20 : 1) : err;
         }
       else
         for (int k = 0; k < PCS_NA; k++)
@@ -210,16 +247,18 @@ __device__ __forceinline__ void pcs_alpha_prior_row (int g, int dom, int (&row)[
 }
 
 // config_alloc, pecaller.c:2987-3027, into slot s: every sample above the depth floor called homozygous `dom`
-__device__ __forceinline__ void pcs_cfg_init (const PcsPool & p, int s, int dom, unsigned long long deep, int haploid, int lane)
+template < int NCH > __device__ __forceinline__ void pcs_cfg_init (const PcsPool & p, int s, int dom, const PcsMask < NCH > &deep, int haploid, int lane)
 {
-  p.calls[(size_t) s * PCS_MAXN + lane] = ((deep >> lane) & 1ull) ? (int8_t) dom : (int8_t) PCS_NG;
+#pragma unroll
+  for (int c = 0; c < NCH; c++)
+    p.calls[(size_t) s * p.row + 64 * c + lane] = ((deep.w[c] >> lane) & 1ull) ? (int8_t) dom : (int8_t) PCS_NG;
   if (lane < PCS_NA)
-    p.acount[s * PCS_NA + lane] = (lane == dom) ? (int16_t) (__popcll (deep) * (haploid ? 1 : 2)) : (int16_t) 0;
+    p.acount[s * PCS_NA + lane] = (lane == dom) ? (int16_t) (deep.count () * (haploid ? 1 : 2)) : (int16_t) 0;
   if (lane == 0)
     {
       p.hets[s] = 0;
       p.nden[s] = 0;
-      p.nall[s] = deep ? 1 : 0;
+      p.nall[s] = deep.count () ? 1 : 0;
       p.like[s] = 0;
       p.prior[s] = 0;
       p.post[s] = 1;
@@ -227,12 +266,12 @@ __device__ __forceinline__ void pcs_cfg_init (const PcsPool & p, int s, int dom,
 }
 
 // fill_config_like for slot s, by one lane
-__device__ __forceinline__ void pcs_cfg_like (const PcsPool & p, int s, const PcsShared & sh, unsigned long long deep, int N)
+template < int NCH > __device__ __forceinline__ void pcs_cfg_like (const PcsPool & p, int s, const PcsShared < NCH > &sh, const PcsMask < NCH > &deep, int N)
 {
   double l = 0;
   for (int i = 0; i < N; i++)
-    if ((deep >> i) & 1ull)
-      l += sh.like[i][p.calls[(size_t) s * PCS_MAXN + i]];
+    if (deep.test (i))
+      l += sh.like[i][p.calls[(size_t) s * p.row + i]];
   p.like[s] = l;
   p.post[s] = l + p.prior[s];
 }
@@ -259,8 +298,8 @@ __device__ __forceinline__ void pcs_sort (PcsPool & p, int n, int lane)
 }
 
 // clean_config_probs, pecaller.c:2248-2344; returns the new list length
-__device__ __forceinline__ int pcs_clean (PcsPool & p, int n, int ref, double ct, const PcsShared & sh, unsigned long long deep,
-                                         const PcsParams & P, int site_hap, int lane)
+template < int NCH > __device__ __forceinline__ int pcs_clean (PcsPool & p, int n, int ref, double ct, const PcsShared < NCH > &sh, const PcsMask < NCH > &deep,
+                                                              const PcsParams & P, int site_hap, int lane)
 {
   pcs_sort (p, n, lane);
   int mx = min (PCS_MAXCFG, n);
@@ -325,7 +364,8 @@ __device__ __forceinline__ void pcs_migrate (const PcsPool & from, const PcsPool
         to.acount[s * PCS_NA + k] = from.acount[s * PCS_NA + k];
     }
   for (int s = 0; s < n; s++)
-    to.calls[(size_t) s * PCS_MAXN + lane] = from.calls[(size_t) s * PCS_MAXN + lane];
+    for (int c = 0; c < from.row; c += 64)
+      to.calls[(size_t) s * to.row + c + lane] = from.calls[(size_t) s * from.row + c + lane];
   pcs_sync ();
 }
 
@@ -386,8 +426,8 @@ __device__ __forceinline__ int pcs_denovo_around (const PcsParams & P, const int
 // fill_config_probs, pecaller.c:2511-2788: the configurations of `cur` re-decided for sample `who`.
 // dupbuf: one byte per list position (LDS for short lists, HBM for long ones).  Returns the length of the list built in nw;
 // nw may be switched to `big_nw` (the wave's pool in HBM) when it outgrows LDS: *went_big is set.
-__device__ int pcs_expand (const PcsPool & cur, PcsPool & nw, const PcsPool & big_nw, bool &went_big, int n, int who, int ref, double thres,
-                           const PcsShared & sh, uint8_t * dupbuf, int r4, int r5, int chrom, int site_hap, const PcsParams & P, int lane)
+template < int NCH > __device__ int pcs_expand (const PcsPool & cur, PcsPool & nw, const PcsPool & big_nw, bool &went_big, int n, int who, int ref, double thres,
+                                                const PcsShared < NCH > &sh, uint8_t * dupbuf, int r4, int r5, int chrom, int site_hap, const PcsParams & P, int lane)
 {
   const int G = P.max_gen, N = P.indiv;
   // ---- a configuration equal to an earlier one on every other sample is skipped (pecaller.c:2542-2558)
@@ -395,11 +435,11 @@ __device__ int pcs_expand (const PcsPool & cur, PcsPool & nw, const PcsPool & bi
   const unsigned long long wmask = ~(0xFFull << (8 * (who & 7)));
   for (int i = lane; i < n; i += 64)
     {
-      const unsigned long long *ci = (const unsigned long long *) (cur.calls + (size_t) cur.ord[i] * PCS_MAXN);
+      const unsigned long long *ci = (const unsigned long long *) (cur.calls + (size_t) cur.ord[i] * cur.row);
       int dup = 0;
       for (int ii = 0; ii < i && !dup; ii++)
         {
-          const unsigned long long *cj = (const unsigned long long *) (cur.calls + (size_t) cur.ord[ii] * PCS_MAXN);
+          const unsigned long long *cj = (const unsigned long long *) (cur.calls + (size_t) cur.ord[ii] * cur.row);
           int same = 1;
           for (int w = 0; w < (N + 7) / 8 && same; w++)
             {
@@ -427,7 +467,7 @@ __device__ int pcs_expand (const PcsPool & cur, PcsPool & nw, const PcsPool & bi
       const int s = cur.ord[pos];
       const bool valid = in && !dupbuf[pos];
       const int j = pcs_order (ref, jj, P.haploid);
-      const int g_old = cur.calls[(size_t) s * PCS_MAXN + who];
+      const int g_old = cur.calls[(size_t) s * cur.row + who];
       double base = cur.like[s];
       if (g_old < PCS_NG)
         base -= sh.like[who][g_old];
@@ -459,7 +499,7 @@ __device__ int pcs_expand (const PcsPool & cur, PcsPool & nw, const PcsPool & bi
       int nden = 0;
       if (P.use_ped && valid)
         {
-          const int8_t *row = cur.calls + (size_t) s * PCS_MAXN;
+          const int8_t *row = cur.calls + (size_t) s * cur.row;
           nden = cur.nden[s] - (g_old < PCS_NG ? pcs_denovo_around (P, row, who, g_old, chrom, ref) : 0) + pcs_denovo_around (P, row, who, j, chrom, ref);
         }
       double prior = 0;
@@ -523,7 +563,9 @@ __device__ int pcs_expand (const PcsPool & cur, PcsPool & nw, const PcsPool & bi
             }
           const int sk = pcs_bcast (s, k), jk = pcs_bcast (j, k);
           const int d = newcount;
-          nw.calls[(size_t) d * PCS_MAXN + lane] = (lane == who) ? (int8_t) jk : cur.calls[(size_t) sk * PCS_MAXN + lane];
+#pragma unroll
+          for (int c = 0; c < NCH; c++)
+            nw.calls[(size_t) d * nw.row + 64 * c + lane] = (64 * c + lane == who) ? (int8_t) jk : cur.calls[(size_t) sk * cur.row + 64 * c + lane];
           const double pr = pcs_bcast (prior, k);
           const int hk = pcs_bcast (hets, k), nk = pcs_bcast (nall, k), dk = pcs_bcast (nden, k);
           int ak = 0;
@@ -552,33 +594,39 @@ __device__ int pcs_expand (const PcsPool & cur, PcsPool & nw, const PcsPool & bi
   return newcount;
 }
 
-// calls and site classification of one column (pecaller.c:1565-1636, de-novo rows 1650-1671), lane = sample: what the reference
-// prints for it -- calls and posteriors, Allele_Counts, the row's type, the passes it took
-__device__ __forceinline__ void pcs_write_site (const PcsParams & P, long site, int lane, int dom, int chrom, const int (&r)[PCS_NA], int tot,
-                                                double average_depth, int final_call, double final_p, int pass, int8_t * call, double *post_out,
-                                                int8_t * type_out, int32_t * allele_count, int8_t * n_pass, int32_t * denovo_out)
+// calls and site classification of one column (pecaller.c:1565-1636, de-novo rows 1650-1671), lane = sample (of each chunk of 64):
+// what the reference prints for it -- calls and posteriors, Allele_Counts, the row's type, the passes it took
+template < int NCH > __device__ __forceinline__ void pcs_write_site (const PcsParams & P, long site, int lane, int dom, int chrom, const int (&r)[NCH][PCS_NA],
+                                                                    const int (&tot)[NCH], double average_depth, const int (&final_call)[NCH],
+                                                                    const double (&final_p)[NCH], int pass, int8_t * call, double *post_out,
+                                                                    int8_t * type_out, int32_t * allele_count, int8_t * n_pass, int32_t * denovo_out)
 {
   const int N = P.indiv, md = P.min_depth;
   // ---- calls and site classification (pecaller.c:1565-1636)
   const double low_base = (8 > 0.4 * average_depth) ? 8 : 0.4 * average_depth;
   int ac6[PCS_NA] = { 0, 0, 0, 0, 0, 0 }, on_target = 0, off_target = 0, not_low = 0;
-  const bool called = lane < N && tot > md;
-  if (called && final_p >= P.threshold)
-    {
+  bool called[NCH];
 #pragma unroll
-      for (int a = 0; a < PCS_NA; a++)
+  for (int c = 0; c < NCH; c++)
+    {
+      called[c] = 64 * c + lane < N && tot[c] > md;
+      if (called[c] && final_p[c] >= P.threshold)
         {
-          const int k = pcs_ac (dom, final_call, a, P.haploid);
-          if (k)
+#pragma unroll
+          for (int a = 0; a < PCS_NA; a++)
             {
-              ac6[a] = k;
-              on_target += r[a];
+              const int k = pcs_ac (dom, final_call[c], a, P.haploid);
+              if (k)
+                {
+                  ac6[a] += k;
+                  on_target += r[c][a];
+                }
+              else if (a != dom || final_call[c] != PCS_NA - 1)
+                off_target += r[c][a];
             }
-          else if (a != dom || final_call != PCS_NA - 1)
-            off_target += r[a];
+          if (tot[c] > low_base && final_call[c] != dom)
+            not_low += 1;
         }
-      if (tot > low_base && final_call != dom)
-        not_low = 1;
     }
   for (int o = 32; o; o >>= 1)
     {
@@ -589,11 +637,13 @@ __device__ __forceinline__ void pcs_write_site (const PcsParams & P, long site, 
       off_target += __shfl_xor (off_target, o);
       not_low += __shfl_xor (not_low, o);
     }
-  if (lane < N)
-    {
-      call[site * N + lane] = called ? (int8_t) final_call : (int8_t) PCS_NG;
-      post_out[site * N + lane] = called ? final_p : 1.0;
-    }
+#pragma unroll
+  for (int c = 0; c < NCH; c++)
+    if (64 * c + lane < N)
+      {
+        call[site * N + 64 * c + lane] = called[c] ? (int8_t) final_call[c] : (int8_t) PCS_NG;
+        post_out[site * N + 64 * c + lane] = called[c] ? final_p[c] : 1.0;
+      }
   int n_all = 0, isdel = 0, isins = 0, type = 0;
 #pragma unroll
   for (int a = 0; a < PCS_NA; a++)
@@ -632,15 +682,45 @@ __device__ __forceinline__ void pcs_write_site (const PcsParams & P, long site, 
   int dcount = 0;
   if (type && P.use_ped)
     {
-      const int fc = called ? final_call : PCS_NG;
-      const double fp = called ? final_p : 1.0;
-      const int d = lane < N ? P.dad[lane] : -1, m = lane < N ? P.mom[lane] : -1;
-      const int dfc = __shfl (fc, d >= 0 ? d : 0), mfc = __shfl (fc, m >= 0 ? m : 0);
-      const double dfp = __hiloint2double (__shfl (__double2hiint (fp), d >= 0 ? d : 0), __shfl (__double2loint (fp), d >= 0 ? d : 0));
-      const double mfp = __hiloint2double (__shfl (__double2hiint (fp), m >= 0 ? m : 0), __shfl (__double2loint (fp), m >= 0 ? m : 0));
-      if (lane < N && fp >= P.threshold)
-        dcount = pcs_add_denovo (P, fc, (d >= 0 && dfp >= P.threshold) ? dfc : PCS_NG, (m >= 0 && mfp >= P.threshold) ? mfc : PCS_NG, P.sex[lane],
-                                 chrom, dom);
+      int fc[NCH];
+      double fp[NCH];
+#pragma unroll
+      for (int c = 0; c < NCH; c++)
+        {
+          fc[c] = called[c] ? final_call[c] : PCS_NG;
+          fp[c] = called[c] ? final_p[c] : 1.0;
+        }
+      // a parent's call and posterior: the parent's lane of the parent's chunk
+      auto from_sample = [&] (int who, int &c_out, double &p_out)
+      {
+        const int wl = who >= 0 ? (who & 63) : 0, wc = who >= 0 ? (who >> 6) : 0;
+        c_out = PCS_NG;
+        p_out = 1.0;
+#pragma unroll
+        for (int c = 0; c < NCH; c++)
+          {
+            const int vc = __shfl (fc[c], wl);
+            const double vp = __hiloint2double (__shfl (__double2hiint (fp[c]), wl), __shfl (__double2loint (fp[c]), wl));
+            if (wc == c)
+              {
+                c_out = vc;
+                p_out = vp;
+              }
+          }
+      };
+#pragma unroll
+      for (int c = 0; c < NCH; c++)
+        {
+          const int smp = 64 * c + lane;
+          const int d = smp < N ? P.dad[smp] : -1, m = smp < N ? P.mom[smp] : -1;
+          int dfc, mfc;
+          double dfp, mfp;
+          from_sample (d, dfc, dfp);
+          from_sample (m, mfc, mfp);
+          if (smp < N && fp[c] >= P.threshold)
+            dcount += pcs_add_denovo (P, fc[c], (d >= 0 && dfp >= P.threshold) ? dfc : PCS_NG, (m >= 0 && mfp >= P.threshold) ? mfc : PCS_NG, P.sex[smp],
+                                      chrom, dom);
+        }
       for (int o = 32; o; o >>= 1)
         dcount += __shfl_xor (dcount, o);
     }
@@ -652,23 +732,40 @@ __device__ __forceinline__ void pcs_write_site (const PcsParams & P, long site, 
     }
 }
 
+// (one chunk of samples, as the shortcut kernel has them)
+__device__ __forceinline__ void pcs_write_site (const PcsParams & P, long site, int lane, int dom, int chrom, const int (&r)[PCS_NA], int tot,
+                                                double average_depth, int final_call, double final_p, int pass, int8_t * call, double *post_out,
+                                                int8_t * type_out, int32_t * allele_count, int8_t * n_pass, int32_t * denovo_out)
+{
+  int r1[1][PCS_NA];
+#pragma unroll
+  for (int a = 0; a < PCS_NA; a++)
+    r1[0][a] = r[a];
+  const int t1[1] = { tot }, c1[1] = { final_call };
+  const double p1[1] = { final_p };
+  pcs_write_site < 1 > (P, site, lane, dom, chrom, r1, t1, average_depth, c1, p1, pass, call, post_out, type_out, allele_count, n_pass, denovo_out);
+}
+
 #define PCS_BUCKETS 4           // parts of the list of columns left to the beam search (pcs_fast_kernel files, pcs_call_kernel walks them)
 // One wave per site.  Outputs are what the reference prints per row: call 0..13 or 14 (N), posterior,
 // site type (0 REF, 1 SNP, 2 DEL, 3 INS, 4 LOW, 5 MULTIALLELIC, 6 MESS; -1 = reference base not A/C/G/T, skipped),
 // Allele_Counts, passes.
-__global__ __launch_bounds__ (64) void pcs_call_kernel (PcsParams P, const uint16_t * reads, const uint8_t * dom_of, const uint8_t * chrom_of,
-                                                      long n_sites, int8_t * call, double *post_out, int8_t * type_out,
-                                                      int32_t * allele_count, int8_t * n_pass, int32_t * denovo_out, char *scratch,
-                                                      unsigned long long *next_site, const unsigned *site_list, const unsigned *n_list)
+// NCH = chunks of 64 samples (1, 2 or 4): a lane stands for sample 64 c + lane of every chunk c
+extern __shared__ __align__ (16) uint8_t pcs_call_lds[];
+template < int NCH > __global__ __launch_bounds__ (64) void pcs_call_kernel (PcsParams P, const uint16_t * reads, const uint8_t * dom_of, const uint8_t * chrom_of,
+                                                                          long n_sites, int8_t * call, double *post_out, int8_t * type_out,
+                                                                          int32_t * allele_count, int8_t * n_pass, int32_t * denovo_out, char *scratch,
+                                                                          unsigned long long *next_site, const unsigned *site_list, const unsigned *n_list)
 {
-  __shared__ PcsShared sh;
+  PcsShared < NCH > &sh = *reinterpret_cast < PcsShared < NCH > *>(pcs_call_lds);
+  constexpr int ROW = PCS_ROW (NCH);
   const int lane = threadIdx.x;
   const int N = P.indiv, G = P.max_gen, md = P.min_depth;
-  char *my = scratch + (size_t) blockIdx.x * (2 * PCS_BIG_BYTES + PCS_BIGCAP);
+  char *my = scratch + (size_t) blockIdx.x * (2 * PCS_BIG_BYTES_OF (ROW) + PCS_BIGCAP);
   PcsPool bigp[2];
-  pcs_pool_big (bigp[0], my);
-  pcs_pool_big (bigp[1], my + PCS_BIG_BYTES);
-  uint8_t *big_dup = (uint8_t *) (my + 2 * PCS_BIG_BYTES);
+  pcs_pool_big (bigp[0], my, ROW);
+  pcs_pool_big (bigp[1], my + PCS_BIG_BYTES_OF (ROW), ROW);
+  uint8_t *big_dup = (uint8_t *) (my + 2 * PCS_BIG_BYTES_OF (ROW));
   // columns are handed out through a counter (the first grid-ful by block index): a column that needs the whole beam search
   // takes ~50 times as long as one settled by the shortcut below, so a fixed stride would leave most waves waiting for a few
   // (site_list: only the listed columns -- the ones pcs_fast_kernel could not settle)
@@ -707,11 +804,13 @@ __global__ __launch_bounds__ (64) void pcs_call_kernel (PcsParams P, const uint1
       const int site_hap = P.haploid | ((chrom_of[site] >> 4) & 1);
       if (dom > 3)
         {
-          if (lane < N)
-            {
-              call[site * N + lane] = PCS_NG;
-              post_out[site * N + lane] = 1.0;
-            }
+#pragma unroll
+          for (int c = 0; c < NCH; c++)
+            if (64 * c + lane < N)
+              {
+                call[site * N + 64 * c + lane] = PCS_NG;
+                post_out[site * N + 64 * c + lane] = 1.0;
+              }
           if (lane < PCS_NA)
             allele_count[site * PCS_NA + lane] = 0;
           if (lane == 0)
@@ -723,33 +822,48 @@ __global__ __launch_bounds__ (64) void pcs_call_kernel (PcsParams P, const uint1
           continue;
         }
       // ---- per-sample set-up (pecaller.c:1230-1260)
-      int r[PCS_NA], tot = 0;
+      int r[NCH][PCS_NA], tot[NCH];
+      double coef[NCH];
+      int initial_call[NCH], final_call[NCH];
+      double final_p[NCH];
+      int tsum = 0, sample_count = 0;
 #pragma unroll
-      for (int a = 0; a < PCS_NA; a++)
-        r[a] = lane < N ? (int) reads[(site * N + lane) * PCS_NA + a] : 0;
-      tot = r[0] + r[1] + r[2] + r[3] + r[4];
-      double coef = pc_factln (P.tab, tot);
+      for (int c = 0; c < NCH; c++)
+        {
+          const int smp = 64 * c + lane;
 #pragma unroll
-      for (int a = 0; a < PCS_NA; a++)
-        coef -= pc_factln (P.tab, r[a]);
-      int initial_call = tot > md ? dom : PCS_NG, final_call = initial_call;
-      double final_p = 1.0;
-      // average depth: the reference adds the integer totals into a double in sample order; integers add exactly
-      int tsum = tot;
+          for (int a = 0; a < PCS_NA; a++)
+            r[c][a] = smp < N ? (int) reads[(site * N + smp) * PCS_NA + a] : 0;
+          tot[c] = r[c][0] + r[c][1] + r[c][2] + r[c][3] + r[c][4];
+          coef[c] = pc_factln (P.tab, tot[c]);
+#pragma unroll
+          for (int a = 0; a < PCS_NA; a++)
+            coef[c] -= pc_factln (P.tab, r[c][a]);
+          initial_call[c] = tot[c] > md ? dom : PCS_NG;
+          final_call[c] = initial_call[c];
+          final_p[c] = 1.0;
+          // average depth: the reference adds the integer totals into a double in sample order; integers add exactly
+          tsum += tot[c];
+          sample_count += (int) __popcll (__ballot (smp < N && tot[c] >= 8));
+        }
       for (int o = 32; o; o >>= 1)
         tsum += __shfl_xor (tsum, o);
       const double average_depth = (double) tsum / (double) N;
       bool bad_base = average_depth < 8;
-      const int sample_count = __popcll (__ballot (lane < N && tot >= 8));
       if (sample_count < (double) 0.5 * N && chrom != 2)
         bad_base = true;
-      if (bad_base)
-        tot = 0;
-      const unsigned long long deep = __ballot (lane < N && tot > md);
+      PcsMask < NCH > deep;
 #pragma unroll
-      for (int a = 0; a < PCS_NA; a++)
-        sh.reads[lane][a] = r[a];
-      sh.tot[lane] = tot;
+      for (int c = 0; c < NCH; c++)
+        {
+          if (bad_base)
+            tot[c] = 0;
+          deep.w[c] = __ballot (64 * c + lane < N && tot[c] > md);
+#pragma unroll
+          for (int a = 0; a < PCS_NA; a++)
+            sh.reads[64 * c + lane][a] = r[c][a];
+          sh.tot[64 * c + lane] = tot[c];
+        }
       PcsPool pool[2];
       pcs_pool_small (pool[0], &sh.pool[0]);
       pcs_pool_small (pool[1], &sh.pool[1]);
@@ -794,46 +908,52 @@ __global__ __launch_bounds__ (64) void pcs_call_kernel (PcsParams P, const uint1
           double norm = 1.0;
           for (int i = 2; i <= pass; i++)
             norm *= 2.5;        // new_norm[pass], pecaller.c:1339-1344
-          double initial_p = 0.0;
-          initial_call = PCS_NG;
-          if (lane < N && tot > md)
+          double initial_p[NCH];
+#pragma unroll
+          for (int c = 0; c < NCH; c++)
             {
-              const double sc0 = (double) min (tot, 100) * norm;
-              const double sc1 = (10 > sc0) ? 10 : sc0;
-              const double scale = (1000 < sc1) ? 1000 : sc1;
-              double mx = -1e100;
-              int best = PCS_NG;
-              for (int g = 0; g < G; g++)
+              const int smp = 64 * c + lane;
+              initial_p[c] = 0.0;
+              initial_call[c] = PCS_NG;
+              if (smp < N && tot[c] > md)
                 {
-                  int tot_a = 0, tot_tot = 0;
-                  double cf = coef, lk = 0.0;
-                  for (int a = 0; a < PCS_NA; a++)
+                  const double sc0 = (double) min (tot[c], 100) * norm;
+                  const double sc1 = (10 > sc0) ? 10 : sc0;
+                  const double scale = (1000 < sc1) ? 1000 : sc1;
+                  double mx = -1e100;
+                  int best = PCS_NG;
+                  for (int g = 0; g < G; g++)
                     {
-                      const double cv = ceil (scale * sh.mean[g][a]);
-                      const int ta = (int) ((1 > cv) ? 1 : cv);
-                      tot_a += ta;
-                      tot_tot += ta + r[a];
-                      cf -= pc_factln (P.tab, ta - 1);
-                      lk += pc_factln (P.tab, ta + r[a] - 1);
+                      int tot_a = 0, tot_tot = 0;
+                      double cf = coef[c], lk = 0.0;
+                      for (int a = 0; a < PCS_NA; a++)
+                        {
+                          const double cv = ceil (scale * sh.mean[g][a]);
+                          const int ta = (int) ((1 > cv) ? 1 : cv);
+                          tot_a += ta;
+                          tot_tot += ta + r[c][a];
+                          cf -= pc_factln (P.tab, ta - 1);
+                          lk += pc_factln (P.tab, ta + r[c][a] - 1);
+                        }
+                      cf += pc_factln (P.tab, tot_a - 1);
+                      lk += cf;
+                      lk -= pc_factln (P.tab, tot_tot - 1);
+                      sh.like[smp][g] = lk;
+                      if (lk > mx)
+                        {
+                          best = g;
+                          mx = lk;
+                        }
                     }
-                  cf += pc_factln (P.tab, tot_a - 1);
-                  lk += cf;
-                  lk -= pc_factln (P.tab, tot_tot - 1);
-                  sh.like[lane][g] = lk;
-                  if (lk > mx)
-                    {
-                      best = g;
-                      mx = lk;
-                    }
+                  initial_p[c] = 1e100;
+                  initial_call[c] = best;
+                  for (int g = 0; g < G; g++)
+                    if (g != best)
+                      {
+                        const double dlt = mx - sh.like[smp][g];
+                        initial_p[c] = (dlt < initial_p[c]) ? dlt : initial_p[c];
+                      }
                 }
-              initial_p = 1e100;
-              initial_call = best;
-              for (int g = 0; g < G; g++)
-                if (g != best)
-                  {
-                    const double dlt = mx - sh.like[lane][g];
-                    initial_p = (dlt < initial_p) ? dlt : initial_p;
-                  }
             }
           // ---- shortcut for the column every sample agrees on (the overwhelming majority).  If, in the first pass, every sample
           //      above the depth floor has the reference homozygote as its best genotype with a margin of more than 2.31 nats, the beam
@@ -847,24 +967,38 @@ __global__ __launch_bounds__ (64) void pcs_call_kernel (PcsParams P, const uint1
           //      (pecaller.c:1454-1471).  The 0.01 nat between 2.3 and 2.31 is ~10^10 times the rounding of the sums involved.
           if (pass == 1)
             {
-              const bool ok = !(lane < N && tot > md) || (initial_call == dom && initial_p > 2.31);
+              bool ok = true;
+#pragma unroll
+              for (int c = 0; c < NCH; c++)
+                ok = ok && (!(64 * c + lane < N && tot[c] > md) || (initial_call[c] == dom && initial_p[c] > 2.31));
               if (__all (ok))
                 {
-                  final_call = (lane < N && tot > md) ? dom : PCS_NG;
-                  final_p = 1.0;
+#pragma unroll
+                  for (int c = 0; c < NCH; c++)
+                    {
+                      final_call[c] = (64 * c + lane < N && tot[c] > md) ? dom : PCS_NG;
+                      final_p[c] = 1.0;
+                    }
                   break;
                 }
             }
           // samples by margin, descending, stable (sort_compare_sample_pointer)
           {
-            int rank = 0;
+            int rank[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; c++)
+              rank[c] = 0;
             for (int jn = 0; jn < N; jn++)
               {
-                const double pj = pcs_bcast (initial_p, jn);
-                rank += (pj > initial_p) || (pj == initial_p && jn < lane);
+                const double pj = pcs_bcast (pcs_chunk_of < NCH > (initial_p, jn), jn & 63);
+#pragma unroll
+                for (int c = 0; c < NCH; c++)
+                  rank[c] += (pj > initial_p[c]) || (pj == initial_p[c] && jn < 64 * c + lane);
               }
-            if (lane < N)
-              sh.sord[rank] = (uint8_t) lane;
+#pragma unroll
+            for (int c = 0; c < NCH; c++)
+              if (64 * c + lane < N)
+                sh.sord[rank[c]] = (uint8_t) (64 * c + lane);
           }
           pcs_sync ();
           for (int i = lane; i < total; i += 64)
@@ -881,10 +1015,13 @@ __global__ __launch_bounds__ (64) void pcs_call_kernel (PcsParams P, const uint1
           //      are ordered by margin, descending, so in a typical column all but the last one or two are of this kind).
           int k_first = 0;
           if (total == 1 && pool[ci].ord[0] == 0 && pool[ci].nall[0] == 1 && pool[ci].prior[0] == 0.0 && pool[ci].nden[0] == 0
-              && pool[ci].acount[dom] == (int16_t) (__popcll (deep) * (site_hap ? 1 : 2)))
+              && pool[ci].acount[dom] == (int16_t) (deep.count () * (site_hap ? 1 : 2)))
             {
-              const unsigned long long settled = __ballot (lane < N && tot > md && initial_call == dom && initial_p > 2.31);
-              while (k_first < N && ((settled >> sh.sord[k_first]) & 1ull))
+              PcsMask < NCH > settled;
+#pragma unroll
+              for (int c = 0; c < NCH; c++)
+                settled.w[c] = __ballot (64 * c + lane < N && tot[c] > md && initial_call[c] == dom && initial_p[c] > 2.31);
+              while (k_first < N && settled.test (sh.sord[k_first]))
                 k_first++;
               if (k_first > 0)
                 {
@@ -906,13 +1043,13 @@ __global__ __launch_bounds__ (64) void pcs_call_kernel (PcsParams P, const uint1
           for (int k = k_first; k < N; k++)
             {
               const int ind = sh.sord[k];
-              if ((deep >> ind) & 1ull)
+              if (deep.test (ind))
                 {
                   const int ni = ci ^ 1;
                   if (big)
                     pool[ni] = bigp[ni];
                   bool went_big = big;
-                  const int r4 = pcs_bcast (r[4], ind), r5 = pcs_bcast (r[5], ind);
+                  const int r4 = sh.reads[ind][4], r5 = sh.reads[ind][5];
                   const int cnt = pcs_expand (pool[ci], pool[ni], bigp[ni], went_big, total, ind, dom, ct, sh, (total <= PCS_SMALLCAP) ? sh.dup : big_dup,
                                               r4, r5, chrom, site_hap, P, lane);
                   big = went_big;
@@ -923,12 +1060,14 @@ __global__ __launch_bounds__ (64) void pcs_call_kernel (PcsParams P, const uint1
                 {
                   // a sample under the depth floor is 'N' in every configuration (pecaller.c:1408-1417)
                   for (int i = lane; i < total; i += 64)
-                    pool[ci].calls[(size_t) pool[ci].ord[i] * PCS_MAXN + ind] = PCS_NG;
-                  if (lane == ind)
-                    {
-                      final_call = PCS_NG;
-                      final_p = 1.0;
-                    }
+                    pool[ci].calls[(size_t) pool[ci].ord[i] * ROW + ind] = PCS_NG;
+#pragma unroll
+                  for (int c = 0; c < NCH; c++)
+                    if (64 * c + lane == ind)
+                      {
+                        final_call[c] = PCS_NG;
+                        final_p[c] = 1.0;
+                      }
                   pcs_sync ();
                 }
             }
@@ -953,32 +1092,34 @@ __global__ __launch_bounds__ (64) void pcs_call_kernel (PcsParams P, const uint1
           }
           // ---- marginal posteriors and calls (pecaller.c:1443-1468), lane = sample
           calls_changed = false;
-          if (lane < N && tot > md)
-            {
-              // post_prob[g] = sum of the posteriors of the configurations that call this sample g, in list order; the
-              // first largest one is the call
-              int besti = 0;
-              double bestp = 0;
-              for (int g = 0; g < G; g++)
-                {
-                  double acc = 0;
-                  for (int i = 0; i < total; i++)
-                    {
-                      const int s = cp.ord[i];
-                      if (cp.calls[(size_t) s * PCS_MAXN + lane] == g)
-                        acc += cp.post[s];
-                    }
-                  if (g == 0 || acc > bestp)
-                    {
-                      besti = g;
-                      bestp = acc;
-                    }
-                }
-              final_p = bestp;
-              final_call = besti;
-              if (final_call != initial_call || final_p < P.threshold)
-                calls_changed = true;
-            }
+#pragma unroll
+          for (int c = 0; c < NCH; c++)
+            if (64 * c + lane < N && tot[c] > md)
+              {
+                // post_prob[g] = sum of the posteriors of the configurations that call this sample g, in list order; the
+                // first largest one is the call
+                int besti = 0;
+                double bestp = 0;
+                for (int g = 0; g < G; g++)
+                  {
+                    double acc = 0;
+                    for (int i = 0; i < total; i++)
+                      {
+                        const int s = cp.ord[i];
+                        if (cp.calls[(size_t) s * ROW + 64 * c + lane] == g)
+                          acc += cp.post[s];
+                      }
+                    if (g == 0 || acc > bestp)
+                      {
+                        besti = g;
+                        bestp = acc;
+                      }
+                  }
+                final_p[c] = bestp;
+                final_call[c] = besti;
+                if (final_call[c] != initial_call[c] || final_p[c] < P.threshold)
+                  calls_changed = true;
+              }
           calls_changed = __any (calls_changed);
           if (N < 4 || pass == 5)
             calls_changed = false;
@@ -994,7 +1135,7 @@ __global__ __launch_bounds__ (64) void pcs_call_kernel (PcsParams P, const uint1
                       const int s = cp.ord[i];
                       const double po = cp.post[s];
                       for (int ind = 0; ind < N; ind++)
-                        if (((deep >> ind) & 1ull) && cp.calls[(size_t) s * PCS_MAXN + ind] == g)
+                        if (deep.test (ind) && cp.calls[(size_t) s * ROW + ind] == g)
                           {
                             const double f = (double) sh.reads[ind][a] / (double) sh.tot[ind];
                             m += f * po;
@@ -1129,9 +1270,11 @@ __global__ __launch_bounds__ (64) void pcs_call_kernel (PcsParams P, const uint1
                 }
               pcs_sync ();
             }
-          initial_call = final_call;
+#pragma unroll
+          for (int c = 0; c < NCH; c++)
+            initial_call[c] = final_call[c];
         }
-      pcs_write_site (P, site, lane, dom, chrom, r, tot, average_depth, final_call, final_p, pass, call, post_out, type_out, allele_count, n_pass, denovo_out);
+      pcs_write_site < NCH > (P, site, lane, dom, chrom, r, tot, average_depth, final_call, final_p, pass, call, post_out, type_out, allele_count, n_pass, denovo_out);
       pcs_sync ();
     }
 }
@@ -1417,7 +1560,47 @@ __device__ bool pcs_mini_beam (const PcsParams & P, const double *tab_unused, co
 #define PCS_FAST_TAB 2048
 #define PCS_FAST_WAVE_BYTES (64 + PCS_NG * 8 + 16)        // per wave: the samples' order, one sample's likelihoods (pcs_mini_beam)
 #define PCS_FAST_BLOCK_OF(TABN) ((TABN) == PCS_FAST_TAB ? 256 : 512)
-#define PCS_FAST_LDS_BYTES_OF(TABN) (((TABN) + 1 + 4 * PCS_NG * PCS_NA) * 8 + (PCS_FAST_BLOCK_OF (TABN) / 64) * PCS_FAST_WAVE_BYTES)
+// pass 1's integer Dirichlet parameters ta = max (1, ceil (scale * mean[g][a])) (pecaller.c:2478) depend on the reference base, the
+// genotype, the allele and on scale = min (depth, 100) clamped to 10 .. 100 only: 4 x 91 x 14 x 6 bytes, built by the host with the
+// kernel's arithmetic (pcs_ta_table) and staged in LDS -- a third of the shortcut kernel's instructions were these ceilings
+#define PCS_TA_SCALES 91
+#define PCS_TA_ROWS (4 * PCS_TA_SCALES * PCS_NG)
+#define PCS_TA_BYTES (PCS_TA_ROWS * 4 + PCS_TA_ROWS * 2)        // a0..a3 packed in a word per row, a4 a5 in a half-word
+#define PCS_FAST_LDS_BYTES_OF(TABN) (((TABN) + 1) * 8 + PCS_TA_BYTES + (PCS_FAST_BLOCK_OF (TABN) / 64) * PCS_FAST_WAVE_BYTES)
+
+// the ta table as words: PCS_TA_ROWS words (alleles 0..3) followed by PCS_TA_ROWS half-words (alleles 4, 5); every ta is at most 100
+static void pcs_ta_table (uint32_t * out)
+{
+  uint16_t *hi = (uint16_t *) (out + PCS_TA_ROWS);
+  for (int dom = 0; dom < 4; dom++)
+    for (int g = 0; g < PCS_NG; g++)
+      {
+        // fill_alpha_prior's row and d_alpha_mean of pass 1 (pecaller.c:3043-3139, 1354-1364)
+        int row[PCS_NA];
+        pcs_alpha_prior_row (g, dom, row);
+        int myt = 0;
+        for (int k = 0; k < PCS_NA; k++)
+          myt += row[k];
+        for (int sc = 0; sc < PCS_TA_SCALES; sc++)
+          {
+            const double scale = (double) (sc + 10);
+            uint32_t w4 = 0, w2 = 0;
+            for (int a = 0; a < PCS_NA; a++)
+              {
+                const double mean = (double) row[a] / (double) myt;
+                const double cv = ceil (scale * mean);
+                const uint32_t ta = (uint32_t) ((1 > cv) ? 1 : cv);
+                if (a < 4)
+                  w4 |= ta << (8 * a);
+                else
+                  w2 |= ta << (8 * (a - 4));
+              }
+            const int i = (dom * PCS_TA_SCALES + sc) * PCS_NG + g;
+            out[i] = w4;
+            hi[i] = (uint16_t) w2;
+          }
+      }
+}
 
 // the deepest sample of a range of columns: max of A + C + G + T + Del + Ins over (column, sample)
 __global__ __launch_bounds__ (256) void pcs_depth_kernel (const uint16_t * reads, long n_items, unsigned *depth_max)
@@ -1439,7 +1622,7 @@ template < int TABN > __global__ __launch_bounds__ (PCS_FAST_BLOCK_OF (TABN), TA
 void pcs_fast_kernel (PcsParams P, const uint16_t * reads, const uint8_t * dom_of, const uint8_t * chrom_of,
                       long n_sites, int8_t * call, double *post_out, int8_t * type_out,
                       int32_t * allele_count, int8_t * n_pass, int32_t * denovo_out,
-                      unsigned *slow_list, unsigned *n_slow, const unsigned *depth_max)
+                      unsigned *slow_list, unsigned *n_slow, const unsigned *depth_max, const uint32_t * ta_table)
 {
   constexpr int PCS_FAST_BLOCK = PCS_FAST_BLOCK_OF (TABN);
   // (every n the columns look up: <= 6 x 100 + depth; the form with the table's head serves when that stays inside it)
@@ -1448,24 +1631,18 @@ void pcs_fast_kernel (PcsParams P, const uint16_t * reads, const uint8_t * dom_o
     return;
   extern __shared__ double pcs_fast_lds[];
   double *tab = pcs_fast_lds;
-  double *mean = pcs_fast_lds + TABN + 1;               // [4][PCS_NG][PCS_NA]
+  uint32_t *ta_lo = (uint32_t *) (pcs_fast_lds + TABN + 1);            // [4][PCS_TA_SCALES][PCS_NG]: ta of alleles 0..3, a byte each
+  uint16_t *ta_hi = (uint16_t *) (ta_lo + PCS_TA_ROWS);                 // ... of alleles 4, 5
   for (int i = threadIdx.x; i < TABN; i += PCS_FAST_BLOCK)
     tab[i] = P.tab[i];
+  for (int i = threadIdx.x; i < PCS_TA_ROWS; i += PCS_FAST_BLOCK)
+    ta_lo[i] = ta_table[i];
+  for (int i = threadIdx.x; i < PCS_TA_ROWS / 2; i += PCS_FAST_BLOCK)
+    ((uint32_t *) ta_hi)[i] = ta_table[PCS_TA_ROWS + i];
   const int N = P.indiv, G = P.max_gen, md = P.min_depth;
-  if ((int) threadIdx.x < 4 * G)
-    {
-      // d_alpha_mean of pass 1 (pecaller.c:1354-1364) for each of the four reference bases
-      const int dom = threadIdx.x / G, g = threadIdx.x - dom * G;
-      int row[PCS_NA], myt = 0;
-      pcs_alpha_prior_row (g, dom, row);
-      for (int a = 0; a < PCS_NA; a++)
-        myt += row[a];
-      for (int a = 0; a < PCS_NA; a++)
-        mean[(dom * PCS_NG + g) * PCS_NA + a] = (double) row[a] / (double) myt;
-    }
   __syncthreads ();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint8_t *w_sord = (uint8_t *) (mean + 4 * PCS_NG * PCS_NA) + (size_t) wave * PCS_FAST_WAVE_BYTES;
+  uint8_t *w_sord = (uint8_t *) (ta_hi + PCS_TA_ROWS) + (size_t) wave * PCS_FAST_WAVE_BYTES;
   double *w_like = (double *) (w_sord + 64);
   const long stride = (long) gridDim.x * (PCS_FAST_BLOCK / 64);
   for (long site = (long) blockIdx.x * (PCS_FAST_BLOCK / 64) + wave; site < n_sites; site += stride)
@@ -1504,10 +1681,10 @@ void pcs_fast_kernel (PcsParams P, const uint16_t * reads, const uint8_t * dom_o
 #pragma unroll
                 for (int a = 0; a < PCS_NA; a++)
                   coef -= pc_factln (tb, r[a]);
-                const double sc0 = (double) min (tot, 100);   // norm of pass 1 is 1
-                const double sc1 = (10 > sc0) ? 10 : sc0;
-                const double scale = (1000 < sc1) ? 1000 : sc1;
-                const double *mrow = mean + dom * PCS_NG * PCS_NA;
+                // scale = min (depth, 100) * norm (1 in pass 1), at least 10: an integer 10 .. 100, the row of the ta table
+                const int sci = (tot < 10 ? 10 : (tot > 100 ? 100 : tot)) - 10;
+                const uint32_t *tl = ta_lo + (dom * PCS_TA_SCALES + sci) * PCS_NG;
+                const uint16_t *th = ta_hi + (dom * PCS_TA_SCALES + sci) * PCS_NG;
                 double mx = -1e100;
 #pragma unroll
                 for (int g = 0; g < PCS_NG; g++)
@@ -1515,13 +1692,13 @@ void pcs_fast_kernel (PcsParams P, const uint16_t * reads, const uint8_t * dom_o
                     lk[g] = 0.0;
                     if (g < G)
                       {
+                        const uint32_t w4 = tl[g], w2 = th[g];
                         int tot_a = 0, tot_tot = 0;
                         double cf = coef, l = 0.0;
 #pragma unroll
                         for (int a = 0; a < PCS_NA; a++)
                           {
-                            const double cv = ceil (scale * mrow[g * PCS_NA + a]);
-                            const int ta = (int) ((1 > cv) ? 1 : cv);
+                            const int ta = (int) ((a < 4 ? (w4 >> (8 * a)) : (w2 >> (8 * (a - 4)))) & 0xFFu);
                             tot_a += ta;
                             tot_tot += ta + r[a];
                             cf -= pc_factln (tb, ta - 1);

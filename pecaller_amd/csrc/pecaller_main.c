@@ -17,7 +17,7 @@
  * With a BED guide file (the last argument, pecaller.c:925-1068) every position of the listed intervals is called, covered
  * or not, and columns on chrY / chrMT are called with HAPLOID forced (955-957).
  *
- * Not supported (an error, not a silent difference): more than 64 samples.  `no_threads` - 1 threads (at most 32) walk the pileup streams, format the rows and deflate <outfile>.base.gz.
+ * Not supported (an error, not a silent difference): more than 256 samples (up to 64 is the device caller's fast case).  `no_threads` - 1 threads (at most 32) walk the pileup streams, format the rows and deflate <outfile>.base.gz.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -33,6 +33,7 @@
 #include "../../include/pemap_hip.h"
 #include "host_io.h"
 
+#define MAX_SAMPLES 256         /* PCS_MAXN of the device caller */
 #define NA 6
 #define MAX_DIST 501            /* pecaller.c:222 */
 /* columns per device call, and genome positions per range of the stream merge.  A call has a fixed part (two kernel launches, the
@@ -97,7 +98,7 @@ advance (sample_t * s, int *running)
 {
   /* (gzeof / gzread of 4 then 12 bytes in the reference: the end of the stream is a read of nothing) */
   zreader *z = &s->f;
-  if (z->count > 0 && z->pos + 16 <= z->ring_len[z->head])
+  if (z->pos + 16 <= z->cur_len)
     {
       /* the whole record lies in the block at hand: 64 of these per column are the merge's inner loop */
       const char *q = z->ring[z->head] + z->pos;
@@ -301,6 +302,10 @@ typedef struct
   const char *genome;
   unsigned int gsize;
   int no_contigs, start_chrom;
+  /* guide mode (a stretch of a BED interval, pecaller.c:941-1039): EVERY position of [p0, p1) is a column, covered or not, on contig
+     gwhich; the columns are appended to the tile from col0 on */
+  int guide, gwhich;
+  long col0;
 } merge_ctx;
 
 static size_t MG_CHUNK = 65536;        /* slots per work item of the column pass (<= TILE) */
@@ -309,7 +314,7 @@ static void
 advance_nr (sample_t * s)
 {
   zreader *z = &s->f;
-  if (z->count > 0 && z->pos + 16 <= z->ring_len[z->head])
+  if (z->pos + 16 <= z->cur_len)
     {
       const char *q = z->ring[z->head] + z->pos;
       memcpy (&s->cur, q, sizeof (unsigned int));
@@ -329,11 +334,20 @@ merge_streams (void *arg)
   merge_ctx *c = (merge_ctx *) arg;
   uint8_t *mark = c->marks + (size_t) c->k * TILE;
   memset (mark, 0, TILE);
+  if (c->guide && c->k == 0)
+    memset (mark, 1, (size_t) (c->p1 - c->p0));
   for (int i = c->k; i < c->no_files; i += c->T)
     {
       sample_t *s = &c->sm[i];
       uint16_t *plane = c->planes + (size_t) i * TILE * NA;
       size_t done = 0;          /* slots of the plane written so far */
+      if (c->guide)
+        {
+          /* records in front of the interval are passed over (pecaller.c:975-976); every position of the stretch counts as seen */
+          while (s->cur != 0 && s->cur < c->p0)
+            advance_nr (s);
+          s->base_count += (unsigned int) (c->p1 - c->p0);
+        }
       while (s->cur != 0 && (unsigned long long) s->cur < c->p1)
         {
           if ((unsigned long long) s->cur < (unsigned long long) c->p0 + done)
@@ -350,7 +364,8 @@ merge_streams (void *arg)
           if (cov > s->max_coverage)
             s->max_coverage = cov;
           s->counts[cov < MAX_DIST - 1 ? cov : MAX_DIST - 1]++;
-          s->base_count++;
+          if (!c->guide)
+            s->base_count++;
           mark[slot] = 1;
           done = slot + 1;
           advance_nr (s);
@@ -390,18 +405,18 @@ merge_columns (void *arg)
   tile_t *t = c->t;
   for (size_t ch = (size_t) c->k; ch < TILE / MG_CHUNK; ch += (size_t) c->T)
     {
-      long col = c->chunk_base[ch];
+      long col = c->col0 + c->chunk_base[ch];
       for (size_t slot = ch * MG_CHUNK; slot < (ch + 1) * MG_CHUNK; slot++)
         if (slot_marked (c, slot))
           {
             const unsigned int lowest = c->p0 + (unsigned int) slot;
-            const int which = find_chrom (c->frag_pos, 0, c->no_contigs - 1, c->start_chrom, lowest);
+            const int which = c->guide ? c->gwhich : find_chrom (c->frag_pos, 0, c->no_contigs - 1, c->start_chrom, lowest);
             const char ref = lowest < c->gsize ? c->genome[lowest] : '\0';
             t->ref_char[col] = ref;
             t->ref_base[col] = (uint8_t) gen_to_int (ref);
             t->contig[col] = which;
             t->pos[col] = 1 + lowest - c->frag_pos[which - 1];
-            t->chrom[col] = c->chrom_type[which];
+            t->chrom[col] = c->chrom_type[which] | ((c->guide && (c->chrom_type[which] == 2 || c->chrom_type[which] == 3)) ? 16 : 0);
             uint16_t *dst = t->reads + (size_t) col * c->indiv * NA;
             for (int i = 0; i < c->no_files; i++)
               memcpy (dst + (size_t) i * NA, c->planes + ((size_t) i * TILE + slot) * NA, NA * sizeof (uint16_t));
@@ -509,9 +524,40 @@ tile_alloc (tile_t * t, int indiv)
   t->type = (int8_t *) malloc (TILE);
   t->ac = (int32_t *) malloc ((size_t) TILE * NA * sizeof (int32_t));
   t->n = 0;
-  if (!t->reads || !t->post || !t->call || !t->ac)
+  if (!t->reads || !t->ref_base || !t->chrom || !t->denovo || !t->ref_char || !t->contig || !t->pos || !t->call || !t->post || !t->type || !t->ac)
     die ("\n pecaller_hip: out of memory for %s", "a tile");
 }
+
+static unsigned long long GUIDE_RANGE_MIN = 4096;      /* positions of a guide interval left at which the streams are walked in parallel (PECALLER_GUIDE_RANGE_MIN; tests: 64) */
+/* the next line of the BED guide file (pecaller.c:1041-1066): contig, first and last position, 1-based -> 0 at its end */
+static int
+next_guide_interval (FILE * guide_file, char **contig_names, int no_contigs, const unsigned int *frag_pos, int *gwhich, unsigned int *lowest,
+                     unsigned int *gend)
+{
+  char line[4096];
+  line[0] = '\0';
+  if (!feof (guide_file))
+    fgets (line, 4095, guide_file);
+  if (strlen (line) < 5)
+    return 0;
+  char *tok = strtok (line, "\t \n");
+  *gwhich = -1;
+  for (int i = 0; i < no_contigs; i++)
+    if (strcmp (tok, contig_names[i]) == 0)
+      {
+        *gwhich = i;
+        break;
+      }
+  if (*gwhich < 0)
+    {
+      printf ("\n For line chrom %s \n", tok);
+      exit (1);
+    }
+  *lowest = frag_pos[*gwhich - 1] + (unsigned int) atoi (strtok (NULL, "\t \n")) - 1;
+  *gend = frag_pos[*gwhich - 1] + (unsigned int) atoi (strtok (NULL, "\t \n")) - 1;
+  return 1;
+}
+
 
 int
 main (int argc, char *argv[])
@@ -658,8 +704,8 @@ main (int argc, char *argv[])
   no_files = found;
   const int indiv = no_files;
   printf ("\n Found a total of %d individuals\n\n", indiv);
-  if (indiv < 1 || indiv > 64)
-    die ("\n pecaller_hip: %s samples; the device caller takes 1 to 64", argv[3]);
+  if (indiv < 1 || indiv > MAX_SAMPLES)
+    die ("\n pecaller_hip: %s samples; the device caller takes 1 to 256 (64 and fewer are its fast case)", argv[3]);
 
   pecall_dev *pc;
   if (pecall_dev_create (&pc, getenv ("PEMAP_DEVICE") ? atoi (getenv ("PEMAP_DEVICE")) : 0))
@@ -668,8 +714,9 @@ main (int argc, char *argv[])
     {
       /* the ped file: family, individual, father, mother, sex per line (pecaller.c:561-604); parents that are not among the
          samples are ignored; a parent's kids are numbered in the order of the lines */
-      int dad[64], mom[64], sex[64], nk[64], kid[64][128], off[65], list[128];
-      for (int i = 0; i < 64; i++)
+      static int dad[MAX_SAMPLES], mom[MAX_SAMPLES], sex[MAX_SAMPLES], nk[MAX_SAMPLES], kid[MAX_SAMPLES][2 * MAX_SAMPLES], off[MAX_SAMPLES + 1],
+        list[2 * MAX_SAMPLES];
+      for (int i = 0; i < MAX_SAMPLES; i++)
         {
           dad[i] = mom[i] = -1;
           sex[i] = nk[i] = 0;
@@ -711,7 +758,7 @@ main (int argc, char *argv[])
       for (int i = 0; i < indiv; i++)
         {
           off[i + 1] = off[i] + nk[i];
-          if (off[i + 1] > 128)
+          if (off[i + 1] > 2 * MAX_SAMPLES)
             die ("\n pecaller_hip: too many parent-child links in %s", argv[10]);
           for (int k = 0; k < nk[i]; k++)
             list[off[i] + k] = kid[i][k];
@@ -749,12 +796,36 @@ main (int argc, char *argv[])
     const char *tl = getenv ("PECALLER_TILE_LOG2");
     if (tl && atoi (tl) >= 10 && atoi (tl) <= 22)
       TILE = (size_t) 1 << atoi (tl);
+    else
+      {
+        /* the host arrays hold ~45 bytes per (column, sample) -- the merge's planes, two tiles of reads, calls and posteriors: 2^21
+           columns are 6 GB with 64 samples; with more samples the tile shrinks so that columns x samples stays at that product */
+        while (TILE > ((size_t) 1 << 16) && TILE * (size_t) no_files > ((size_t) 1 << 27))
+          TILE >>= 1;
+      }
     if (MG_CHUNK > TILE)
       MG_CHUNK = TILE;
+    const char *gr = getenv ("PECALLER_GUIDE_RANGE_MIN");
+    if (gr && atol (gr) >= 1)
+      GUIDE_RANGE_MIN = (unsigned long long) atol (gr);
   }
   tile_t t, spare;
   tile_alloc (&t, indiv);
   tile_alloc (&spare, indiv);
+  /* the tiles are handed to pecall_dev_call_sites again and again: page-locked once, their columns and results move by DMA
+     straight from and to them (a refusal only means staged copies) */
+  for (int k = 0; k < 2; k++)
+    {
+      tile_t *tt = k ? &spare : &t;
+      (void) pecall_dev_pin_host (pc, tt->reads, (uint64_t) TILE * indiv * NA * sizeof (uint16_t));
+      (void) pecall_dev_pin_host (pc, tt->ref_base, (uint64_t) TILE);
+      (void) pecall_dev_pin_host (pc, tt->chrom, (uint64_t) TILE);
+      (void) pecall_dev_pin_host (pc, tt->call, (uint64_t) TILE * indiv);
+      (void) pecall_dev_pin_host (pc, tt->post, (uint64_t) TILE * indiv * sizeof (double));
+      (void) pecall_dev_pin_host (pc, tt->type, (uint64_t) TILE);
+      (void) pecall_dev_pin_host (pc, tt->ac, (uint64_t) TILE * NA * sizeof (int32_t));
+      (void) pecall_dev_pin_host (pc, tt->denovo, (uint64_t) TILE * sizeof (int32_t));
+    }
   /* the threads of the merge and of the row formatting: the reference's worker threads minus its dispatcher, at most 32 */
   int MT = no_threads - 1;
   {
@@ -772,7 +843,7 @@ main (int argc, char *argv[])
   long *chunk_base = (long *) calloc (TILE / MG_CHUNK, sizeof (long));
   uint16_t *planes = NULL;
   uint8_t *marks = NULL;
-  if (!guide_file)
+  /* (with a guide file too: its long intervals go through the same merge) */
     {
       planes = (uint16_t *) malloc ((size_t) no_files * TILE * NA * sizeof (uint16_t));
       marks = (uint8_t *) malloc ((size_t) MT * TILE);
@@ -879,6 +950,37 @@ main (int argc, char *argv[])
             running += sm[i].cur != 0;
           tile_done = 1;
         }
+      else if (running > 0 && (unsigned long long) gend + 1 - lowest >= GUIDE_RANGE_MIN && (size_t) t.n < TILE)
+        {
+          /* a long stretch of the guide interval: every stream is walked over it on its own, as without a guide file (the per-column
+             scan of all streams below costs 1.4 us a column) */
+          unsigned long long n = (unsigned long long) gend + 1 - lowest;
+          if (n > TILE - (size_t) t.n)
+            n = TILE - (size_t) t.n;
+          for (int k = 0; k < MT; k++)
+            {
+              mc[k].p0 = lowest;
+              mc[k].p1 = (unsigned long long) lowest + n;
+              mc[k].guide = 1;
+              mc[k].gwhich = gwhich;
+              mc[k].col0 = t.n;
+            }
+          run_threads (merge_streams, mc, MT);
+          run_threads (merge_count, mc, MT);
+          long ncol = 0;
+          for (size_t ch = 0; ch < TILE / MG_CHUNK; ch++)
+            {
+              const long nn = chunk_base[ch];
+              chunk_base[ch] = ncol;
+              ncol += nn;
+            }
+          run_threads (merge_columns, mc, MT);
+          t.n += ncol;
+          tot_bases += (unsigned int) ncol;
+          lowest += (unsigned int) n;
+          if (lowest > gend && !next_guide_interval (guide_file, contig_names, no_contigs, frag_pos, &gwhich, &lowest, &gend))
+            running = 0;
+        }
       else if (running > 0)
         {
           /* one position of the guide interval (pecaller.c:941-1039) */
@@ -918,33 +1020,8 @@ main (int argc, char *argv[])
                 }
             }
           lowest++;
-          if (lowest > gend)
-            {
-              char line[4096];
-              line[0] = '\0';
-              if (!feof (guide_file))
-                fgets (line, 4095, guide_file);
-              if (strlen (line) < 5)
-                running = 0;
-              else
-                {
-                  char *tok = strtok (line, "\t \n");
-                  gwhich = -1;
-                  for (int i = 0; i < no_contigs; i++)
-                    if (strcmp (tok, contig_names[i]) == 0)
-                      {
-                        gwhich = i;
-                        break;
-                      }
-                  if (gwhich < 0)
-                    {
-                      printf ("\n For line chrom %s \n", tok);
-                      exit (1);
-                    }
-                  lowest = frag_pos[gwhich - 1] + (unsigned int) atoi (strtok (NULL, "\t \n")) - 1;
-                  gend = frag_pos[gwhich - 1] + (unsigned int) atoi (strtok (NULL, "\t \n")) - 1;
-                }
-            }
+          if (lowest > gend && !next_guide_interval (guide_file, contig_names, no_contigs, frag_pos, &gwhich, &lowest, &gend))
+            running = 0;
         }
       if (tile_done || (size_t) t.n == TILE || (running <= 0 && t.n > 0))
         {

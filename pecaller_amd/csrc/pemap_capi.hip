@@ -1238,7 +1238,7 @@ static void launch_vote (pemap_dev * d, const RunCtx & c, bool split, int slot, 
     }
   if (part == 1)
     return;
-  hipLaunchKernelGGL (pm_emit_kernel, dim3 ((n_ends + 255) / 256), dim3 (256), 0, st, c.ix, c.b, H, tasks_s, tasks_m, ctr);
+  hipLaunchKernelGGL (pm_emit_kernel, dim3 ((n_ends + 63) / 64), dim3 (64), 0, st, c.ix, c.b, H, tasks_s, tasks_m, ctr);
   if (!split)
     hipEventRecord (ev[3], st);
   hipEventRecord (ev[10], st);
@@ -1313,7 +1313,7 @@ template < int W, int LPA > static void launch_chunk (pemap_dev * d, const RunCt
     hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, LPA, false >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, H,
                         tasks_m, &ctr->n_tasks_m, ctr, dirbuf, dump_slab, c.tstride, c.L, swprio, &ctr->sw_next[1]);
   hipEventRecord (ev[5], d->stream);
-  hipLaunchKernelGGL (pm_select_kernel, dim3 ((c.b.n + 255) / 256), dim3 (256), 0, d->stream, c.b, c.prm, H, d->d_redo, wins, ctr,
+  hipLaunchKernelGGL (pm_select_kernel, dim3 ((c.b.n + 63) / 64), dim3 (64), 0, d->stream, c.b, c.prm, H, d->d_redo, wins, ctr,
                       m1, m2, mt);
   hipEventRecord (ev[6], d->stream);
   hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_sw_kernel < W, LPA, true >), dim3 (d->sw_grid), dim3 (64), 0, d->stream, c.ix, c.b, c.prm, H,
@@ -1323,9 +1323,9 @@ template < int W, int LPA > static void launch_chunk (pemap_dev * d, const RunCt
   // PEMAP_WALK_BLOCKS_PER_CU (default 4, swept 1..16): resident 256-lane blocks of the walk per CU; few enough walkers that
   // their direction lines stay in L2 between steps
   const int wbp = d->kn.walk_blocks_per_cu;
-  int wgrid = (n_ends + 255) / 256;
-  if (wgrid > d->n_cus * wbp)
-    wgrid = d->n_cus * wbp;
+  int wgrid = (n_ends + 63) / 64;
+  if (wgrid > d->n_cus * wbp * 4)
+    wgrid = d->n_cus * wbp * 4;         // (waves: the knob counts blocks of four)
   // the walk (dependent-load latency) goes to the memory stream in the split pipeline: it runs beside the next chunk's vote/SW
   // (measured on MI355X: 107 ms per step against 103 ms with the walk left on the ALU stream, so it is opt-in: PEMAP_WALK_ON_MEM_STREAM=1)
   hipStream_t ws = (split && !d->serial_split && d->walk_on_mem) ? d->stream2 : d->stream;
@@ -1337,15 +1337,15 @@ template < int W, int LPA > static void launch_chunk (pemap_dev * d, const RunCt
     }
   unsigned long long *path = set2 ? d->d_path2 : d->d_path;
   uint16_t *nsteps = set2 ? d->d_nsteps2 : d->d_nsteps;
-  hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_walk_kernel < W, LPA >), dim3 (wgrid), dim3 (256), 0, ws, c.b, H, wins, ctr, d->d_cur,
+  hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_walk_kernel < W, LPA >), dim3 (wgrid), dim3 (64), 0, ws, c.b, H, wins, ctr, d->d_cur,
                       dirbuf, c.tstride, pile_of (d), d->d_ins_log, d->ins_cap, path, d->path_words, nsteps);
   {
     // one wave per winning alignment applies the recorded steps to the pileup
     const int pbp = d->kn.pile_blocks_per_cu;
-    int pgrid = (n_ends + 3) / 4;
-    if (pgrid > d->n_cus * pbp)
-      pgrid = d->n_cus * pbp;
-    hipLaunchKernelGGL (pm_pile_kernel, dim3 (pgrid), dim3 (256), 0, ws, c.b, H, wins, ctr, pile_of (d), path, d->path_words, nsteps);
+    int pgrid = n_ends;
+    if (pgrid > d->n_cus * pbp * 4)
+      pgrid = d->n_cus * pbp * 4;       // (waves: the knob counts blocks of four)
+    hipLaunchKernelGGL (pm_pile_kernel, dim3 (pgrid), dim3 (64), 0, ws, c.b, H, wins, ctr, pile_of (d), path, d->path_words, nsteps);
   }
   hipEventRecord (ev[8], ws);
   if (split)

@@ -343,9 +343,11 @@ __device__ __forceinline__ void pm_emit_hit (const PmIndex & ix, const PmHits & 
 // One thread per read-end.  An end with one hit is scored once, with direction nibbles, into its own slab; ends with
 // several hits are scored without, and only the winner is scored again (pm_select_kernel).  Slab numbers and task-list
 // ranges are handed out with one atomic per wave.
-__global__ __launch_bounds__ (256) void pm_emit_kernel (PmIndex ix, PmBatch b, PmHits h, uint32_t * tasks_s, uint32_t * tasks_m, PmCounters * ctr)
+// (one-wave workgroups, like every kernel that runs beside the seed kernel: a wave starts wherever a SIMD has room, a workgroup of
+// four waited until a CU had room for all four)
+__global__ __launch_bounds__ (64) void pm_emit_kernel (PmIndex ix, PmBatch b, PmHits h, uint32_t * tasks_s, uint32_t * tasks_m, PmCounters * ctr)
 {
-  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int e = blockIdx.x * 64 + threadIdx.x;
   const int lane = threadIdx.x & 63;
   const int tot = e < b.n_ends ? h.n_hits[e] : 0;
   const unsigned long long below = (1ull << lane) - 1ull;

@@ -897,7 +897,7 @@ __device__ int pm_single_select (const double *sc, int n, int len, double min_al
   return 7;                     // NON_NO
 }
 
-__global__ void pm_select_kernel (PmBatch b, PmParams prm, PmHits h, uint32_t * redo, uint32_t * wins, PmCounters * ctr, uint32_t * m1,
+__global__ __launch_bounds__ (64) void pm_select_kernel (PmBatch b, PmParams prm, PmHits h, uint32_t * redo, uint32_t * wins, PmCounters * ctr, uint32_t * m1,
                                   uint32_t * m2, int *mtype)
 {
   int it = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1086,7 +1086,7 @@ __device__ __forceinline__ void pm_log_insertion (uint8_t * ins_log, unsigned in
 // they did not fit, every step refetched its lines and the kernel ran at the HBM limit for random 64-byte lines.
 #define PM_PATH_WORDS(L) ((((2 * (L) + 21 + 31) / 32) + 1) & ~1)
 
-template < int W, int PM_LPA > __global__ __launch_bounds__ (256) void pm_walk_kernel (PmBatch b, PmHits h, const uint32_t * wins, PmCounters * ctr,
+template < int W, int PM_LPA > __global__ __launch_bounds__ (64) void pm_walk_kernel (PmBatch b, PmHits h, const uint32_t * wins, PmCounters * ctr,
                                                                            PmInsCursor * cur, const uint32_t * dirbuf, int tstride,
                                                                            PmPile counts, uint8_t * ins_log, unsigned ins_cap,
                                                                            unsigned long long *path, int path_words, uint16_t * n_steps)
@@ -1194,7 +1194,7 @@ template < int W, int PM_LPA > __global__ __launch_bounds__ (256) void pm_walk_k
 // An alignment decided by pm_gapless_kernel has no recorded steps: it is mm diagonal steps from (row sti, column mm).
 // Lane = step, so neighbouring lanes usually hold neighbouring positions of the same plane (PmPile: the plane of the reference
 // base), i.e. the two halves of one word: the even position's lane then adds to both halves at once and its neighbour stays out.
-__global__ __launch_bounds__ (256) void pm_pile_kernel (PmBatch b, PmHits h, const uint32_t * wins, PmCounters * ctr, PmPile counts,
+__global__ __launch_bounds__ (64) void pm_pile_kernel (PmBatch b, PmHits h, const uint32_t * wins, PmCounters * ctr, PmPile counts,
                                                        const unsigned long long *path, int path_words, const uint16_t * n_steps)
 {
   const int lane = threadIdx.x & 63;

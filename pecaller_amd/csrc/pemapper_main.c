@@ -11,7 +11,8 @@
  * formats (pemapper.c:775-781, 819-900).
  *
  * Differences from the reference, all outside the hot path: `threads` bounds the host threads that deflate the pileup (the
- * batch itself goes to the GPU); batches are handed over with pemap_dev_submit_batch, so the next one is parsed while the
+ * batch itself goes to the GPU) and, over three, the files of an array that are read side by side (a worker per file pair, at most 8:
+ * PEMAPPER_FILE_WORKERS); batches are handed over with pemap_dev_submit_batch, so the next one is parsed while the
  * GPU maps; <out>.pileup.gz is a sequence of gzip members (it inflates to the reference's bytes); the index arrays are rebuilt on the GPU from <sdx>.seq instead of inflating the 16 GiB <sdx>.idx (the device
  * builder is verified to produce the reference builder's arrays; set PEMAP_INDEX_FROM_FILES=1 to load .idx/.mdx);
  * reads longer than PEMAP_MAX_READ or shorter than PEMAP_MIN_READ are an error instead of undefined behaviour.
@@ -89,6 +90,14 @@ lr_inflate (void *arg)
       if (stop)
         return NULL;
       int got = gzread (r->f, r->ring[tail], LR_BLOCK);
+      if (got <= 0)
+        {
+          /* the reference's my_gzgets ends the file at the first failed read; so does this reader, but not silently */
+          int en = Z_OK;
+          gzerror (r->f, &en);
+          if (got < 0 || (en != Z_OK && en != Z_STREAM_END))
+            fprintf (stderr, "\n Warning: a read file is truncated or not a valid gzip stream; the reads before the damage are mapped \n");
+        }
       pthread_mutex_lock (&r->mu);
       if (got <= 0)
         r->done = 1;
@@ -496,6 +505,221 @@ read_name_list (const char *path, char **names, char **outs)
   return n;
 }
 
+/* ---- the files of an output set are read and mapped by a few workers side by side (the reference's usage is array mode over many
+        file pairs, pemapper.c:307-348, map_directory_array.pl:92-100): a gz member inflates on one core at ~2 M reads per second,
+        the device maps thirty times that.  A worker owns two sets of batch buffers -- one is filled from its file's streams while
+        the GPU maps the other (the reference's reader thread fills a free PTHREAD_DATA_NODE while its workers map the others,
+        pemapper.c:663-703), pinned once like pd_node_alloc -- and hands its batches to the ONE device object (submit / wait are
+        made for several threads); every file's coordinates go to its own .mfile, pileup counters and summary are sums. */
+typedef struct
+{
+  pemap_dev *dev;
+  int paired, trim_s, trim_e, batch_pairs;
+  long max_reads;
+  char **names1, **names2;
+  int next, last;               /* files [next, last) of the output set are still to be taken */
+  long tot_pairs;
+  pthread_mutex_t mu;
+} file_pool;
+
+typedef struct
+{
+  file_pool *P;
+  char *r1s[2], *r2s[2];
+  int *l1s[2], *l2s[2], *mts[2];
+} file_worker;
+
+static void
+worker_alloc (file_worker * w, file_pool * P)
+{
+  w->P = P;
+  for (int k = 0; k < 2; k++)
+    {
+      w->r1s[k] = (char *) malloc ((size_t) P->batch_pairs * ROW_STRIDE);
+      w->r2s[k] = P->paired ? (char *) malloc ((size_t) P->batch_pairs * ROW_STRIDE) : NULL;
+      w->l1s[k] = (int *) malloc (sizeof (int) * (size_t) P->batch_pairs);
+      w->l2s[k] = (int *) malloc (sizeof (int) * (size_t) P->batch_pairs);
+      w->mts[k] = (int *) malloc (sizeof (int) * (size_t) P->batch_pairs);
+      if (!w->r1s[k] || (P->paired && !w->r2s[k]) || !w->l1s[k] || !w->l2s[k] || !w->mts[k])
+        die ("\n pemapper_hip: out of memory for %s", "the batch buffers");
+      (void) pemap_dev_pin_host (P->dev, w->r1s[k], (uint64_t) P->batch_pairs * ROW_STRIDE);   /* (a refusal only means staged copies) */
+      if (P->paired)
+        (void) pemap_dev_pin_host (P->dev, w->r2s[k], (uint64_t) P->batch_pairs * ROW_STRIDE);
+    }
+}
+
+static void
+map_one_file (file_worker * w, int iter)
+{
+  file_pool *P = w->P;
+  pemap_dev *dev = P->dev;
+  const int paired = P->paired;
+  char path[4200];
+  int cur_set = 0, have_pending = 0;
+  uint64_t pending = 0;
+  char *r1 = w->r1s[0], *r2 = w->r2s[0];
+  int *l1 = w->l1s[0], *l2 = w->l2s[0], *mt = w->mts[0];
+  char **r1s = w->r1s, **r2s = w->r2s;
+  int **l1s = w->l1s, **l2s = w->l2s, **mts = w->mts;
+    lreader in1, in2;
+    lr_open (&in1, P->names1[iter]);
+    if (paired)
+      lr_open (&in2, P->names2[iter]);
+    size_t cap = 1 << 20, current_read = 0;
+    uint32_t *maps1 = (uint32_t *) calloc (cap, sizeof (uint32_t)), *maps2 = paired ? (uint32_t *) calloc (cap, sizeof (uint32_t)) : NULL;
+    struct timespec ts0, ts1;
+    clock_gettime (CLOCK_MONOTONIC, &ts0);
+    fill_job j1, j2;
+    memset (&j1, 0, sizeof j1);
+    memset (&j2, 0, sizeof j2);
+    j1.in = &in1;
+    j1.trim_s = P->trim_s;
+    j1.trim_e = P->trim_e;
+    j1.first_mate = 1;
+    j2 = j1;
+    j2.in = &in2;
+    j2.first_mate = 0;
+    int not_done = 1;
+    int nb = 0;
+    printf ("\n Ready to map \n");
+    while (not_done)
+      {
+        long want = P->batch_pairs;
+        if ((long) current_read + want > P->max_reads)
+          want = P->max_reads - (long) current_read;
+        j1.rows = r1;
+        j1.lens = l1;
+        j1.want = (int) want;
+        j2.rows = r2;
+        j2.lens = l2;
+        j2.want = (int) want;
+        pthread_t t2;
+        int threaded = 0;
+        if (paired)
+          threaded = pthread_create (&t2, NULL, fill_rows, &j2) == 0;
+        fill_rows (&j1);
+        if (paired)
+          {
+            if (threaded)
+              pthread_join (t2, NULL);
+            else
+              fill_rows (&j2);
+          }
+        /* the reference's loop checks the first mate's length for the end-of-input rule before either length for the range, and
+           stops at the first record either file cannot supply */
+        nb = j1.got;
+        if (paired && j2.got < nb)
+          nb = j2.got;
+        if (j1.end == 3 && j1.got == nb)
+          {
+            printf ("\n Read %ld of %s has length %d: supported range is %d..%d \n", (long) current_read + nb, P->names1[iter], j1.bad_len, PEMAP_MIN_READ,
+                    PEMAP_MAX_READ);
+            exit (1);
+          }
+        if (paired && j2.end == 3 && j2.got == nb && !(j1.end == 2 && j1.got == nb))
+          {
+            printf ("\n Read %ld of %s has length %d: supported range is %d..%d \n", (long) current_read + nb, P->names2[iter], j2.bad_len, PEMAP_MIN_READ,
+                    PEMAP_MAX_READ);
+            exit (1);
+          }
+        current_read += (size_t) nb;
+        if (nb < want || (long) current_read >= P->max_reads)
+          not_done = 0;
+        if (nb > 0)
+          {
+            if (current_read > cap)
+              {
+                /* the batch in flight writes into the arrays about to move */
+                if (have_pending)
+                  ck (dev, pemap_dev_wait_batch (dev, pending));
+                have_pending = 0;
+                size_t ncap = cap;
+                while (ncap < current_read)
+                  ncap *= 2;
+                maps1 = (uint32_t *) realloc (maps1, ncap * sizeof (uint32_t));
+                if (paired)
+                  maps2 = (uint32_t *) realloc (maps2, ncap * sizeof (uint32_t));
+                cap = ncap;
+              }
+            uint64_t ticket = 0;
+            ck (dev, pemap_dev_submit_batch (dev, r1, l1, r2, l2, nb, ROW_STRIDE, maps1 + (current_read - (size_t) nb),
+                                             paired ? maps2 + (current_read - (size_t) nb) : NULL, mt, &ticket));
+            /* the other set's batch must be back before that set is filled again */
+            if (have_pending)
+              ck (dev, pemap_dev_wait_batch (dev, pending));
+            pending = ticket;
+            have_pending = 1;
+            cur_set ^= 1;
+            r1 = r1s[cur_set];
+            r2 = r2s[cur_set];
+            l1 = l1s[cur_set];
+            l2 = l2s[cur_set];
+            mt = mts[cur_set];
+            printf ("\n We have read %ld reads \n\n", (long) current_read);
+            nb = 0;
+          }
+      }
+    if (have_pending)
+      ck (dev, pemap_dev_wait_batch (dev, pending));
+    have_pending = 0;
+    if (nb > 0)               /* loop left through the length test */
+      {
+        if (current_read > cap)
+          {
+            maps1 = (uint32_t *) realloc (maps1, current_read * sizeof (uint32_t));
+            if (paired)
+              maps2 = (uint32_t *) realloc (maps2, current_read * sizeof (uint32_t));
+          }
+        ck (dev, pemap_dev_map_batch (dev, r1, l1, r2, l2, nb, ROW_STRIDE, maps1 + (current_read - (size_t) nb),
+                                      paired ? maps2 + (current_read - (size_t) nb) : NULL, mt));
+      }
+    clock_gettime (CLOCK_MONOTONIC, &ts1);
+    {
+      const double sec = (double) (ts1.tv_sec - ts0.tv_sec) + 1e-9 * (double) (ts1.tv_nsec - ts0.tv_nsec);
+      printf ("\n pemapper_hip: %ld %s read and mapped in %.3f s (%.2f M reads/s, input parsing included) \n", (long) current_read,
+              paired ? "pairs" : "reads", sec, (paired ? 2.0 : 1.0) * (double) current_read / (sec > 0 ? sec : 1) / 1e6);
+    }
+    printf ("\n Made it out alive, and have started cleanup \n\n");
+    snprintf (path, sizeof path, "%s.mfile", P->names1[iter]);
+    FILE *m = fopen (path, "wb");
+    if (!m)
+      die ("\n Can not open file %s", path);
+    fwrite (maps1, sizeof (uint32_t), current_read, m);
+    fclose (m);
+    if (paired)
+      {
+        snprintf (path, sizeof path, "%s.mfile", P->names2[iter]);
+        m = fopen (path, "wb");
+        if (!m)
+          die ("\n Can not open file %s", path);
+        fwrite (maps2, sizeof (uint32_t), current_read, m);
+        fclose (m);
+        lr_close (&in2);
+      }
+    lr_close (&in1);
+    free (maps1);
+    free (maps2);
+  pthread_mutex_lock (&P->mu);
+  P->tot_pairs += (long) current_read;
+  pthread_mutex_unlock (&P->mu);
+}
+
+static void *
+file_worker_main (void *arg)
+{
+  file_worker *w = (file_worker *) arg;
+  file_pool *P = w->P;
+  for (;;)
+    {
+      pthread_mutex_lock (&P->mu);
+      const int iter = P->next < P->last ? P->next++ : -1;
+      pthread_mutex_unlock (&P->mu);
+      if (iter < 0)
+        return NULL;
+      map_one_file (w, iter);
+    }
+}
+
 int
 main (int argc, char *argv[])
 {
@@ -704,29 +928,36 @@ main (int argc, char *argv[])
 
   char basename[1024];
   strncpy (basename, argv[1], 1000);
-  basename[1000] = 0;
-  /* two sets of batch buffers: one is filled from the fastq streams while the GPU maps the other (the reference's reader thread
-     fills a free PTHREAD_DATA_NODE while its workers map the others, pemapper.c:663-703).  Pinned once, like pd_node_alloc. */
-  char *r1s[2], *r2s[2];
-  int *l1s[2], *l2s[2], *mts[2];
-  for (int k = 0; k < 2; k++)
-    {
-      r1s[k] = (char *) malloc ((size_t) BATCH_PAIRS * ROW_STRIDE);
-      r2s[k] = paired ? (char *) malloc ((size_t) BATCH_PAIRS * ROW_STRIDE) : NULL;
-      l1s[k] = (int *) malloc (sizeof (int) * BATCH_PAIRS);
-      l2s[k] = (int *) malloc (sizeof (int) * BATCH_PAIRS);
-      mts[k] = (int *) malloc (sizeof (int) * BATCH_PAIRS);
-      (void) pemap_dev_pin_host (dev, r1s[k], (uint64_t) BATCH_PAIRS * ROW_STRIDE);     /* (a refusal only means staged copies) */
-      if (paired)
-        (void) pemap_dev_pin_host (dev, r2s[k], (uint64_t) BATCH_PAIRS * ROW_STRIDE);
-    }
-  int cur_set = 0, have_pending = 0;
-  uint64_t pending = 0;
-  char *r1 = r1s[0], *r2 = r2s[0];
-  int *l1 = l1s[0], *l2 = l2s[0], *mt = mts[0];
+  /* workers: a file pair keeps ~4 host threads busy (two inflate threads, two line scans); at most 8 files at a time */
+  int n_workers = c.io_threads / 3;
+  if (n_workers > 8)
+    n_workers = 8;
+  if (n_workers > file_num)
+    n_workers = file_num;
+  if (n_workers < 1)
+    n_workers = 1;
+  {
+    const char *e = getenv ("PEMAPPER_FILE_WORKERS");
+    if (e && atoi (e) >= 1 && atoi (e) <= 64)
+      n_workers = atoi (e) < file_num ? atoi (e) : file_num;
+  }
+  file_pool pool;
+  memset (&pool, 0, sizeof pool);
+  pool.dev = dev;
+  pool.paired = paired;
+  pool.trim_s = trim_s;
+  pool.trim_e = trim_e;
+  pool.max_reads = max_reads;
+  pool.names1 = names1;
+  pool.names2 = names2;
+  /* one file at a time: batches of 2^20 pairs; several: 2^18, the device pipeline's own chunk (three batches are in flight at most) */
+  pool.batch_pairs = n_workers > 1 ? BATCH_PAIRS / 4 : BATCH_PAIRS;
+  pthread_mutex_init (&pool.mu, NULL);
+  file_worker *workers = (file_worker *) calloc ((size_t) n_workers, sizeof (file_worker));
+  for (int k = 0; k < n_workers; k++)
+    worker_alloc (&workers[k], &pool);
   printf ("\n About to start mapping everything \n\n");
-  long tot_pairs = 0;
-  for (int iter = 0; iter < file_num; iter++)
+  for (int iter = 0; iter < file_num;)
     {
       printf ("\n About to open new set of files \n");
       /* pemapper_tsw.c:636-648: a new output name closes the previous output set */
@@ -734,152 +965,32 @@ main (int argc, char *argv[])
         {
           if (iter > 0)
             {
-              dump_output (&c, basename, tot_pairs);
-              tot_pairs = 0;
+              dump_output (&c, basename, pool.tot_pairs);
+              pool.tot_pairs = 0;
             }
           strncpy (basename, outs[iter], 1000);
         }
-      lreader in1, in2;
-      lr_open (&in1, names1[iter]);
-      if (paired)
-        lr_open (&in2, names2[iter]);
-      size_t cap = 1 << 20, current_read = 0;
-      uint32_t *maps1 = (uint32_t *) calloc (cap, sizeof (uint32_t)), *maps2 = paired ? (uint32_t *) calloc (cap, sizeof (uint32_t)) : NULL;
-      struct timespec ts0, ts1;
-      clock_gettime (CLOCK_MONOTONIC, &ts0);
-      fill_job j1, j2;
-      memset (&j1, 0, sizeof j1);
-      memset (&j2, 0, sizeof j2);
-      j1.in = &in1;
-      j1.trim_s = trim_s;
-      j1.trim_e = trim_e;
-      j1.first_mate = 1;
-      j2 = j1;
-      j2.in = &in2;
-      j2.first_mate = 0;
-      int not_done = 1;
-      int nb = 0;
-      printf ("\n Ready to map \n");
-      while (not_done)
+      /* the files that follow with the same output name (all of them, for the plain pemapper): one output set */
+      int last = iter + 1;
+      while (last < file_num && !(outs[last] && strcmp (basename, outs[last]) != 0))
+        last++;
+      pool.next = iter;
+      pool.last = last;
+      const int T = last - iter < n_workers ? last - iter : n_workers;
+      pthread_t th[64];
+      int started = 0;
+      for (int k = 1; k < T; k++)
         {
-          long want = BATCH_PAIRS;
-          if ((long) current_read + want > max_reads)
-            want = max_reads - (long) current_read;
-          j1.rows = r1;
-          j1.lens = l1;
-          j1.want = (int) want;
-          j2.rows = r2;
-          j2.lens = l2;
-          j2.want = (int) want;
-          pthread_t t2;
-          int threaded = 0;
-          if (paired)
-            threaded = pthread_create (&t2, NULL, fill_rows, &j2) == 0;
-          fill_rows (&j1);
-          if (paired)
-            {
-              if (threaded)
-                pthread_join (t2, NULL);
-              else
-                fill_rows (&j2);
-            }
-          /* the reference's loop checks the first mate's length for the end-of-input rule before either length for the range, and
-             stops at the first record either file cannot supply */
-          nb = j1.got;
-          if (paired && j2.got < nb)
-            nb = j2.got;
-          if (j1.end == 3 && j1.got == nb)
-            {
-              printf ("\n Read %ld of %s has length %d: supported range is %d..%d \n", (long) current_read + nb, names1[iter], j1.bad_len, PEMAP_MIN_READ,
-                      PEMAP_MAX_READ);
-              exit (1);
-            }
-          if (paired && j2.end == 3 && j2.got == nb && !(j1.end == 2 && j1.got == nb))
-            {
-              printf ("\n Read %ld of %s has length %d: supported range is %d..%d \n", (long) current_read + nb, names2[iter], j2.bad_len, PEMAP_MIN_READ,
-                      PEMAP_MAX_READ);
-              exit (1);
-            }
-          current_read += (size_t) nb;
-          if (nb < want || (long) current_read >= max_reads)
-            not_done = 0;
-          if (nb > 0)
-            {
-              if (current_read > cap)
-                {
-                  /* the batch in flight writes into the arrays about to move */
-                  if (have_pending)
-                    ck (dev, pemap_dev_wait_batch (dev, pending));
-                  have_pending = 0;
-                  size_t ncap = cap;
-                  while (ncap < current_read)
-                    ncap *= 2;
-                  maps1 = (uint32_t *) realloc (maps1, ncap * sizeof (uint32_t));
-                  if (paired)
-                    maps2 = (uint32_t *) realloc (maps2, ncap * sizeof (uint32_t));
-                  cap = ncap;
-                }
-              uint64_t ticket = 0;
-              ck (dev, pemap_dev_submit_batch (dev, r1, l1, r2, l2, nb, ROW_STRIDE, maps1 + (current_read - (size_t) nb),
-                                               paired ? maps2 + (current_read - (size_t) nb) : NULL, mt, &ticket));
-              /* the other set's batch must be back before that set is filled again */
-              if (have_pending)
-                ck (dev, pemap_dev_wait_batch (dev, pending));
-              pending = ticket;
-              have_pending = 1;
-              cur_set ^= 1;
-              r1 = r1s[cur_set];
-              r2 = r2s[cur_set];
-              l1 = l1s[cur_set];
-              l2 = l2s[cur_set];
-              mt = mts[cur_set];
-              printf ("\n We have read %ld reads \n\n", (long) current_read);
-              nb = 0;
-            }
+          if (pthread_create (&th[k], NULL, file_worker_main, &workers[k]) != 0)
+            break;              /* (the workers that did start take the files between them) */
+          started = k;
         }
-      if (have_pending)
-        ck (dev, pemap_dev_wait_batch (dev, pending));
-      have_pending = 0;
-      if (nb > 0)               /* loop left through the length test */
-        {
-          if (current_read > cap)
-            {
-              maps1 = (uint32_t *) realloc (maps1, current_read * sizeof (uint32_t));
-              if (paired)
-                maps2 = (uint32_t *) realloc (maps2, current_read * sizeof (uint32_t));
-            }
-          ck (dev, pemap_dev_map_batch (dev, r1, l1, r2, l2, nb, ROW_STRIDE, maps1 + (current_read - (size_t) nb),
-                                        paired ? maps2 + (current_read - (size_t) nb) : NULL, mt));
-        }
-      clock_gettime (CLOCK_MONOTONIC, &ts1);
-      {
-        const double sec = (double) (ts1.tv_sec - ts0.tv_sec) + 1e-9 * (double) (ts1.tv_nsec - ts0.tv_nsec);
-        printf ("\n pemapper_hip: %ld %s read and mapped in %.3f s (%.2f M reads/s, input parsing included) \n", (long) current_read,
-                paired ? "pairs" : "reads", sec, (paired ? 2.0 : 1.0) * (double) current_read / (sec > 0 ? sec : 1) / 1e6);
-      }
-      printf ("\n Made it out alive, and have started cleanup \n\n");
-      snprintf (path, sizeof path, "%s.mfile", names1[iter]);
-      FILE *m = fopen (path, "wb");
-      if (!m)
-        die ("\n Can not open file %s", path);
-      fwrite (maps1, sizeof (uint32_t), current_read, m);
-      fclose (m);
-      if (paired)
-        {
-          snprintf (path, sizeof path, "%s.mfile", names2[iter]);
-          m = fopen (path, "wb");
-          if (!m)
-            die ("\n Can not open file %s", path);
-          fwrite (maps2, sizeof (uint32_t), current_read, m);
-          fclose (m);
-          lr_close (&in2);
-        }
-      lr_close (&in1);
-      free (maps1);
-      free (maps2);
-      tot_pairs += (long) current_read;
+      file_worker_main (&workers[0]);
+      for (int k = 1; k <= started; k++)
+        pthread_join (th[k], NULL);
+      iter = last;
     }
-  dump_output (&c, basename, tot_pairs);
+  dump_output (&c, basename, pool.tot_pairs);
   pemap_dev_destroy (dev);
   return 0;
 }

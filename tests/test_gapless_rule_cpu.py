@@ -182,3 +182,46 @@ def test_rule_on_clipped_windows_and_odd_letters():
 def test_rule_in_bisulfite_mode():
     decided, deferred, narrow, odd = _check(edge_windows(78, 20000, True), True)
     assert decided > 8000 and deferred > 2000 and narrow > 7000 and odd > 4000, (decided, deferred, narrow, odd)
+
+
+def _add_ones(y, n):
+    """The fold by binades of pm_add_ones (pemap_sw.hip.h), restated with Python's doubles."""
+    import math
+    while n > 0 and y < 1.0:
+        y = y + 1.0
+        n -= 1
+    while n > 0:
+        e = math.frexp(y)[1] - 1                # 2^e <= y < 2^(e+1)
+        top = (2 << e) - 1
+        k = min(n, top - int(y))
+        if k > 0:
+            y = y + float(k)
+            n -= k
+        if n > 0:
+            y = y + 1.0
+            n -= 1
+    return y
+
+
+def test_fold_by_binades_is_the_step_by_step_fold():
+    """pemapper.c:2062-2081 adds the bonus one read base at a time; the kernel takes the steps of a binade at once."""
+    miss = -1.0 / 3.0
+    for m1 in range(0, 300):
+        start = float(m1) + miss
+        y = start
+        for n in range(0, 520 - m1):
+            assert _add_ones(start, n) == y, (m1, n)
+            y = y + 1.0
+    # two mismatches: fold, one more -1/3, fold again
+    rng = np.random.default_rng(5)
+    for _ in range(3000):
+        mm = int(rng.integers(20, 512))
+        m1, m2 = sorted(rng.choice(mm, 2, replace=False).tolist())
+        y = 0.0
+        for c in range(mm):
+            y = y + (miss if c in (m1, m2) else 1.0)
+        z = float(m1) + miss
+        z = _add_ones(z, m2 - m1 - 1)
+        z = z + miss
+        z = _add_ones(z, mm - m2 - 1)
+        assert z == y, (mm, m1, m2)

@@ -75,6 +75,41 @@ def test_cli_array_mode_and_max_reads(tmp_path):
     assert r.returncode == 1 and b"Max_threads" in r.stdout
 
 
+@pytest.mark.parametrize("workers", ["1", "4"])
+def test_cli_array_mode_several_files_in_flight(tmp_path, workers, monkeypatch):
+    """the reference's usual run: an array of file pairs into one output set (pemapper.c:307-348, map_directory_array.pl:92-100).
+    The golden reads cut into five uneven file pairs (one of them plain text), read and mapped by four workers side by side (and by
+    one, the old way): every pair's .mfile holds its reads' coordinates, and the pileup, the insertions and the summary of the set
+    are the reference's for the whole read set (counters are sums, the order of the files is free)."""
+    monkeypatch.setenv("PEMAPPER_FILE_WORKERS", workers)
+    sdx = _prep(tmp_path)
+    g1, g2 = (gzip.open(os.path.join(fixtures.GOLD, "g1_%d_.fastq.gz" % k)).read().split(b"\n") for k in (1, 2))
+    cuts = [0, 3000, 3001, 9000, 14500, 20000]
+    n1, n2 = [], []
+    for k, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+        fa, fb = str(tmp_path / ("part%d_1_.fastq" % k)), str(tmp_path / ("part%d_2_.fastq" % k))
+        if k != 2:
+            fa, fb = fa + ".gz", fb + ".gz"
+        for fn, lines in ((fa, g1), (fb, g2)):
+            data = b"\n".join(lines[4 * a:4 * b]) + b"\n"
+            (gzip.open(fn, "wb", compresslevel=1) if fn.endswith(".gz") else open(fn, "wb")).write(data)
+        n1.append(fa)
+        n2.append(fb)
+    (tmp_path / "a1.txt").write_text("\n".join(n1) + "\n")
+    (tmp_path / "a2.txt").write_text("\n".join(n2) + "\n")
+    out = str(tmp_path / "outm")
+    subprocess.check_call([EXE, out, sdx, "pa", str(tmp_path / "a1.txt"), str(tmp_path / "a2.txt"), "500", "0", "N", "0.85", "16", "200000000"],
+                          stdout=subprocess.DEVNULL)
+    m = fixtures.meta()["r150"]
+    for k, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+        assert np.array_equal(np.fromfile(n1[k] + ".mfile", dtype="<u4"), fixtures.golden_m("r150", 1)[a:b]), k
+        assert np.array_equal(np.fromfile(n2[k] + ".mfile", dtype="<u4"), fixtures.golden_m("r150", 2)[a:b]), k
+    pile = refio.read_pileup(out + ".pileup.gz")
+    assert len(pile) == m["pileup_records"] and refio.md5(pile) == m["pileup_md5"]
+    assert refio.read_indel(out + ".indel.txt.gz") == refio.read_indel(os.path.join(fixtures.GOLD, "r150.indel.txt.gz"))
+    assert open(out + ".summary.txt").read() == open(os.path.join(fixtures.GOLD, "r150.summary.txt")).read()
+
+
 def test_cli_plain_text_input_and_uneven_mate_files(tmp_path):
     """the two mate files are scanned by two threads (fill_rows): plain-text fastq gives the files the gz input gives (gzopen reads
     both, pemapper.c:626); a second mate file that ends early ends the run at its last record, as the reference's loop does

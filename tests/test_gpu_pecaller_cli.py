@@ -87,6 +87,54 @@ def test_pecaller_cli_outputs(tmp_path, tile_log2, threads, monkeypatch):
             assert srows[pos1] == row
 
 
+def test_pecaller_cli_100_samples(tmp_path):
+    """more than 64 pileup files in the directory (the reference takes any number: pecaller.c:251-257, 495-515): pecaller_hip's rows
+    against the oracle in the directory's order and, where the order is the fixture's, the reference's own text"""
+    assert os.path.exists(EXE), "build with make -C pecaller_amd/csrc"
+    z = np.load(os.path.join(fx.GOLD, "pecall_wide.npz"))
+    names = [str(x) for x in z["names"]]
+    reads, pos, pad = z["reads"], z["pos"], int(z["pad"][0])
+    _, seqs = refio.read_fasta(os.path.join(fx.GOLD, "g1.fa.gz"))
+    shutil.copy(os.path.join(fx.GOLD, "g1.sdx"), tmp_path / "g1.sdx")
+    with gzip.open(tmp_path / "g1.seq", "wb", compresslevel=1) as f:
+        f.write(np.concatenate(seqs).tobytes())
+    run = tmp_path / "run"
+    run.mkdir()
+    for s, nm in enumerate(names):
+        recs = [struct.pack("<I6H", int(pos[i]), *[int(x) for x in reads[i, s]]) for i in range(len(pos)) if reads[i, s].sum() > 0]
+        recs += [struct.pack("<I6H", int(pos[-1]) + 1 + k, 20, 0, 0, 0, 0, 0) for k in range(pad)]
+        with gzip.open(run / ("%s.pileup.gz" % nm), "wb", compresslevel=1) as f:
+            f.write(b"".join(recs))
+    subprocess.check_call([EXE, "pileup", str(tmp_path / "g1.sdx"), "105", "out", "0.95", "0.001", "n", "8", "n"], cwd=run, stdout=subprocess.DEVNULL)
+    base = gzip.open(run / "out.base.gz", "rt").read().split("\n")
+    cols = [c for c in base[0].split("\t")[3:] if c]
+    assert sorted(cols) == sorted(names) and len(cols) == 100
+    perm = [names.index(c) for c in cols]
+    f = fx.load("pecall_wide")
+    r = reads[:, perm, :]
+    call, p, typ, ac, _ = oracle_py.call_sites(r, f["dom"])
+    rows = {int(x.split("\t")[1]): x for x in base[1:] if x}
+    snp = open(run / "out.snp").read().split("\n")
+    srows = {int(x.split("\t")[1]): x for x in snp[1:] if x}
+    n_base = n_snp = 0
+    for i, q in enumerate(pos):
+        pos1 = int(q) + 1
+        if f["dom"][i] > 3 or r[i].sum() == 0:
+            assert pos1 not in rows
+            continue
+        n_base += 1
+        assert rows[pos1] == fx.base_row("chr1", pos1, chr(f["ref"][i]), call[i], p[i]), pos1
+        if typ[i] > 0:
+            n_snp += 1
+            assert srows[pos1] == fx.snp_row("chr1", pos1, chr(f["ref"][i]), call[i], p[i], typ[i], ac[i]), pos1
+    assert n_base == len(f["base_rows"]) and n_snp > 30
+    if cols == [str(x) for x in z["columns"]]:
+        for pos1, row in f["base_rows"].items():
+            assert rows[pos1] == row
+        for pos1, row in f["snp_rows"].items():
+            assert srows[pos1] == row
+
+
 def test_pecaller_cli_with_pedigree(tmp_path):
     """use_pedfile = y: the ped file parsed by the host program, DENOVO_ rows"""
     z = np.load(os.path.join(fx.GOLD, "pecall_ped.npz"))
@@ -135,10 +183,16 @@ def test_pecaller_cli_with_pedigree(tmp_path):
             assert srows[pos1] == row
 
 
-def test_pecaller_cli_guide_mode(tmp_path):
+@pytest.mark.parametrize("range_min", [None, "64"])
+def test_pecaller_cli_guide_mode(tmp_path, range_min, monkeypatch):
     """a BED guide file: every position of the intervals is called (uncovered ones too), chrY / chrMT columns haploid; the
-    device caller itself on the same columns first (the + 16 chromosome flag)"""
+    device caller itself on the same columns first (the + 16 chromosome flag).  range_min = 64: stretches of 64 positions and more
+    of an interval go through the parallel walk of the streams (by default from 4,096 on), the rest through the per-column scan --
+    same rows, same <out>.dist"""
     from pecaller_amd.pecall import PecallDev
+    if range_min:
+        monkeypatch.setenv("PECALLER_GUIDE_RANGE_MIN", range_min)
+        monkeypatch.setenv("PECALLER_TILE_LOG2", "10")        # (and tiles of 1,024 columns: stretches cut by a full tile)
     f = fx.load_guide()
     dev = PecallDev(0)
     got = dev.call_sites(f["reads"], f["dom"], chrom=f["chrom"])

@@ -24,3 +24,28 @@ def test_parallel_gz_writer_and_threaded_reader(tmp_path):
             # several members were written (the file holds more than one gzip header)
             raw = open(out, "rb").read()
             assert raw.count(b"\x1f\x8b\x08\x00") >= 4
+
+
+def test_threaded_reader_dies_on_a_broken_stream(tmp_path):
+    """gzread < 0 or a stream cut short is not an end of input: pecaller_hip must not call on the part that inflated."""
+    exe = str(tmp_path / "host_io_check")
+    subprocess.check_call(["gcc", "-O2", "-o", exe, os.path.join(ROOT, "tests", "csrc", "host_io_check.c"), "-lz", "-lpthread"])
+    rng = np.random.default_rng(3)
+    payload = rng.integers(0, 256, 5 << 20, dtype=np.uint8).tobytes()
+    good = str(tmp_path / "good.gz")
+    with gzip.open(good, "wb") as f:
+        f.write(payload)
+    r = subprocess.run([exe, good, "read"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0 and b"read %d" % len(payload) in r.stdout
+    raw = open(good, "rb").read()
+    cut = str(tmp_path / "cut.gz")
+    open(cut, "wb").write(raw[:len(raw) // 2])
+    r = subprocess.run([exe, cut, "read"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1 and b"truncated or not a valid gzip" in r.stderr, (r.returncode, r.stdout, r.stderr)
+    bad = bytearray(raw)
+    for k in range(len(raw) // 3, len(raw) // 3 + 64):
+        bad[k] ^= 0x5A
+    garbled = str(tmp_path / "garbled.gz")
+    open(garbled, "wb").write(bytes(bad))
+    r = subprocess.run([exe, garbled, "read"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1 and b"truncated or not a valid gzip" in r.stderr, (r.returncode, r.stdout, r.stderr)

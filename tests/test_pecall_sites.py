@@ -5,7 +5,7 @@ import oracle_py
 import pecall_sites_fixture as fx
 
 
-@pytest.mark.parametrize("tag", ["pecall_sites", "pecall_ped"])
+@pytest.mark.parametrize("tag", ["pecall_sites", "pecall_ped", "pecall_wide"])
 def test_site_oracle_matches_reference_text(tag):
     f = fx.load(tag)
     call, p, typ, ac, npass = oracle_py.call_sites(f["reads"], f["dom"], ped=f.get("ped"))
@@ -32,14 +32,19 @@ def test_site_oracle_matches_reference_text(tag):
     assert n_base == len(f["base_rows"]) and n_snp == len(f["snp_rows"]), (n_base, len(f["base_rows"]), n_snp, len(f["snp_rows"]))
     assert not bad, bad[:3]
     assert npass.max() >= 2                      # the fixture exercises the alpha re-estimation
+    if tag == "pecall_wide":
+        assert f["reads"].shape[1] == 100       # more than 64 samples: the reference takes any INDIV (pecaller.c:251-257)
     if tag == "pecall_ped":
         assert (den[typ > 0] > 0).sum() >= 10     # DENOVO_ rows
 
 
 @pytest.mark.gpu
-def test_gpu_site_caller_matches_reference_text_and_oracle():
+@pytest.mark.parametrize("tag", ["pecall_sites", "pecall_wide"])
+def test_gpu_site_caller_matches_reference_text_and_oracle(tag):
+    """the 8-sample fixture, and 100 samples (two chunks of 64: a lane stands for a sample of each) against the text the reference
+    printed and against the oracle"""
     from pecaller_amd.pecall import PecallDev
-    f = fx.load()
+    f = fx.load(tag)
     dev = PecallDev(0)
     call, p, typ, ac, npass = dev.call_sites(f["reads"], f["dom"])
     ocall, op, otyp, oac, onpass = oracle_py.call_sites(f["reads"], f["dom"])
@@ -207,4 +212,65 @@ def test_gpu_site_caller_odd_sample_counts(n):
     assert np.max(np.abs(got[1] - exp[1])) <= 1e-6
     for a, b in zip(got[2:], exp[2:]):
         assert np.array_equal(a, b)
+    dev.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,ped", [(65, False), (128, False), (150, False), (200, True), (256, False)])
+def test_gpu_site_caller_more_than_64_samples(n, ped):
+    """sample counts on both sides of the chunk boundaries (2 chunks up to 128, 4 up to 256), with and without a pedigree that
+    spans the chunks, against the oracle; 257 is refused"""
+    from pecaller_amd.pecall import PecallDev
+    from pecaller_amd.pemap import PemapError
+    rng = np.random.default_rng(300 + n)
+    n_sites = 400
+    dom = rng.integers(0, 4, n_sites).astype(np.uint8)
+    dom[::53] = 14
+    depth = rng.integers(12, 40, n)
+    depth[3] = 2
+    depth[n - 2] = 5
+    is_var = rng.random(n_sites) < 0.3
+    q = rng.uniform(0.02, 0.5, n_sites)
+    alt = rng.integers(0, 6, n_sites)
+    reads = np.zeros((n_sites, n, 6), np.int64)
+    idx = np.arange(n_sites)
+    r = np.where(dom < 4, dom, 0)
+    for i in range(n):
+        d = rng.poisson(depth[i], n_sites)
+        dose = np.where(is_var, rng.binomial(2, q), 0)
+        e = rng.binomial(d, 0.004)
+        ar = rng.binomial(d - e, dose / 2.0)
+        reads[idx, i, r] += d - e - ar
+        reads[idx, i, alt] += ar
+        reads[idx, i, r] += np.where(alt == 5, ar, 0)      # an insertion is counted on top of the base it follows
+        reads[idx, i, rng.integers(0, 4, n_sites)] += e
+    reads = reads.astype(np.uint16)
+    pd = None
+    if ped:
+        # trios whose members sit in different chunks of 64: child i, father i + 64, mother i + 128
+        dad = np.full(n, -1, np.int32)
+        mom = np.full(n, -1, np.int32)
+        sex = (1 + (np.arange(n) % 2)).astype(np.int32)
+        for c in range(0, 40, 3):
+            dad[c], mom[c] = c + 64, c + 128
+            sex[c + 64], sex[c + 128] = 1, 2
+        pd = dict(dad=dad, mom=mom, sex=sex, denovo_rate=1e-5)
+    dev = PecallDev(0)
+    if pd:
+        kids = [[k for k in range(n) if dad[k] == i or mom[k] == i] for i in range(n)]
+        off = np.concatenate([[0], np.cumsum([len(k) for k in kids])]).astype(np.int32)
+        dev.set_pedigree(dad, mom, sex, off, np.array([k for ks in kids for k in ks] + [0], np.int32), 1e-5)
+    got = dev.call_sites(reads, dom)
+    gden = dev.denovo.copy()
+    exp = oracle_py.call_sites(reads, dom, ped=pd)
+    assert np.array_equal(got[0], exp[0])
+    assert np.max(np.abs(got[1] - exp[1])) <= 1e-6
+    for a, b in zip(got[2:], exp[2:]):
+        assert np.array_equal(a, b)
+    if pd:
+        assert np.array_equal(gden, oracle_py.call_sites.denovo)
+    assert (got[2] > 0).sum() > 50 and got[4].max() >= 2
+    if n == 256:
+        with pytest.raises(PemapError):
+            dev.call_sites(np.zeros((4, 257, 6), np.uint16), dom[:4])
     dev.close()

@@ -31,5 +31,13 @@ for ctr, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
                 for k, v in acc.items() if k.startswith(("pm_", "pile_", "ix_", "pcs_", "pc_"))}
 if len(sys.argv) > 2:
     out["steps"] = int(sys.argv[2])     # steps of the main configuration the profiled command ran (for per-step totals)
+# the device sources the profile was taken on (bench.py drops a profile of other kernels)
+import hashlib
+h = hashlib.sha1()
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for fn in sorted(glob.glob(os.path.join(root, "pecaller_amd", "csrc", "*.hip*"))):
+    h.update(os.path.basename(fn).encode())
+    h.update(open(fn, "rb").read())
+out["kernel_sources_sha"] = h.hexdigest()[:16]
 json.dump(out, open(os.path.join(d, "pmc.json"), "w"), indent=1)
 print("wrote", os.path.join(d, "pmc.json"), {k: len(v) for k, v in out.items() if isinstance(v, dict)})

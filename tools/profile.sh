@@ -1,18 +1,21 @@
 #!/bin/bash
-# rocprofv3 passes behind profiles/: kernel-trace stats, then FETCH_SIZE and WRITE_SIZE in separate --pmc runs, then the SQ
-# instruction mix.  Run on the GPU box from the repo root:  tools/profile.sh <tag>  ->  gpurun_out/prof_<tag>/{stats.csv,pmc.json,...}
+# rocprofv3 passes behind profiles/: kernel-trace stats, then FETCH_SIZE and WRITE_SIZE in separate --pmc runs.
+# Run on the GPU box from the repo root:  tools/profile.sh <tag> [config]   (config: hg38_150 (default) or tsw250)
+#   -> gpurun_out/prof_<tag>/{stats.csv, pmc.json, ...}; copy pmc.json to profiles/r03_bench_pmc_<config>.json
 # (the program itself follows `--`: no env / bash -c hop between the profiler and python3)
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
+CFG=${2:-hg38_150}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu --pecall-cpu-seconds 1 > $OUT/stats.log 2>&1
+ARGS="--config $CFG --no-cpu --no-secondary --no-pecaller"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --steps 4 --warmup 1 $ARGS > $OUT/stats.log 2>&1
 echo "stats pass done"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu --no-secondary --no-pecaller > $OUT/fetch.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $ROOT/bench.py --steps 2 --warmup 1 $ARGS > $OUT/fetch.log 2>&1
 echo "FETCH_SIZE pass done"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu --no-secondary --no-pecaller > $OUT/write.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $ROOT/bench.py --steps 2 --warmup 1 $ARGS > $OUT/write.log 2>&1
 echo "WRITE_SIZE pass done"
 cd $ROOT
 python3 tools/pmc_summary.py $OUT 6    # (2 timed + 1 warm-up) steps at the seam + the same resident
