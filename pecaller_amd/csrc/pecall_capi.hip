@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <math.h>
 #include <chrono>
+#include <vector>
 #include "../../include/pemap_hip.h"
 #include "pecall_kernels.hip.h"
 #include "pecall_site.hip.h"
@@ -62,8 +63,7 @@ struct pecall_dev
   // the seam (pecall_dev_call_sites) beside the copies of the chunks around them
   long chunk_sites;
   hipStream_t stream_call[PCS_CALL_STREAMS], stream_h2d, stream_d2h;
-  hipEvent_t *ev_h2d, *ev_fast, *ev_call, *ev_d2h, *ev_depth;  // [cap_chunks]
-  unsigned *h_depth;            // [cap_chunks], pinned: the deepest sample of every chunk (pcs_depth_kernel), read by the host
+  hipEvent_t *ev_h2d, *ev_fast, *ev_call, *ev_d2h;      // [cap_chunks]
   char *h_in[PCS_SLOTS], *h_out[PCS_SLOTS];            // pinned staging for callers whose buffers are not pinned
   size_t h_in_bytes, h_out_bytes;
 };
@@ -191,11 +191,7 @@ extern "C" void pecall_dev_destroy (pecall_dev * d)
       hipEventDestroy (d->ev_fast[k]);
       hipEventDestroy (d->ev_call[k]);
       hipEventDestroy (d->ev_d2h[k]);
-      hipEventDestroy (d->ev_depth[k]);
     }
-  free (d->ev_depth);
-  if (d->h_depth)
-    hipHostFree (d->h_depth);
   free (d->ev_h2d);
   free (d->ev_fast);
   free (d->ev_call);
@@ -581,6 +577,7 @@ static int pcs_ensure_chunks (pecall_dev * d, long n_sites)
   if (!d->stream_h2d)
     {
       for (int i = 0; i < PCS_CALL_STREAMS; i++)
+        // (a stream priority for the beam searches was tried: 64 -> 60 M columns/s, the shortcut kernels wait for them then)
         PCCHK (d, hipStreamCreateWithFlags (&d->stream_call[i], hipStreamNonBlocking));
       PCCHK (d, hipStreamCreateWithFlags (&d->stream_h2d, hipStreamNonBlocking));
       PCCHK (d, hipStreamCreateWithFlags (&d->stream_d2h, hipStreamNonBlocking));
@@ -603,62 +600,59 @@ static int pcs_ensure_chunks (pecall_dev * d, long n_sites)
       d->ev_fast = (hipEvent_t *) realloc (d->ev_fast, sizeof (hipEvent_t) * nch);
       d->ev_call = (hipEvent_t *) realloc (d->ev_call, sizeof (hipEvent_t) * nch);
       d->ev_d2h = (hipEvent_t *) realloc (d->ev_d2h, sizeof (hipEvent_t) * nch);
-      d->ev_depth = (hipEvent_t *) realloc (d->ev_depth, sizeof (hipEvent_t) * nch);
-      if (d->h_depth)
-        hipHostFree (d->h_depth);
-      d->h_depth = nullptr;
-      PCCHK (d, hipHostMalloc ((void **) &d->h_depth, sizeof (unsigned) * nch, hipHostMallocDefault));
       for (int k = d->cap_chunks; k < nch; k++)
         {
           PCCHK (d, hipEventCreateWithFlags (&d->ev_h2d[k], hipEventDisableTiming));
           PCCHK (d, hipEventCreateWithFlags (&d->ev_fast[k], hipEventDisableTiming));
           PCCHK (d, hipEventCreateWithFlags (&d->ev_call[k], hipEventDisableTiming));
           PCCHK (d, hipEventCreateWithFlags (&d->ev_d2h[k], hipEventDisableTiming));
-          PCCHK (d, hipEventCreateWithFlags (&d->ev_depth[k], hipEventDisableTiming));
         }
       d->cap_chunks = nch;
     }
   return 0;
 }
 
-// Chunk k = columns [off, off + m), first half: its counters, and the deepest sample of its columns on its way to the host -- the
-// host picks the form of the shortcut kernel by it (the table's head in LDS, or the whole table: a workgroup of that form needs 112 KB
-// of a CU's LDS and is not even started where it would only return).
+// Chunk k = columns [off, off + m): its counters, the deepest sample of its columns (the shortcut kernel has two forms: the head of
+// the ln n! table in LDS, three workgroups per CU, or the whole table, one per CU -- which one serves depends on the depth), the
+// shortcut kernel (with the small beam) on the object's stream, and the beam search of the columns it lists on one of
+// PCS_CALL_STREAMS streams, so that it runs beside the next chunks' shortcut kernels.
+// Nothing here waits for the device.  The form with the table's head is launched without knowing the depth; it tests the depth
+// itself and leaves a chunk that is too deep untouched (an empty list for the beam search).  The host looks at the depths once, when
+// all chunks are through, and gives those chunks -- columns beyond ~1400 reads in one sample, rare -- a second pass with
+// whole_table = true.  (Waiting for each chunk's depth before its launch cost the seam half its rate: the 4-byte copy to the host
+// queued behind the chunks' 150 MB copies.)
 static int pcs_chunk_depth (pecall_dev * d, const PcsParams & P, int k, long off, long m)
 {
   const int N = P.indiv;
   unsigned long long *ctr = d->d_next_site + (size_t) k * 4;
   PCCHK (d, hipMemsetAsync (ctr, 0, 4 * sizeof (unsigned long long), d->stream));
-  d->h_depth[k] = 0u;
   if (N <= 64)
     {
-      unsigned *depth_max = (unsigned *) (ctr + 3);
       long dgrid = (m * N + 255) / 256;
       if (dgrid > d->grid * 4)
         dgrid = d->grid * 4;
-      hipLaunchKernelGGL (pcs_depth_kernel, dim3 ((unsigned) dgrid), dim3 (256), 0, d->stream, d->d_sreads + off * N * PCS_NA, m * N, depth_max);
-      PCCHK (d, hipMemcpyAsync (&d->h_depth[k], depth_max, sizeof (unsigned), hipMemcpyDeviceToHost, d->stream));
+      hipLaunchKernelGGL (pcs_depth_kernel, dim3 ((unsigned) dgrid), dim3 (256), 0, d->stream, d->d_sreads + off * N * PCS_NA, m * N, (unsigned *) (ctr + 3));
     }
-  PCCHK (d, hipEventRecord (d->ev_depth[k], d->stream));
   return 0;
 }
 
-// second half: the shortcut kernel (with the small beam) on the object's stream, the beam search of the columns it lists on one of
-// PCS_CALL_STREAMS streams, so that it runs beside the next chunks' shortcut kernels
-static int pcs_chunk_kernels (pecall_dev * d, const PcsParams & P, int k, long off, long m)
+static int pcs_chunk_kernels (pecall_dev * d, const PcsParams & P, int k, long off, long m, bool whole_table)
 {
   const int N = P.indiv;
   unsigned long long *ctr = d->d_next_site + (size_t) k * 4;
   unsigned *n_slow = (unsigned *) (ctr + 1);
   unsigned *slow = d->d_slow + (size_t) PCS_BUCKETS * off;
+  unsigned *depth_max = (unsigned *) (ctr + 3);
   const int nch = N <= 64 ? 1 : N <= 128 ? 2 : 4;
+  // (second pass: behind the first pass's beam search of the chunk, which shares these counters; the depth stays)
+  if (whole_table)
+    {
+      PCCHK (d, hipStreamWaitEvent (d->stream, d->ev_call[k], 0));
+      PCCHK (d, hipMemsetAsync (ctr, 0, 3 * sizeof (unsigned long long), d->stream));
+    }
   if (nch == 1)
     {
-      unsigned *depth_max = (unsigned *) (ctr + 3);
-      PCCHK (d, hipEventSynchronize (d->ev_depth[k]));
-      // (every n the columns look up: <= 6 x 100 + depth; the form with the table's head serves when that stays inside it -- the
-      // kernels test the same and return when launched in the wrong form)
-      if (d->h_depth[k] + 6u * 100u + 1u < (unsigned) PCS_FAST_TAB)
+      if (!whole_table)
         {
           constexpr int B = PCS_FAST_BLOCK_OF (PCS_FAST_TAB);
           long fgrid = (m + B / 64 - 1) / (B / 64);
@@ -679,6 +673,8 @@ static int pcs_chunk_kernels (pecall_dev * d, const PcsParams & P, int k, long o
                               d->d_ac + off * PCS_NA, d->d_npass + off, d->d_den + off, slow, n_slow, depth_max, d->d_ta);
         }
     }
+  else if (whole_table)
+    return 0;                   // (more than 64 samples: one form only)
   // (more than 64 samples: no shortcut kernel; the beam search's kernel takes every column of the chunk, a lane standing for a
   // sample of each chunk of 64 -- the reference's range, any INDIV (pecaller.c:251-257), not this library's fast case)
   PCCHK (d, hipEventRecord (d->ev_fast[k], d->stream));
@@ -705,6 +701,24 @@ static int pcs_chunk_kernels (pecall_dev * d, const PcsParams & P, int k, long o
   return 0;
 }
 
+// the chunks whose depth asks for the whole table (to be called when the first pass is through on the device): 1 in deep[k]
+static int pcs_deep_chunks (pecall_dev * d, const PcsParams & P, int nch, std::vector < char >&deep, int *n_deep)
+{
+  *n_deep = 0;
+  deep.assign ((size_t) nch, 0);
+  if (P.indiv > 64)
+    return 0;
+  std::vector < unsigned long long >c ((size_t) nch * 4);
+  PCCHK (d, hipMemcpy (c.data (), d->d_next_site, c.size () * sizeof (unsigned long long), hipMemcpyDeviceToHost));
+  for (int k = 0; k < nch; k++)
+    if (!((unsigned) c[(size_t) k * 4 + 3] + 6u * 100u + 1u < (unsigned) PCS_FAST_TAB))
+      {
+        deep[k] = 1;
+        (*n_deep)++;
+      }
+  return 0;
+}
+
 extern "C" int pecall_dev_sites_run (pecall_dev * d, int haploid, double threshold, double theta, float *kernel_ms)
 {
   PCCHK (d, hipSetDevice (d->device));
@@ -719,19 +733,39 @@ extern "C" int pecall_dev_sites_run (pecall_dev * d, int haploid, double thresho
   if ((rc = pcs_ensure_chunks (d, n_sites)))
     return rc;
   PCCHK (d, hipEventRecord (d->ev_site[0], d->stream));
-  int k = 0;
-  for (long off = 0; off < n_sites; off += d->chunk_sites, k++)
-    if ((rc = pcs_chunk_depth (d, P, k, off, n_sites - off < d->chunk_sites ? n_sites - off : d->chunk_sites)))
-      return rc;
-  k = 0;
-  for (long off = 0; off < n_sites; off += d->chunk_sites, k++)
-    if ((rc = pcs_chunk_kernels (d, P, k, off, n_sites - off < d->chunk_sites ? n_sites - off : d->chunk_sites)))
-      return rc;
-  // (the object's stream ends behind the last beam searches: ev_site[1] closes the interval of all streams)
-  for (int q = k > PCS_CALL_STREAMS ? k - PCS_CALL_STREAMS : 0; q < k; q++)
-    PCCHK (d, hipStreamWaitEvent (d->stream, d->ev_call[q], 0));
-  PCCHK (d, hipEventRecord (d->ev_site[1], d->stream));
-  PCCHK (d, hipStreamSynchronize (d->stream));
+  const long C = d->chunk_sites;
+  const int k = (int) ((n_sites + C - 1) / C);
+  std::vector < char >deep ((size_t) k, 0);
+  for (int pass = 0; pass < 2; pass++)
+    {
+      // (the depths of all chunks first: a small kernel between two shortcut kernels costs the end of one and the start of the next)
+      for (int q = 0; q < k && pass == 0; q++)
+        if ((rc = pcs_chunk_depth (d, P, q, (long) q * C, n_sites - (long) q * C < C ? n_sites - (long) q * C : C)))
+          return rc;
+      for (int q = 0; q < k; q++)
+        if (pass == 0 || deep[q])
+          if ((rc = pcs_chunk_kernels (d, P, q, (long) q * C, n_sites - (long) q * C < C ? n_sites - (long) q * C : C, pass == 1)))
+            return rc;
+      // (the object's stream ends behind the beam searches: ev_site[1] closes the interval of all streams)
+      for (int q = 0; q < k; q++)
+        PCCHK (d, hipStreamWaitEvent (d->stream, d->ev_call[q], 0));
+      if (pass == 0)
+        {
+          PCCHK (d, hipEventRecord (d->ev_site[1], d->stream));
+          PCCHK (d, hipStreamSynchronize (d->stream));
+          int n_deep = 0;
+          if ((rc = pcs_deep_chunks (d, P, k, deep, &n_deep)))
+            return rc;
+          if (n_deep == 0)
+            break;
+        }
+      else
+        {
+          // (deep chunks: the second pass is part of the run; its interval ends here)
+          PCCHK (d, hipEventRecord (d->ev_site[1], d->stream));
+          PCCHK (d, hipStreamSynchronize (d->stream));
+        }
+    }
   if (kernel_ms)
     PCCHK (d, hipEventElapsedTime (kernel_ms, d->ev_site[0], d->ev_site[1]));
   if (getenv ("PECALL_LIST_STATS"))
@@ -882,15 +916,13 @@ extern "C" int pecall_dev_call_sites (pecall_dev * d, const uint16_t * reads, co
     return 0;
   };
   // chunk j's kernels, and its results on their way out behind its beam search (which follows its shortcut kernel)
-  auto kernels_and_out = [&] (int j) -> int
+  auto kernels_and_out = [&] (int j, bool whole_table) -> int
   {
     const long off = (long) j * C, m = n_sites - off < C ? n_sites - off : C;
-    int rc2 = pcs_chunk_kernels (d, P, j, off, m);
-    if (rc2)
+    int rc2 = whole_table ? 0 : pcs_chunk_depth (d, P, j, off, m);
+    if (rc2 || (rc2 = pcs_chunk_kernels (d, P, j, off, m, whole_table)))
       return rc2;
     PCCHK (d, hipStreamWaitEvent (d->stream_d2h, d->ev_call[j], 0));
-    if (!out_direct && j >= PCS_SLOTS && (rc2 = finish (j - PCS_SLOTS)))
-      return rc2;
     char *o = out_direct ? nullptr : d->h_out[j % PCS_SLOTS];
 #define PCS_OUT(dst_host, dev_ptr, bytes) do { void *dst_ = out_direct ? (void *) (dst_host) : (void *) o; if (out_direct ? (dst_host) != nullptr : true) \
     PCCHK (d, hipMemcpyAsync (dst_, dev_ptr, bytes, hipMemcpyDeviceToHost, d->stream_d2h)); if (!out_direct) o += (bytes); } while (0)
@@ -911,12 +943,8 @@ extern "C" int pecall_dev_call_sites (pecall_dev * d, const uint16_t * reads, co
     {
       const long off = (long) k * C, m = n_sites - off < C ? n_sites - off : C;
       const double t0 = since ();
-      // ---- the kernels of the chunk before (its depth has reached the host by now, or soon): they run while this chunk is staged and
-      //      travels
-      if (k >= 1 && (rc = kernels_and_out (k - 1)))
-        return rc;
-      // ---- in: (a staging slot is free again when the chunk that used it PCS_SLOTS chunks ago has been copied to the device, and
-      //      its results have left the slot of the same number: finish (k - PCS_SLOTS) below ran before this)
+      // ---- in: (a staging slot is free again when the chunk that used it PCS_SLOTS chunks ago has been copied to the device; the
+      //      result slot of the same number when that chunk's results have been handed over: finish (k - PCS_SLOTS))
       const uint16_t *src_r = reads + off * N * PCS_NA;
       const uint8_t *src_b = ref_base + off, *src_c = chrom_type ? chrom_type + off : nullptr;
       if (!in_direct)
@@ -943,21 +971,34 @@ extern "C" int pecall_dev_call_sites (pecall_dev * d, const uint16_t * reads, co
       else
         PCCHK (d, hipMemsetAsync (d->d_chromy + off, 0, (size_t) m, d->stream_h2d));
       PCCHK (d, hipEventRecord (d->ev_h2d[k], d->stream_h2d));
-      // ---- the chunk's counters and its depth (the host needs it for the kernels' launch: it launches them one chunk behind,
-      //      while this chunk's columns travel)
+      // ---- the chunk's kernels behind its copy, its results behind its kernels: all queued, the host goes on to the next chunk
       PCCHK (d, hipStreamWaitEvent (d->stream, d->ev_h2d[k], 0));
-      if ((rc = pcs_chunk_depth (d, P, k, off, m)))
+      if (!out_direct && k >= PCS_SLOTS && (rc = finish (k - PCS_SLOTS)))
+        return rc;
+      if ((rc = kernels_and_out (k, false)))
         return rc;
       if (trace)
         fprintf (stderr, "[pecall seam] chunk %d: host at %.2f ms, enqueued by %.2f ms (direct in %d out %d)\n", k, t0, since (), (int) in_direct, (int) out_direct);
     }
-  if ((rc = kernels_and_out (nch - 1)))
-    return rc;
-  if (trace)
-    fprintf (stderr, "[pecall seam] last kernels enqueued by %.2f ms\n", since ());
   for (int j = (out_direct || nch < PCS_SLOTS) ? 0 : nch - PCS_SLOTS; j < nch; j++)
     if ((rc = finish (j)))
       return rc;
+  if (trace)
+    fprintf (stderr, "[pecall seam] first pass on the host by %.2f ms\n", since ());
+  // ---- chunks too deep for the table's head: once more, with the whole table (their columns are on the device)
+  {
+    std::vector < char >deep;
+    int n_deep = 0;
+    PCCHK (d, hipStreamSynchronize (d->stream));
+    if ((rc = pcs_deep_chunks (d, P, nch, deep, &n_deep)))
+      return rc;
+    for (int j = 0; j < nch && n_deep; j++)
+      if (deep[j])
+        {
+          if ((rc = kernels_and_out (j, true)) || (rc = finish (j)))
+            return rc;
+        }
+  }
   PCCHK (d, hipStreamSynchronize (d->stream));
   for (int i = 0; i < PCS_CALL_STREAMS; i++)
     PCCHK (d, hipStreamSynchronize (d->stream_call[i]));

@@ -1558,6 +1558,7 @@ __device__ bool pcs_mini_beam (const PcsParams & P, const double *tab_unused, co
 // and 12 waves per CU run (the registers' limit) beside whatever else is resident; otherwise the whole table (80 KB) is staged by
 // workgroups of 8 waves, one per CU, as before round 3.  Both forms are launched; the one the depth does not select returns at once.
 #define PCS_FAST_TAB 2048
+#define PCS_FAST_GRAB 8                // columns a wave of the shortcut kernel takes per fetch of the work counter
 #define PCS_FAST_WAVE_BYTES (64 + PCS_NG * 8 + 16)        // per wave: the samples' order, one sample's likelihoods (pcs_mini_beam)
 #define PCS_FAST_BLOCK_OF(TABN) ((TABN) == PCS_FAST_TAB ? 256 : 512)
 // pass 1's integer Dirichlet parameters ta = max (1, ceil (scale * mean[g][a])) (pecaller.c:2478) depend on the reference base, the
@@ -1622,7 +1623,7 @@ template < int TABN > __global__ __launch_bounds__ (PCS_FAST_BLOCK_OF (TABN), TA
 void pcs_fast_kernel (PcsParams P, const uint16_t * reads, const uint8_t * dom_of, const uint8_t * chrom_of,
                       long n_sites, int8_t * call, double *post_out, int8_t * type_out,
                       int32_t * allele_count, int8_t * n_pass, int32_t * denovo_out,
-                      unsigned *slow_list, unsigned *n_slow, const unsigned *depth_max, const uint32_t * ta_table)
+                      unsigned *slow_list, unsigned *n_slow, unsigned *depth_max, const uint32_t * ta_table)
 {
   constexpr int PCS_FAST_BLOCK = PCS_FAST_BLOCK_OF (TABN);
   // (every n the columns look up: <= 6 x 100 + depth; the form with the table's head serves when that stays inside it)
@@ -1644,8 +1645,21 @@ void pcs_fast_kernel (PcsParams P, const uint16_t * reads, const uint8_t * dom_o
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint8_t *w_sord = (uint8_t *) (ta_hi + PCS_TA_ROWS) + (size_t) wave * PCS_FAST_WAVE_BYTES;
   double *w_like = (double *) (w_sord + 64);
-  const long stride = (long) gridDim.x * (PCS_FAST_BLOCK / 64);
-  for (long site = (long) blockIdx.x * (PCS_FAST_BLOCK / 64) + wave; site < n_sites; site += stride)
+  // Columns are handed out PCS_FAST_GRAB at a time through a counter (depth_max[1]; the first grid-ful of pieces by wave index).
+  // With a fixed stride the launch took as long as its unluckiest workgroup: beside the beam searches of earlier chunks, whose
+  // waves hold 40 KB of LDS each for milliseconds, a CU now and then has room for two of these workgroups instead of three, the third
+  // starts when another one ends -- and then still had its full share to do (2.2 ms per chunk alone, 3.5 ms beside them).
+  unsigned *const next_piece = depth_max + 1;
+  const long n_pieces = (n_sites + PCS_FAST_GRAB - 1) / PCS_FAST_GRAB;
+  const long first_free = (long) gridDim.x * (PCS_FAST_BLOCK / 64);
+  for (long piece = (long) blockIdx.x * (PCS_FAST_BLOCK / 64) + wave; piece < n_pieces;)
+    {
+      // (the next piece's number is asked for now and looked at when this piece is done)
+      unsigned nx = 0u;
+      if (lane == 0)
+        nx = atomicAdd (next_piece, 1u);
+      const long site_end = min ((piece + 1) * PCS_FAST_GRAB, n_sites);
+      for (long site = piece * PCS_FAST_GRAB; site < site_end; site++)
     {
       const int dom = dom_of[site];
       const int chrom = chrom_of[site] & 3;
@@ -1779,5 +1793,7 @@ void pcs_fast_kernel (PcsParams P, const uint16_t * reads, const uint8_t * dom_o
           if (lane == 0)
             slow_list[(size_t) b * (size_t) n_sites + atomicAdd (&n_slow[b], 1u)] = (unsigned) site;
         }
+    }
+      piece = first_free + (long) (unsigned) __shfl ((int) nx, 0);
     }
 }
