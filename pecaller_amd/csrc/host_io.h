@@ -8,6 +8,10 @@
  *   pgz       a gz FILE written as a sequence of gzip members deflated by several threads (like pigz -i): the bytes a reader
  *             inflates are exactly the bytes given, in order; zlib's gzread -- what the reference's readers use
  *             (pecaller.c:891-907) -- reads concatenated members as one stream.  Level = zlib's default, as gzopen "wb".
+ *   gzsrc     where the readers' bytes come from: a regular file is mapped and, if it is gzip, inflated by fast_inflate.h (2-3
+ *             times zlib's rate; every member's CRC and length checked); a file that is not gzip is handed out as it lies in the
+ *             mapping (gzopen reads such files too, pemapper.c:626); anything else -- a pipe, or PEMAP_ZLIB_INFLATE=1 -- goes
+ *             through zlib's gzread as before.
  */
 #ifndef HOST_IO_H
 #define HOST_IO_H
@@ -16,12 +20,169 @@
 #include <string.h>
 #include <zlib.h>
 #include <pthread.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include "fast_inflate.h"
 
-#define ZR_BLOCK (1 << 20)
+/* ---- the source of a reader's bytes */
+typedef struct
+{
+  int mode;                     /* 0 zlib, 1 gzip through fast_inflate, 2 not compressed */
+  gzFile f;
+  int fd;
+  const uint8_t *map;
+  size_t map_len, plain_pos;
+  fi_state *fi;
+  uint8_t *buf, *out;           /* mode 1: FI_WINDOW bytes of room for the window, then the blocks */
+  size_t buf_len, block;
+  const char *err;
+} gzsrc;
+
+static pthread_once_t gzsrc_once = PTHREAD_ONCE_INIT;
+static void
+gzsrc_global_init (void)
+{
+  fi_crc32 (0u, (const uint8_t *) "", 0);       /* tables, CPU features */
+}
+
+/* 0 = ok, -1 = the file cannot be opened.  `block` = bytes handed out per call at most, `ring` = blocks the consumer may hold. */
+__attribute__ ((unused)) static int
+gzsrc_open (gzsrc * g, const char *path, size_t block, int ring)
+{
+  memset (g, 0, sizeof *g);
+  g->fd = -1;
+  g->block = block;
+  pthread_once (&gzsrc_once, gzsrc_global_init);
+  const char *force = getenv ("PEMAP_ZLIB_INFLATE");
+  if (!(force && atoi (force)))
+    {
+      g->fd = open (path, O_RDONLY);
+      if (g->fd < 0)
+        return -1;
+      struct stat st;
+      if (fstat (g->fd, &st) == 0 && S_ISREG (st.st_mode))
+        {
+          if (st.st_size == 0)
+            {
+              g->mode = 2;      /* an empty file: no bytes (gzread gives 0) */
+              return 0;
+            }
+          void *m = mmap (NULL, (size_t) st.st_size, PROT_READ, MAP_PRIVATE, g->fd, 0);
+          if (m != MAP_FAILED)
+            {
+              madvise (m, (size_t) st.st_size, MADV_SEQUENTIAL);
+              g->map = (const uint8_t *) m;
+              g->map_len = (size_t) st.st_size;
+              if (g->map_len >= 2 && g->map[0] == 0x1f && g->map[1] == 0x8b)
+                {
+                  g->mode = 1;
+                  g->fi = (fi_state *) malloc (sizeof (fi_state));
+                  g->buf_len = FI_WINDOW + (size_t) (2 * ring + 2) * block + FI_SLACK;
+                  g->buf = (uint8_t *) malloc (g->buf_len);
+                  if (!g->fi || !g->buf)
+                    return -1;
+                  fi_init (g->fi, g->map, g->map_len);
+                  g->out = g->buf + FI_WINDOW;
+                }
+              else
+                g->mode = 2;
+              return 0;
+            }
+        }
+      close (g->fd);
+      g->fd = -1;
+    }
+  g->mode = 0;
+  g->f = gzopen (path, "rb");
+  if (!g->f)
+    return -1;
+  gzbuffer (g->f, 1 << 20);
+  return 0;
+}
+
+/* the next block: 1 = *ptr / *len describe it (mode 0: read into own_buf, `block` bytes of room), 0 = end of data, -1 = the stream
+   is damaged or cut short */
+__attribute__ ((unused)) static int
+gzsrc_next (gzsrc * g, char *own_buf, char **ptr, int *len)
+{
+  if (g->mode == 0)
+    {
+      const int got = gzread (g->f, own_buf, (unsigned) g->block);
+      if (got <= 0)
+        {
+          /* (gzread gives 0 after a truncated member and keeps Z_BUF_ERROR) */
+          int en = Z_OK;
+          gzerror (g->f, &en);
+          return (got < 0 || (en != Z_OK && en != Z_STREAM_END)) ? -1 : 0;
+        }
+      *ptr = own_buf;
+      *len = got;
+      return 1;
+    }
+  if (g->mode == 2)
+    {
+      if (g->plain_pos >= g->map_len)
+        return 0;
+      size_t m = g->map_len - g->plain_pos;
+      if (m > g->block)
+        m = g->block;
+      *ptr = (char *) (g->map + g->plain_pos);  /* (read-only: the consumers do not write into their blocks) */
+      *len = (int) m;
+      g->plain_pos += m;
+      return 1;
+    }
+  for (;;)
+    {
+      if (g->out + g->block + FI_SLACK > g->buf + g->buf_len)
+        {
+          /* back to the start of the buffer: the window moves with the writer (the blocks the consumer may still hold are the last
+             `ring`, all of them further up than the 2 blocks' room the writer has before it waits for the consumer) */
+          memmove (g->buf, g->out - FI_WINDOW, FI_WINDOW);      /* (they overlap when the blocks are small) */
+          fi_moved (g->fi, g->out, g->buf + FI_WINDOW);
+          g->out = g->buf + FI_WINDOW;
+        }
+      uint8_t *start = g->out;
+      const int rc = fi_run (g->fi, &g->out, start + g->block - FI_SLACK);
+      /* (what was decoded before the damage is handed out first; the next call reports the damage) */
+      if (rc == FI_ERROR && g->out == start)
+        {
+          g->err = g->fi->msg;
+          return -1;
+        }
+      if (g->out > start)
+        {
+          *ptr = (char *) start;
+          *len = (int) (g->out - start);
+          return 1;
+        }
+      if (rc == FI_END)
+        return 0;
+    }
+}
+
+__attribute__ ((unused)) static void
+gzsrc_close (gzsrc * g)
+{
+  if (g->f)
+    gzclose (g->f);
+  if (g->map)
+    munmap ((void *) g->map, g->map_len);
+  if (g->fd >= 0)
+    close (g->fd);
+  free (g->fi);
+  free (g->buf);
+  memset (g, 0, sizeof *g);
+  g->fd = -1;
+}
+
+#define ZR_BLOCK (1 << 18)     /* (64 to 256 of these streams are open at once: 18 blocks of buffer each) */
 #define ZR_RING 8
 typedef struct
 {
-  gzFile f;
+  gzsrc src;
+  char *own[ZR_RING];           /* the ring's own buffers (zlib mode only) */
   pthread_t th;
   pthread_mutex_t mu;
   pthread_cond_t cv;
@@ -52,15 +213,13 @@ zr_inflate (void *arg)
       pthread_mutex_unlock (&r->mu);
       if (stop)
         return NULL;
-      int got = gzread (r->f, r->ring[tail], ZR_BLOCK);
-      int bad = 0;
-      if (got <= 0)
-        {
-          /* a short or corrupt stream is an error, not an end (gzread gives 0 after a truncated member and keeps Z_BUF_ERROR) */
-          int en = Z_OK;
-          gzerror (r->f, &en);
-          bad = got < 0 || (en != Z_OK && en != Z_STREAM_END);
-        }
+      /* a short or corrupt stream is an error, not an end */
+      char *blk = NULL;
+      int got = 0;
+      const int rc = gzsrc_next (&r->src, r->own[tail], &blk, &got);
+      const int bad = rc < 0;
+      if (rc <= 0)
+        got = 0;
       pthread_mutex_lock (&r->mu);
       if (bad)
         r->error = 1;
@@ -68,6 +227,7 @@ zr_inflate (void *arg)
         r->done = 1;
       else
         {
+          r->ring[tail] = blk;
           r->ring_len[tail] = got;
           r->count++;
         }
@@ -84,13 +244,12 @@ __attribute__ ((unused)) static int
 zr_open (zreader * r, const char *path)
 {
   memset (r, 0, sizeof *r);
-  r->f = gzopen (path, "rb");
-  if (!r->f)
+  if (gzsrc_open (&r->src, path, ZR_BLOCK, ZR_RING))
     return -1;
   r->path = path;
-  gzbuffer (r->f, 1 << 20);
-  for (int i = 0; i < ZR_RING; i++)
-    r->ring[i] = (char *) malloc (ZR_BLOCK);
+  if (r->src.mode == 0)
+    for (int i = 0; i < ZR_RING; i++)
+      r->own[i] = (char *) malloc (ZR_BLOCK);
   pthread_mutex_init (&r->mu, NULL);
   pthread_cond_init (&r->cv, NULL);
   if (pthread_create (&r->th, NULL, zr_inflate, r))
@@ -156,9 +315,9 @@ zr_close (zreader * r)
   pthread_cond_broadcast (&r->cv);
   pthread_mutex_unlock (&r->mu);
   pthread_join (r->th, NULL);
-  gzclose (r->f);
+  gzsrc_close (&r->src);
   for (int i = 0; i < ZR_RING; i++)
-    free (r->ring[i]);
+    free (r->own[i]);
   pthread_mutex_destroy (&r->mu);
   pthread_cond_destroy (&r->cv);
 }

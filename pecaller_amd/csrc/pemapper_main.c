@@ -58,7 +58,8 @@ ck (pemap_dev * dev, int rc)
 #define LR_RING 8
 typedef struct
 {
-  gzFile f;
+  gzsrc src;
+  char *own[LR_RING];           /* the ring's own buffers (zlib mode only) */
   char *buf;
   size_t cap, len, pos;
   int eof;
@@ -89,20 +90,21 @@ lr_inflate (void *arg)
       pthread_mutex_unlock (&r->mu);
       if (stop)
         return NULL;
-      int got = gzread (r->f, r->ring[tail], LR_BLOCK);
-      if (got <= 0)
-        {
-          /* the reference's my_gzgets ends the file at the first failed read; so does this reader, but not silently */
-          int en = Z_OK;
-          gzerror (r->f, &en);
-          if (got < 0 || (en != Z_OK && en != Z_STREAM_END))
-            fprintf (stderr, "\n Warning: a read file is truncated or not a valid gzip stream; the reads before the damage are mapped \n");
-        }
+      /* the reference's my_gzgets ends the file at the first failed read; so does this reader, but not silently */
+      char *blk = NULL;
+      int got = 0;
+      const int rc = gzsrc_next (&r->src, r->own[tail], &blk, &got);
+      if (rc < 0)
+        fprintf (stderr, "\n Warning: a read file is truncated or not a valid gzip stream (%s); the reads before the damage are mapped \n",
+                 r->src.err ? r->src.err : "zlib");
+      if (rc <= 0)
+        got = 0;
       pthread_mutex_lock (&r->mu);
       if (got <= 0)
         r->done = 1;
       else
         {
+          r->ring[tail] = blk;
           r->ring_len[tail] = got;
           r->count++;
         }
@@ -117,17 +119,18 @@ lr_inflate (void *arg)
 static void
 lr_open (lreader * r, const char *path)
 {
-  r->f = gzopen (path, "r");
-  if (!r->f)
+  if (gzsrc_open (&r->src, path, LR_BLOCK, LR_RING))
     die ("\n Can not open file %s for reading", path);
-  gzbuffer (r->f, 1 << 20);
   r->cap = 2 * LR_BLOCK;
   r->buf = (char *) malloc (r->cap + 1);
   r->len = r->pos = 0;
   r->eof = 0;
   r->head = r->count = r->done = r->stop = 0;
   for (int i = 0; i < LR_RING; i++)
-    r->ring[i] = (char *) malloc (LR_BLOCK);
+    {
+      r->ring[i] = NULL;
+      r->own[i] = r->src.mode == 0 ? (char *) malloc (LR_BLOCK) : NULL;
+    }
   pthread_mutex_init (&r->mu, NULL);
   pthread_cond_init (&r->cv, NULL);
   if (pthread_create (&r->th, NULL, lr_inflate, r))
@@ -143,15 +146,16 @@ lr_close (lreader * r)
   pthread_cond_broadcast (&r->cv);
   pthread_mutex_unlock (&r->mu);
   pthread_join (r->th, NULL);
-  gzclose (r->f);
+  gzsrc_close (&r->src);
   for (int i = 0; i < LR_RING; i++)
-    free (r->ring[i]);
+    free (r->own[i]);
   pthread_mutex_destroy (&r->mu);
   pthread_cond_destroy (&r->cv);
   free (r->buf);
 }
 
-/* next line without its '\n' (a '\r' stays, as in the reference) and its length, NULL at end of data.  A line that lies inside one
+/* next line (its '\n' not counted; a '\r' stays, as in the reference; NOT 0-terminated unless it was put together in r->buf) and its
+   length, NULL at end of data.  A line that lies inside one
    block of the ring is returned where it is (valid until the next call); only a line that straddles blocks is put together in
    r->buf.  (The reference's my_gzgets copies every line, pemapper.c:2447-2483.) */
 static char *
@@ -167,7 +171,7 @@ lr_gets (lreader * r, size_t *len_out)
           const size_t n = nl ? (size_t) (nl - base) : r->len - r->pos;
           if (nl && have == 0)
             {
-              *nl = '\0';
+              /* (the block is left as it is: it may be the input file's mapping, or the window the inflater copies matches from) */
               r->pos += n + 1;
               if (len_out)
                 *len_out = n;
@@ -977,6 +981,9 @@ main (int argc, char *argv[])
       pool.next = iter;
       pool.last = last;
       const int T = last - iter < n_workers ? last - iter : n_workers;
+      struct timespec set0, set1;
+      const long pairs_before = pool.tot_pairs;
+      clock_gettime (CLOCK_MONOTONIC, &set0);
       pthread_t th[64];
       int started = 0;
       for (int k = 1; k < T; k++)
@@ -988,6 +995,14 @@ main (int argc, char *argv[])
       file_worker_main (&workers[0]);
       for (int k = 1; k <= started; k++)
         pthread_join (th[k], NULL);
+      clock_gettime (CLOCK_MONOTONIC, &set1);
+      if (last - iter > 1)
+        {
+          const double sec = (double) (set1.tv_sec - set0.tv_sec) + 1e-9 * (double) (set1.tv_nsec - set0.tv_nsec);
+          printf ("\n pemapper_hip: %d files by %d workers: %ld %s read and mapped in %.3f s (%.2f M reads/s, input parsing included) \n", last - iter, started + 1,
+                  pool.tot_pairs - pairs_before, paired ? "pairs" : "reads", sec,
+                  (paired ? 2.0 : 1.0) * (double) (pool.tot_pairs - pairs_before) / (sec > 0 ? sec : 1) / 1e6);
+        }
       iter = last;
     }
   dump_output (&c, basename, pool.tot_pairs);

@@ -1,6 +1,6 @@
 #!/bin/bash
 # wall-clock rate of the host program pemapper_hip on N x 20 k pairs (the golden fixture concatenated: gz members concatenate), from
-# gz input and from the same reads as plain text.   tools/cli_throughput.sh [copies=100]
+# gz input and from the same reads as plain text.   tools/cli_throughput.sh [copies=100] [copies for the array-mode run=copies]
 set -e
 N=${1:-100}
 ROOT=$(pwd); W=$(mktemp -d); cd $W
@@ -24,5 +24,15 @@ for kind in big plain plain; do
   python3 -c "
 import os; n=os.path.getsize('${kind}_1_.$sfx.mfile')//4; w=$T1-$T0; print('$kind input: pairs', n, 'wall %.2f s' % w, '= %.2f M reads/s end to end (start-up, index build of the 5 Mbp fixture genome and output included)' % (2*n/w/1e6))"
 done
+# ---- array mode: the same reads as 8 gz file pairs into one output set (the reference's usual run, pemapper.c:307-348), the files
+#      read and mapped side by side by the program's file workers
+M=$(((${2:-$N}) / 8)); [ $M -lt 1 ] && M=1     # (second argument: copies for the array-mode run, all 8 files together)
+for f in $(seq 8); do for k in 1 2; do for i in $(seq $M); do cat $ROOT/tests/golden/g1_${k}_.fastq.gz; done > part${f}_${k}_.fastq.gz; done; echo $W/part${f}_1_.fastq.gz >> a1.txt; echo $W/part${f}_2_.fastq.gz >> a2.txt; done
+T0=$(date +%s.%N)
+$ROOT/pecaller_amd/pemapper_hip out_arr g1.sdx pa a1.txt a2.txt 500 0 N 0.85 24 2000000000 > log_arr.txt 2>&1 || { tail -3 log_arr.txt; exit 1; }
+T1=$(date +%s.%N)
+grep "files by" log_arr.txt
+python3 -c "
+import os; n=sum(os.path.getsize('part%d_1_.fastq.gz.mfile' % f)//4 for f in range(1,9)); w=$T1-$T0; print('array mode, 8 gz file pairs: pairs', n, 'wall %.2f s' % w, '= %.2f M reads/s end to end' % (2*n/w/1e6))"
 cmp out_big.pileup.gz out_plain.pileup.gz > /dev/null 2>&1 && echo "pileups of the two runs: identical bytes" || { gzip -dc out_big.pileup.gz | md5sum; gzip -dc out_plain.pileup.gz | md5sum; }
 cd /; rm -rf $W

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """wall clock of the host program pecaller_hip on N pileup columns x S samples of bench.py's config-4 generator (30x Poisson, 0.4 %
-error, 1 variant per kb), laid over the golden fixture's genome:  python3 tools/pecaller_cli_throughput.py [columns=1000000] [samples=64]
+error, 1 variant per kb), on a genome of its own (the generator's reference bases), the generated columns laid down `repeats` times:  python3 tools/pecaller_cli_throughput.py [columns=1000000] [samples=64] [repeats=1]
 (the program prints its own split: merge + device + text)"""
 import gzip, os, shutil, subprocess, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,31 +10,34 @@ import numpy as np
 import bench, refio
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-_, seqs = refio.read_fasta(os.path.join(ROOT, "tests", "golden", "g1.fa.gz"))
-genome = np.concatenate(seqs)
-n = min(n, len(genome) - 2000)
+REP = int(sys.argv[3]) if len(sys.argv) > 3 else 1        # the generated columns laid down REP times, one after the other
 OFF = 1000              # (position 0 means 'stream ended' to the merge, pecaller.c:891-907)
 reads, dom = bench.pecall_columns(n, S)              # [n][S][6] u16; dom = reference base code of the generator
-# the generator's reference base is not the fixture genome's letter: rotate the four base columns so that it is
-code = {ord("A"): 0, ord("C"): 1, ord("G"): 2, ord("T"): 3}
-g = np.array([code.get(int(c), 0) for c in genome[OFF:OFF + n]], np.int64)
-rot = (g - dom.astype(np.int64)) % 4
-idx = (np.arange(4)[None, :] - rot[:, None]) % 4
-r2 = reads.copy()
-r2[:, :, :4] = np.take_along_axis(reads[:, :, :4], np.broadcast_to(idx[:, None, :], (n, S, 4)), axis=2)
+# a genome of its own: the letter at every column is the generator's reference base
+genome = np.full(OFF + n * REP + 1000, ord("A"), np.uint8)
+genome[OFF:OFF + n * REP] = np.tile(np.frombuffer(b"ACGT", np.uint8)[dom], REP)
 W = tempfile.mkdtemp()
-shutil.copy(os.path.join(ROOT, "tests", "golden", "g1.sdx"), os.path.join(W, "g1.sdx"))
-gzip.open(os.path.join(W, "g1.seq"), "wb", compresslevel=1).write(genome.tobytes())
+open(os.path.join(W, "g1.sdx"), "w").write("1\n%d\tchr1\n" % len(genome))
+gzip.open(os.path.join(W, "g1.seq"), "wb", compresslevel=1).write(genome.tobytes() + b"N" * 15)
 run = os.path.join(W, "run")
 os.mkdir(run)
 rec = np.dtype([("pos", "<u4"), ("c", "<u2", 6)])
-for s in range(S):
+
+
+def write_sample(s):
     a = np.zeros(n, rec)
-    a["pos"] = np.arange(n, dtype=np.uint32) + OFF
-    a["c"] = r2[:, s, :]
-    a = a[a["c"].sum(axis=1) > 0]
-    with gzip.open(os.path.join(run, "s%03d.pileup.gz" % s), "wb", compresslevel=1) as f:
-        f.write(a.tobytes())
+    a["c"] = reads[:, s, :]
+    keep = a["c"].sum(axis=1) > 0
+    with open(os.path.join(run, "s%03d.pileup.gz" % s), "wb") as f:
+        for k in range(REP):
+            a["pos"] = np.arange(n, dtype=np.uint32) + OFF + k * n
+            f.write(gzip.compress(a[keep].tobytes(), compresslevel=1))      # (gz members concatenate)
+
+
+import multiprocessing
+with multiprocessing.get_context("fork").Pool(min(16, os.cpu_count() or 1)) as pool:
+    pool.map(write_sample, range(S))
+n = n * REP
 t0 = time.time()
 out = subprocess.run([os.path.join(ROOT, "pecaller_amd", "pecaller_hip"), "pileup", os.path.join(W, "g1.sdx"), str(S), "out", "0.95", "0.001", "n", "24", "n"],
                      cwd=run, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
