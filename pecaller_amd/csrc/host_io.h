@@ -7,7 +7,8 @@
  *             pecaller run, or the two mate files of a mapper run, inflate beside each other and beside the consumer.
  *   pgz       a gz FILE written as a sequence of gzip members deflated by several threads (like pigz -i): the bytes a reader
  *             inflates are exactly the bytes given, in order; zlib's gzread -- what the reference's readers use
- *             (pecaller.c:891-907) -- reads concatenated members as one stream.  Level = zlib's default, as gzopen "wb".
+ *             (pecaller.c:891-907) -- reads concatenated members as one stream.  Level = zlib's default, as gzopen "wb", unless the
+ *             program sets another (pecaller_hip's rows: level 2, half the deflate time for 1.4x the file) or PEMAP_GZ_LEVEL does.
  *   gzsrc     where the readers' bytes come from: a regular file is mapped and, if it is gzip, inflated by fast_inflate.h (2-3
  *             times zlib's rate; every member's CRC and length checked); a file that is not gzip is handed out as it lies in the
  *             mapping (gzopen reads such files too, pemapper.c:626); anything else -- a pipe, or PEMAP_ZLIB_INFLATE=1 -- goes
@@ -329,6 +330,7 @@ typedef struct
   FILE *f;
   int threads;
   int wrote_any;
+  int level;                    /* zlib's levels; Z_DEFAULT_COMPRESSION unless the caller or PEMAP_GZ_LEVEL says otherwise */
 } pgz;
 
 typedef struct
@@ -340,14 +342,15 @@ typedef struct
   int next;
   pthread_mutex_t mu;
   int failed;
+  int level;
 } pgz_job;
 
 static int
-pgz_member (const char *src, size_t n, unsigned char **out, size_t *out_len)
+pgz_member (const char *src, size_t n, unsigned char **out, size_t *out_len, int level)
 {
   z_stream z;
   memset (&z, 0, sizeof z);
-  if (deflateInit2 (&z, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK)
+  if (deflateInit2 (&z, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK)
     return -1;
   const size_t cap = deflateBound (&z, (uLong) n) + 64;
   unsigned char *o = (unsigned char *) malloc (cap);
@@ -380,7 +383,7 @@ pgz_worker (void *arg)
         return NULL;
       const size_t off = (size_t) k * PGZ_PIECE;
       const size_t n = j->bytes - off < PGZ_PIECE ? j->bytes - off : PGZ_PIECE;
-      if (pgz_member (j->src + off, n, &j->out[k], &j->out_len[k]))
+      if (pgz_member (j->src + off, n, &j->out[k], &j->out_len[k], j->level))
         j->failed = 1;
     }
 }
@@ -391,6 +394,12 @@ pgz_open (pgz * p, const char *path, int threads)
   p->f = fopen (path, "wb");
   p->threads = threads < 1 ? 1 : threads > 64 ? 64 : threads;
   p->wrote_any = 0;
+  p->level = Z_DEFAULT_COMPRESSION;
+  {
+    const char *e = getenv ("PEMAP_GZ_LEVEL");
+    if (e && atoi (e) >= 1 && atoi (e) <= 9)
+      p->level = atoi (e);
+  }
   return p->f ? 0 : -1;
 }
 
@@ -405,6 +414,7 @@ pgz_write (pgz * p, const void *buf, size_t bytes)
   j.src = (const char *) buf;
   j.bytes = bytes;
   j.n_pieces = (bytes + PGZ_PIECE - 1) / PGZ_PIECE;
+  j.level = p->level;
   j.out = (unsigned char **) calloc (j.n_pieces, sizeof (unsigned char *));
   j.out_len = (size_t *) calloc (j.n_pieces, sizeof (size_t));
   pthread_mutex_init (&j.mu, NULL);
@@ -442,7 +452,7 @@ pgz_close (pgz * p)
       /* an empty gz stream, as gzopen + gzclose leave behind */
       unsigned char *o = NULL;
       size_t n = 0;
-      if (pgz_member ("", 0, &o, &n) || fwrite (o, 1, n, p->f) != n)
+      if (pgz_member ("", 0, &o, &n, p->level) || fwrite (o, 1, n, p->f) != n)
         rc = -1;
       free (o);
     }

@@ -39,7 +39,7 @@
 /* columns per device call, and genome positions per range of the stream merge.  A call has a fixed part (two kernel launches, the
    transfers' latencies), so tiles are large; PECALLER_TILE_LOG2 (10..22) overrides the exponent (tests: several ranges on a small
    fixture) */
-static size_t TILE = (size_t) 1 << 21;
+static size_t TILE = (size_t) 1 << 20;
 
 static void
 die (const char *fmt, const char *arg)
@@ -348,28 +348,50 @@ merge_streams (void *arg)
             advance_nr (s);
           s->base_count += (unsigned int) (c->p1 - c->p0);
         }
+      /* The records of the range.  The pending one first (s->cur / s->data); then straight out of the inflater's block as long as whole
+         records lie in it -- 64 of these loops are the merge's time: one load of the position, the six counters copied as 8 + 4
+         bytes, their sum for the stream's statistics.  (The coverage total is a sum of integers: it is kept in an integer and added
+         to the double once per range; every partial sum is far below 2^53, so the double is the same.) */
+      unsigned long long cov_sum = 0;
+      unsigned int cov_max = s->max_coverage;
+      unsigned int n_rec = 0;
+      zreader *z = &s->f;
       while (s->cur != 0 && (unsigned long long) s->cur < c->p1)
         {
-          if ((unsigned long long) s->cur < (unsigned long long) c->p0 + done)
-            die ("\n pecaller_hip: the records of %s are not in ascending order", s->name);
-          const size_t slot = (size_t) (s->cur - c->p0);
-          memset (plane + done * NA, 0, (slot - done) * NA * sizeof (uint16_t));
-          unsigned int cov = 0;
-          for (int a = 0; a < NA; a++)
+          unsigned int pos = s->cur;
+          const char *rec = NULL;       /* NULL: the counters are in s->data */
+          for (;;)
             {
-              plane[slot * NA + a] = s->data[a];
-              cov += s->data[a];
+              if ((unsigned long long) pos < (unsigned long long) c->p0 + done)
+                die ("\n pecaller_hip: the records of %s are not in ascending order", s->name);
+              const size_t slot = (size_t) (pos - c->p0);
+              if (slot != done)
+                memset (plane + done * NA, 0, (slot - done) * NA * sizeof (uint16_t));
+              uint16_t *dst = plane + slot * NA;
+              memcpy (dst, rec ? (const void *) (rec + 4) : (const void *) s->data, NA * sizeof (uint16_t));
+              const unsigned int cov = (unsigned int) dst[0] + dst[1] + dst[2] + dst[3] + dst[4] + dst[5];
+              cov_sum += cov;
+              if (cov > cov_max)
+                cov_max = cov;
+              s->counts[cov < MAX_DIST - 1 ? cov : MAX_DIST - 1]++;
+              n_rec++;
+              mark[slot] = 1;
+              done = slot + 1;
+              /* the next record, if it lies whole in the block at hand and belongs to the range */
+              if (z->pos + 16 > z->cur_len)
+                break;
+              rec = z->ring[z->head] + z->pos;
+              memcpy (&pos, rec, sizeof pos);
+              if (pos == 0 || (unsigned long long) pos >= c->p1)
+                break;          /* (left where it is: advance_nr below reads it as the pending record) */
+              z->pos += 16;
             }
-          s->mean += (double) cov;
-          if (cov > s->max_coverage)
-            s->max_coverage = cov;
-          s->counts[cov < MAX_DIST - 1 ? cov : MAX_DIST - 1]++;
-          if (!c->guide)
-            s->base_count++;
-          mark[slot] = 1;
-          done = slot + 1;
           advance_nr (s);
         }
+      s->mean += (double) cov_sum;
+      s->max_coverage = cov_max;
+      if (!c->guide)
+        s->base_count += n_rec;
       memset (plane + done * NA, 0, ((size_t) TILE - done) * NA * sizeof (uint16_t));
     }
   return NULL;
@@ -438,15 +460,48 @@ run_threads (void *(*fn) (void *), merge_ctx * ctx, int T)
     pthread_join (th[k], NULL);
 }
 
-/* ---- the device call and the text of a tile run on a thread of their own while the main thread merges the next tile (two sets of
-        tile arrays change hands) */
+/* ---- the device call of a tile and its text run on a thread each while the main thread merges the next tile: three sets of tile
+        arrays go round (merge -> device -> rows -> free) */
+#define N_TILES 3
 typedef struct
+{
+  pthread_mutex_t mu;
+  pthread_cond_t cv;
+  tile_t free_tile[N_TILES];
+  int n_free;
+} tile_pool;
+
+static void
+pool_put (tile_pool * p, tile_t t)
+{
+  pthread_mutex_lock (&p->mu);
+  p->free_tile[p->n_free++] = t;
+  pthread_cond_broadcast (&p->cv);
+  pthread_mutex_unlock (&p->mu);
+}
+
+static tile_t
+pool_get (tile_pool * p)
+{
+  pthread_mutex_lock (&p->mu);
+  while (p->n_free == 0)
+    pthread_cond_wait (&p->cv, &p->mu);
+  tile_t t = p->free_tile[--p->n_free];
+  pthread_mutex_unlock (&p->mu);
+  t.n = 0;
+  return t;
+}
+
+typedef struct consumer_s
 {
   pthread_t th;
   pthread_mutex_t mu;
   pthread_cond_t cv;
   int has_job, busy, stop;
   tile_t job;
+  int role;                     /* 0: the device call, then on to `next`; 1: the rows, then back to the pool */
+  struct consumer_s *next;
+  tile_pool *pool;
   /* what the work needs */
   pecall_dev *pc;
   int indiv, haploid, threads;
@@ -460,6 +515,20 @@ typedef struct
   double sec_dev, sec_text;
   long tot_cols;
 } consumer_t;
+
+static void consumer_wait_idle (consumer_t * c);
+
+/* hand a tile to a stage (waits until the stage has given its previous one away) */
+static void
+consumer_give (consumer_t * c, tile_t t)
+{
+  consumer_wait_idle (c);
+  pthread_mutex_lock (&c->mu);
+  c->job = t;
+  c->has_job = 1;
+  pthread_cond_broadcast (&c->cv);
+  pthread_mutex_unlock (&c->mu);
+}
 
 static void *
 consumer_main (void *arg)
@@ -479,20 +548,28 @@ consumer_main (void *arg)
       c->busy = 1;
       pthread_mutex_unlock (&c->mu);
       tile_t *t = &c->job;
-      struct timespec a, b, d;
+      struct timespec a, b;
       clock_gettime (CLOCK_MONOTONIC, &a);
-      if (pecall_dev_call_sites (c->pc, t->reads, t->ref_base, t->chrom, t->n, c->indiv, c->haploid, c->threshold, c->theta, t->call, t->post, t->type, t->ac,
-                                 NULL, t->denovo))
-        die ("\n pecaller_hip: %s", pecall_dev_last_error (c->pc));
-      clock_gettime (CLOCK_MONOTONIC, &b);
-      emit_tile (t, c->indiv, c->contig_names, c->threads, c->ob, c->snpfile, c->pilefile);
-      if (pgz_write (c->outfile, c->ob->p, c->ob->n))
-        die ("\n pecaller_hip: write to %s.base.gz failed", c->outname);
-      c->ob->n = 0;
-      clock_gettime (CLOCK_MONOTONIC, &d);
-      c->sec_dev += (double) (b.tv_sec - a.tv_sec) + 1e-9 * (double) (b.tv_nsec - a.tv_nsec);
-      c->sec_text += (double) (d.tv_sec - b.tv_sec) + 1e-9 * (double) (d.tv_nsec - b.tv_nsec);
-      c->tot_cols += t->n;
+      if (c->role == 0)
+        {
+          if (pecall_dev_call_sites (c->pc, t->reads, t->ref_base, t->chrom, t->n, c->indiv, c->haploid, c->threshold, c->theta, t->call, t->post, t->type,
+                                     t->ac, NULL, t->denovo))
+            die ("\n pecaller_hip: %s", pecall_dev_last_error (c->pc));
+          clock_gettime (CLOCK_MONOTONIC, &b);
+          c->sec_dev += (double) (b.tv_sec - a.tv_sec) + 1e-9 * (double) (b.tv_nsec - a.tv_nsec);
+          consumer_give (c->next, *t);
+        }
+      else
+        {
+          emit_tile (t, c->indiv, c->contig_names, c->threads, c->ob, c->snpfile, c->pilefile);
+          if (pgz_write (c->outfile, c->ob->p, c->ob->n))
+            die ("\n pecaller_hip: write to %s.base.gz failed", c->outname);
+          c->ob->n = 0;
+          clock_gettime (CLOCK_MONOTONIC, &b);
+          c->sec_text += (double) (b.tv_sec - a.tv_sec) + 1e-9 * (double) (b.tv_nsec - a.tv_nsec);
+          c->tot_cols += t->n;
+          pool_put (c->pool, *t);
+        }
       pthread_mutex_lock (&c->mu);
       c->busy = 0;
       pthread_cond_broadcast (&c->cv);
@@ -607,7 +684,12 @@ main (int argc, char *argv[])
   sbuf ob = { NULL, 0, 0 };
   FILE *snpfile, *distfile;
   sprintf (ss, "%s.base.gz", argv[4]);
-  if (pgz_open (&outfile, ss, no_threads > 32 ? 32 : no_threads))
+  const int pgz_rc = pgz_open (&outfile, ss, no_threads > 32 ? 32 : no_threads);
+  /* the rows are ~280 bytes of text per column and 64 samples: at zlib's default level their deflate is the largest single item of the
+     run's CPU time (12 of ~30 core-seconds per 8 M columns); level 2 takes half of that for a file 1.4 times the size */
+  if (!getenv ("PEMAP_GZ_LEVEL"))
+    outfile.level = 2;
+  if (pgz_rc)
     die ("\n Can not open file %s", ss);
   sprintf (ss, "%s.snp", argv[4]);
   if (!(snpfile = fopen (ss, "w")))
@@ -798,9 +880,9 @@ main (int argc, char *argv[])
       TILE = (size_t) 1 << atoi (tl);
     else
       {
-        /* the host arrays hold ~45 bytes per (column, sample) -- the merge's planes, two tiles of reads, calls and posteriors: 2^21
-           columns are 6 GB with 64 samples; with more samples the tile shrinks so that columns x samples stays at that product */
-        while (TILE > ((size_t) 1 << 16) && TILE * (size_t) no_files > ((size_t) 1 << 27))
+        /* the host arrays hold ~57 bytes per (column, sample) -- the merge's planes, three tiles of reads, calls and posteriors: 2^20
+           columns are 3.8 GB with 64 samples; with more samples the tile shrinks so that columns x samples stays at that product */
+        while (TILE > ((size_t) 1 << 16) && TILE * (size_t) no_files > ((size_t) 1 << 26))
           TILE >>= 1;
       }
     if (MG_CHUNK > TILE)
@@ -809,14 +891,17 @@ main (int argc, char *argv[])
     if (gr && atol (gr) >= 1)
       GUIDE_RANGE_MIN = (unsigned long long) atol (gr);
   }
-  tile_t t, spare;
-  tile_alloc (&t, indiv);
-  tile_alloc (&spare, indiv);
+  tile_pool pool;
+  memset (&pool, 0, sizeof pool);
+  pthread_mutex_init (&pool.mu, NULL);
+  pthread_cond_init (&pool.cv, NULL);
   /* the tiles are handed to pecall_dev_call_sites again and again: page-locked once, their columns and results move by DMA
      straight from and to them (a refusal only means staged copies) */
-  for (int k = 0; k < 2; k++)
+  for (int k = 0; k < N_TILES; k++)
     {
-      tile_t *tt = k ? &spare : &t;
+      tile_t one;
+      tile_alloc (&one, indiv);
+      tile_t *tt = &one;
       (void) pecall_dev_pin_host (pc, tt->reads, (uint64_t) TILE * indiv * NA * sizeof (uint16_t));
       (void) pecall_dev_pin_host (pc, tt->ref_base, (uint64_t) TILE);
       (void) pecall_dev_pin_host (pc, tt->chrom, (uint64_t) TILE);
@@ -825,7 +910,9 @@ main (int argc, char *argv[])
       (void) pecall_dev_pin_host (pc, tt->type, (uint64_t) TILE);
       (void) pecall_dev_pin_host (pc, tt->ac, (uint64_t) TILE * NA * sizeof (int32_t));
       (void) pecall_dev_pin_host (pc, tt->denovo, (uint64_t) TILE * sizeof (int32_t));
+      pool_put (&pool, one);
     }
+  tile_t t = pool_get (&pool);
   /* the threads of the merge and of the row formatting: the reference's worker threads minus its dispatcher, at most 32 */
   int MT = no_threads - 1;
   {
@@ -868,7 +955,7 @@ main (int argc, char *argv[])
       mc[k].gsize = gsize;
       mc[k].no_contigs = no_contigs;
     }
-  consumer_t cons;
+  consumer_t cons, rows;
   memset (&cons, 0, sizeof cons);
   pthread_mutex_init (&cons.mu, NULL);
   pthread_cond_init (&cons.cv, NULL);
@@ -884,8 +971,15 @@ main (int argc, char *argv[])
   cons.pilefile = pilefile;
   cons.outfile = &outfile;
   cons.outname = argv[4];
-  if (pthread_create (&cons.th, NULL, consumer_main, &cons))
-    die ("\n pecaller_hip: can not start %s", "the device-and-text thread");
+  rows = cons;
+  pthread_mutex_init (&rows.mu, NULL);
+  pthread_cond_init (&rows.cv, NULL);
+  rows.role = 1;
+  rows.pool = &pool;
+  cons.role = 0;
+  cons.next = &rows;
+  if (pthread_create (&rows.th, NULL, consumer_main, &rows) || pthread_create (&cons.th, NULL, consumer_main, &cons))
+    die ("\n pecaller_hip: can not start %s", "the device and the text threads");
   clock_gettime (CLOCK_MONOTONIC, &tc0);
   t.n = 0;
   unsigned int tot_bases = 0;
@@ -1027,32 +1121,27 @@ main (int argc, char *argv[])
         {
           clock_gettime (CLOCK_MONOTONIC, &tc1);
           sec_merge += (double) (tc1.tv_sec - tc0.tv_sec) + 1e-9 * (double) (tc1.tv_nsec - tc0.tv_nsec);
-          /* hand the tile to the device-and-text thread and go on with the other set of arrays (free once that thread is idle) */
-          consumer_wait_idle (&cons);
-          pthread_mutex_lock (&cons.mu);
-          cons.job = t;
-          cons.has_job = 1;
-          pthread_cond_broadcast (&cons.cv);
-          pthread_mutex_unlock (&cons.mu);
-          {
-            const tile_t given = t;
-            t = spare;
-            spare = given;
-          }
+          /* hand the tile to the device thread and go on with a free set of arrays */
+          consumer_give (&cons, t);
+          t = pool_get (&pool);
           t.n = 0;
           clock_gettime (CLOCK_MONOTONIC, &tc0);
           sec_wait += (double) (tc0.tv_sec - tc1.tv_sec) + 1e-9 * (double) (tc0.tv_nsec - tc1.tv_nsec);
         }
     }
-  consumer_wait_idle (&cons);
-  pthread_mutex_lock (&cons.mu);
-  cons.stop = 1;
-  pthread_cond_broadcast (&cons.cv);
-  pthread_mutex_unlock (&cons.mu);
-  pthread_join (cons.th, NULL);
+  for (int st = 0; st < 2; st++)
+    {
+      consumer_t *cc = st ? &rows : &cons;      /* (the device thread has passed its last tile on before it is idle) */
+      consumer_wait_idle (cc);
+      pthread_mutex_lock (&cc->mu);
+      cc->stop = 1;
+      pthread_cond_broadcast (&cc->cv);
+      pthread_mutex_unlock (&cc->mu);
+      pthread_join (cc->th, NULL);
+    }
   sec_dev = cons.sec_dev;
-  sec_text = cons.sec_text;
-  tot_cols = cons.tot_cols;
+  sec_text = rows.sec_text;
+  tot_cols = rows.tot_cols;
 
   /* ---- <outfile>.dist, pecaller.c:1077-1140 */
   unsigned int *tot_1x = (unsigned int *) calloc (no_files, sizeof (unsigned int)), *tot_8x = (unsigned int *) calloc (no_files, sizeof (unsigned int));
