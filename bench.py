@@ -532,6 +532,29 @@ def pmc_traffic(kernel, gsize, B, L, config="hg38_150"):
     return (round(tot * 1024.0), src) if hit else (None, src)
 
 
+def pecall_pmc_traffic(n):
+    """HBM bytes of one resident run of the caller's kernels over the n columns, from profiles/r03_pecall_pmc.json (tools/profile_pecall.sh:
+    separate --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pecall_kernel_time.py, 5 runs each) -- valid while the columns and the device
+    sources are the profiled ones.  The kernels stream their columns (coalesced 768-byte rows in, 600 bytes out): FETCH_SIZE / WRITE_SIZE are
+    taken as rocprofv3 reports them, in KB."""
+    path = os.path.join(ROOT, "profiles", "r03_pecall_pmc.json")
+    try:
+        pm = json.load(open(path))
+    except (OSError, ValueError):
+        return None, None
+    sha = kernel_sources_sha()
+    if pm.get("kernel_sources_sha") != sha:
+        return None, "profiles/r03_pecall_pmc.json is of other kernels (sources %s, now %s): re-run tools/profile_pecall.sh" % (pm.get("kernel_sources_sha"), sha)
+    if pm.get("columns") != n:
+        return None, "profiles/r03_pecall_pmc.json was taken on %s columns" % pm.get("columns")
+    tot = 0.0
+    for cn in ("FETCH_SIZE", "WRITE_SIZE"):
+        for k, v in pm[cn].items():
+            if k.startswith("pcs_"):
+                tot += v["mean_KB_per_launch"] * v["launches"] / pm.get("steps", 5)
+    return round(tot * 1024.0), "profiles/r03_pecall_pmc.json (device sources %s)" % sha
+
+
 def cpu_baseline(dev, a, B, leg, warmup):
     """the oracle (CPU restatement of the reference loop, pthreads) on a bounded sample of the same workload, same index;
     its coordinates and classes are also compared with what the GPU produced for the same reads (checker role)"""
@@ -667,8 +690,9 @@ def pecaller_leg(a):
         calls_eq = calls_eq and bool(np.array_equal(call[s], oc)) and bool(np.array_equal(ac[s], oac))
         types_eq = types_eq and bool(np.array_equal(typ[s], otyp))
     achieved = PECALL_BYTES_PER_SITE * n / (kernel_ms * 1e-3) / 1e9
+    traffic, tsrc = pecall_pmc_traffic(n)
     return {"metric": "M pileup columns called/sec, 64 samples, 30x", "value": round(n / (kernel_ms * 1e-3) / 1e6, 4), "unit": "M columns/s",
-            "timed_region": "pcs_fast_kernel + pcs_call_kernel on columns resident in HBM, in chunks of 2^18 columns on two streams (HIP events around all of them, mean of 3 runs)",
+            "timed_region": "pcs_depth_kernel + pcs_fast_kernel + pcs_call_kernel on columns resident in HBM, in chunks of 2^18 columns, the beam searches of the chunks on four streams beside the next chunks' shortcut kernels (HIP events around all of them, mean of 3 runs)",
             "seam_value": round(n / seam_dt / 1e6, 4), "seam_timed_region": "pecall_dev_call_sites: host columns in, calls + posteriors out (PCIe included; the caller's buffers page-locked once, copies and kernels of neighbouring chunks side by side)",
             "seam_pageable_value": round(n / seam_pageable_dt / 1e6, 4),
             "dtype": "f64", "data": "synthetic", "n_gpus": 1,
@@ -676,7 +700,7 @@ def pecaller_leg(a):
                                    "prob_to_call 0.95, theta 0.001, diploid, no pedigree" % (n, S), "generated_in_s": round(t_gen, 1)},
             "variant_rows": int((typ > 0).sum()), "passes_histogram": np.bincount(npass).tolist(),
             "roofline": {"bound": "hbm", "kernel": "pcs_fast_kernel+pcs_call_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "avg_launch_ms": round(kernel_ms, 3),
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc, "avg_launch_ms": round(kernel_ms, 3),
                          "algorithmic_bytes_per_launch": PECALL_BYTES_PER_SITE * n, "bytes_per_site": PECALL_BYTES_PER_SITE},
             "cpu_baseline": {"value": round(m / cpu_dt / 1e6, 5), "unit": "M columns/s", "cores": nt, "kind": "port",
                              "sample": "%d of the same columns, %d oracle callers on %d threads, %.1f s" % (m, nt, nt, cpu_dt),

@@ -66,15 +66,10 @@ struct PmKnobs
   double dir_budget_gb;
   int lookup_waves /* -1 unset */;
   int lookup_prio, vote_prio, sw_prio;
-  int rest_stream3;
-  int vote_rest_on_alu, vote_waves;
+  int vote_waves;
   int walk_blocks_per_cu, pile_blocks_per_cu;
-  int mem_cus, mem_prio;
-  int pipeline, walk_on_mem, vote_on_mem /* -1 unset */;
-  int vote_stream_prio;
-  bool vote_stream_prio_set;
+  int pipeline;
   int chunk_pairs;
-  int d2h_stream;               // 1: the results of a submitted batch return on a stream of their own instead of the ALU stream
   int gapless_blocks_per_cu;
   int band, band_waves_per_cu;  // the banded DP (pm_band_kernel) for the problems it is exact for; its waves per CU
   int seed_phase;               // always 0 without PEMAP_TIMING_PROBES
@@ -102,23 +97,14 @@ static void read_knobs (PmKnobs & k)
   k.lookup_prio = env_int ("PEMAP_LOOKUP_PRIO", 0);
   k.vote_prio = env_int ("PEMAP_VOTE_PRIO", 0);
   k.sw_prio = env_int ("PEMAP_SW_PRIO", 0);
-  k.vote_rest_on_alu = env_int ("PEMAP_VOTE_REST_ON_ALU", -1);       // -1 unset: 1 with the fused seed kernel, else 0
-  k.rest_stream3 = env_int ("PEMAP_REST_STREAM3", 0);
   k.vote_waves = env_int ("PEMAP_VOTE_WAVES", 1024);
   if (k.vote_waves < 1) k.vote_waves = 1;
   k.walk_blocks_per_cu = env_int ("PEMAP_WALK_BLOCKS_PER_CU", 4);
   k.pile_blocks_per_cu = env_int ("PEMAP_PILE_BLOCKS_PER_CU", 8);
   if (k.walk_blocks_per_cu < 1) k.walk_blocks_per_cu = 1;
   if (k.pile_blocks_per_cu < 1) k.pile_blocks_per_cu = 1;
-  k.mem_cus = env_int ("PEMAP_MEM_CUS", 0);
-  k.mem_prio = env_int ("PEMAP_MEM_PRIO", 0);
   k.pipeline = env_int ("PEMAP_PIPELINE", 1);
-  k.walk_on_mem = env_int ("PEMAP_WALK_ON_MEM_STREAM", 0);
-  k.vote_on_mem = env_int ("PEMAP_VOTE_ON_MEM", -1);
-  k.vote_stream_prio_set = getenv ("PEMAP_VOTE_STREAM_PRIO") != nullptr;
-  k.vote_stream_prio = env_int ("PEMAP_VOTE_STREAM_PRIO", 0);
   k.chunk_pairs = env_int ("PEMAP_CHUNK_PAIRS", 262144);
-  k.d2h_stream = env_int ("PEMAP_D2H_STREAM", 0);
   k.band = env_int ("PEMAP_BAND", 1);
   k.gapless_blocks_per_cu = env_int ("PEMAP_GAPLESS_BLOCKS_PER_CU", 24);     // one-wave workgroups of pm_gapless_kernel launched per CU at most
   if (k.gapless_blocks_per_cu < 1) k.gapless_blocks_per_cu = 1;
@@ -186,7 +172,7 @@ struct pemap_dev
   // run bookkeeping
   int run_first, run_n;
   bool run_pending;             // kernels of the last run still in flight / not yet accounted
-  bool run_split, serial_split, walk_on_mem;
+  bool run_split, serial_split;
   int run_chunks, run_chunk_pairs, run_L;
   uint64_t run_ends;
   hipEvent_t ev[7];
@@ -216,8 +202,7 @@ struct pemap_dev
   PmRingSlot ring[PM_RING];
   int ring_cap;                 // rows per slot, 0 = the ring is not set up (the staged arrays hold a resident read set)
   unsigned long long ring_seq;
-  hipStream_t stream_h2d, stream_d2h;
-  hipEvent_t ev_batch_alu;
+  hipStream_t stream_h2d;
   float last_ms[8];
   std::vector < uint8_t > h_ins;        // host copy of all insertion-log bytes so far
   long summary[13];
@@ -326,8 +311,7 @@ extern "C" int pemap_dev_create (pemap_dev ** out, int device_id)
   d->last_big = 0;
   d->ring_cap = 0;
   d->ring_seq = 0;
-  d->stream_h2d = d->stream_d2h = nullptr;
-  d->ev_batch_alu = nullptr;
+  d->stream_h2d = nullptr;
   for (int i = 0; i < PM_RING; i++)
     {
       d->ring[i].active = false;
@@ -482,11 +466,6 @@ extern "C" void pemap_dev_destroy (pemap_dev * d)
   if (d->stream_h2d)
     {
       hipStreamDestroy (d->stream_h2d);
-      if (d->stream_d2h)
-        {
-          hipStreamDestroy (d->stream_d2h);
-          hipEventDestroy (d->ev_batch_alu);
-        }
     }
   for (int i = 0; i < 7; i++)
     hipEventDestroy (d->ev[i]);
@@ -1131,9 +1110,10 @@ static void launch_lookup (pemap_dev * d, const RunCtx & c, int slot, PmChunkCtr
   // kernel makes the stamp the moment the look-up kernel can start, so that ev[0]..ev[1] is the kernel's own duration)
   hipLaunchKernelGGL (pm_nop_kernel, dim3 (1), dim3 (1), 0, st);
   hipEventRecord (ev[0], st);
-  // PEMAP_LOOKUP_WAVES=n: n persistent one-wave workgroups per CU.  Default 6 (the fused kernel alone is fastest with the 8 its LDS
-  // admits, the step with 6: what the seed waves gain beyond that the other stream's kernels lose)
-  const int lw = d->kn.lookup_waves > 0 ? d->kn.lookup_waves : 6;
+  // PEMAP_LOOKUP_WAVES=n: n persistent one-wave workgroups per CU.  Default 7 of the 8 the fused kernel's LDS admits.  With the other
+  // stream's kernels in one-wave workgroups (round 3) the step follows the seed kernel: 12 steps of the default workload take
+  // 26.4 / 25.1 / 25.0 ms each on resident reads with 6 / 7 / 8, 27.8 / 27.4 / 27.9 at the seam (profiles/r03_ab_sweeps.txt)
+  const int lw = d->kn.lookup_waves > 0 ? d->kn.lookup_waves : 7;
   int lgrid = lw * d->n_cus;
   if (lgrid > c.b.n_ends)
     lgrid = c.b.n_ends;
@@ -1326,15 +1306,9 @@ template < int W, int LPA > static void launch_chunk (pemap_dev * d, const RunCt
   int wgrid = (n_ends + 63) / 64;
   if (wgrid > d->n_cus * wbp * 4)
     wgrid = d->n_cus * wbp * 4;         // (waves: the knob counts blocks of four)
-  // the walk (dependent-load latency) goes to the memory stream in the split pipeline: it runs beside the next chunk's vote/SW
-  // (measured on MI355X: 107 ms per step against 103 ms with the walk left on the ALU stream, so it is opt-in: PEMAP_WALK_ON_MEM_STREAM=1)
-  hipStream_t ws = (split && !d->serial_split && d->walk_on_mem) ? d->stream2 : d->stream;
-  if (ws != d->stream)
-    {
-      hipEventRecord (d->ev_alu_done[slot], d->stream);
-      hipStreamWaitEvent (ws, d->ev_alu_done[slot], 0);
-      hipEventRecord (ev[7], ws);
-    }
+  // (the walk on the look-up stream, beside the next chunk's vote and SW, was tried: 107 ms per step against 103; it stays on the ALU
+  // stream)
+  hipStream_t ws = d->stream;
   unsigned long long *path = set2 ? d->d_path2 : d->d_path;
   uint16_t *nsteps = set2 ? d->d_nsteps2 : d->d_nsteps;
   hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_walk_kernel < W, LPA >), dim3 (wgrid), dim3 (64), 0, ws, c.b, H, wins, ctr, d->d_cur,
@@ -1432,25 +1406,8 @@ static int ensure_pipeline (pemap_dev * d, int chunk_ends)
 {
   if (!d->stream2)
     {
-      // PEMAP_MEM_CUS=n: the look-up stream only runs on n CUs of every XCD (CU-mask bit i is CU i/8 of XCD i%8)
-      const int ncu = d->kn.mem_cus;
-      if (ncu > 0 && ncu < 32)
-        {
-          uint32_t mask[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-          for (int i = 0; i < ncu * 8; i++)
-            mask[i >> 5] |= 1u << (i & 31);
-          HIPCHK (d, hipExtStreamCreateWithCUMask (&d->stream2, 8, mask));
-        }
-      else
-        {
-          // PEMAP_MEM_PRIO=1 / -1: look-up stream at the highest / lowest priority the device offers (experiment)
-          int lo = 0, hi = 0;
-          hipDeviceGetStreamPriorityRange (&lo, &hi);     // lo = least (numerically largest), hi = greatest
-          if (d->kn.mem_prio != 0)
-            HIPCHK (d, hipStreamCreateWithPriority (&d->stream2, hipStreamNonBlocking, d->kn.mem_prio > 0 ? hi : lo));
-          else
-            HIPCHK (d, hipStreamCreateWithFlags (&d->stream2, hipStreamNonBlocking));
-        }
+      // (a CU mask and stream priorities for the look-up stream were tried in rounds 1 and 2 and gave nothing)
+      HIPCHK (d, hipStreamCreateWithFlags (&d->stream2, hipStreamNonBlocking));
       for (int i = 0; i < 2; i++)
         {
           HIPCHK (d, hipEventCreateWithFlags (&d->ev_lists_ready[i], hipEventDisableTiming));
@@ -1537,28 +1494,21 @@ static int run_slice (pemap_dev * d, int first, int n, int sync, const hipEvent_
   // 0 monolithic seed kernel, one stream; 2 split kernels on one stream (diagnostic).
   const bool split = d->kn.pipeline != 0 && !d->kn.seed_phase;
   d->serial_split = d->kn.pipeline == 2;
-  // PEMAP_VOTE_REST_ON_ALU unset: with the fused seed kernel the big read-ends' remainder and the emit kernel run on the ALU stream for
+  // With the fused seed kernel the big read-ends' remainder and the emit kernel run on the ALU stream for
   // reads of up to 160 bases (where the seed kernel is the longer side: 29.8 ms per step against 31.4), behind the seed kernel for
   // longer ones (2 x 245: 56.9 ms against 58.6)
-  d->rest_on_alu = d->kn.vote_rest_on_alu >= 0 ? d->kn.vote_rest_on_alu != 0 : (pm_fused (d) && seg_template (L) <= 10);
-  d->walk_on_mem = d->kn.walk_on_mem != 0;
-  // PEMAP_VOTE_ON_MEM=1: the vote runs behind its look-ups on the memory stream, beside the SW / walk of the previous chunk
-  // PEMAP_VOTE_ON_MEM=1: the vote runs behind its look-ups on the memory stream; 2: on a third stream of its own, beside
-  // the SW / walk of the previous chunk and the look-ups of the next
-  // Default: 2 with the look-up replicas (measured 41.5 ms per step against 44.7 with the vote on the ALU stream: with the
+  d->rest_on_alu = pm_fused (d) && seg_template (L) <= 10;
+  // Where the vote runs -- 1: behind its look-ups on the memory stream (the fused kernel's remainder); 2: on a third stream of its own,
+  // beside the SW / walk of the previous chunk and the look-ups of the next; 0: on the ALU stream.
+  // 2 with the look-up replicas (measured 41.5 ms per step against 44.7 with the vote on the ALU stream: with the
   // cheap look-ups and the gapless rule no stream is saturated any more, and the vote of chunk k+1 fills the gaps), 0 without
   // (it was slower beside the look-ups of the reference's layout).
-  { const int vm = (split && pm_fused (d)) ? 1 : d->kn.vote_on_mem >= 0 ? d->kn.vote_on_mem : (d->n_rep == 8 ? 2 : 0);
+  { const int vm = (split && pm_fused (d)) ? 1 : (d->n_rep == 8 ? 2 : 0);
     d->vote_on_mem = split && !d->serial_split && vm != 0;
     d->vote_stream = (d->vote_on_mem && vm == 2) ? 3 : 2; }
-  const bool rest3 = split && pm_fused (d) && !d->serial_split && d->kn.rest_stream3 != 0;
-  if (((d->vote_on_mem && d->vote_stream == 3) || rest3) && !d->stream3)
+  if (d->vote_on_mem && d->vote_stream == 3 && !d->stream3)
     {
-      // PEMAP_VOTE_STREAM_PRIO: queue priority of the vote's stream (-1 high, 0 normal, 1 low)
-      if (d->kn.vote_stream_prio_set)
-        HIPCHK (d, hipStreamCreateWithPriority (&d->stream3, hipStreamNonBlocking, d->kn.vote_stream_prio));
-      else
-        HIPCHK (d, hipStreamCreateWithFlags (&d->stream3, hipStreamNonBlocking));
+      HIPCHK (d, hipStreamCreateWithFlags (&d->stream3, hipStreamNonBlocking));
       for (int i = 0; i < 2; i++)
         HIPCHK (d, hipEventCreateWithFlags (&d->ev_lookup_done[i], hipEventDisableTiming));
     }
@@ -1654,16 +1604,6 @@ static int run_slice (pemap_dev * d, int first, int n, int sync, const hipEvent_
         if (g >= 2 && !d->serial_split)
           HIPCHK (d, hipStreamWaitEvent (fs, d->ev_walk_done[slot], 0));
         launch_lookup (d, cl, slot, d->d_chunk_ctr + g, &d->evs[(size_t) g * PM_NEV], true);
-        if (rest3)
-          {
-            // PEMAP_REST_STREAM3=1: the big read-ends' remainder and the emit kernel on a stream of their own, so that the next
-            // chunk's fused kernel follows this one without them in between
-            HIPCHK (d, hipEventRecord (d->ev_lookup_done[slot], fs));
-            HIPCHK (d, hipStreamWaitEvent (d->stream3, d->ev_lookup_done[slot], 0));
-            launch_vote (d, cl, true, slot, d->d_chunk_ctr + g, &d->evs[(size_t) g * PM_NEV], d->stream3, 2);
-            HIPCHK (d, hipEventRecord (d->ev_lists_ready[slot], d->stream3));
-            return 0;
-          }
         if (!(pm_vote_rest_on_alu (d) && !d->serial_split))
           launch_vote (d, cl, true, slot, d->d_chunk_ctr + g, &d->evs[(size_t) g * PM_NEV], fs, 2);
         HIPCHK (d, hipEventRecord (d->ev_lists_ready[slot], fs));
@@ -1706,9 +1646,6 @@ static int run_slice (pemap_dev * d, int first, int n, int sync, const hipEvent_
           if (d->serial_split)
             TRY (enqueue_lookup (k));
           HIPCHK (d, hipStreamWaitEvent (d->stream, d->ev_lists_ready[slot], 0));
-          // this chunk's vote overwrites the array set that walk(k-2) reads
-          if (g >= 2 && !d->serial_split && d->walk_on_mem)
-            HIPCHK (d, hipStreamWaitEvent (d->stream, d->ev_walk_done[slot], 0));
         }
       uint32_t *m1 = d->d_m1 + f, *m2 = d->paired ? d->d_m2 + f : nullptr;
       int *mt = d->d_mtype + f;
@@ -2164,17 +2101,6 @@ extern "C" int pemap_dev_submit_batch (pemap_dev * d, const char *reads1, const 
   // Not on a stream of their own: HIP multiplexes streams onto a few hardware queues, and a copy stream parked on "batch k is
   // done" held up whichever pipeline stream shared its queue -- 3.5 ms per batch (measured: 45.2 ms per step against 41.7).
   hipStream_t rs = d->stream;
-  if (d->kn.d2h_stream)
-    {
-      if (!d->stream_d2h)
-        {
-          HIPCHK (d, hipStreamCreateWithFlags (&d->stream_d2h, hipStreamNonBlocking));
-          HIPCHK (d, hipEventCreateWithFlags (&d->ev_batch_alu, hipEventDisableTiming));
-        }
-      rs = d->stream_d2h;
-      HIPCHK (d, hipEventRecord (d->ev_batch_alu, d->stream));
-      HIPCHK (d, hipStreamWaitEvent (rs, d->ev_batch_alu, 0));
-    }
   HIPCHK (d, hipMemcpyAsync (r.h_res, d->d_m1 + first, (size_t) n * 4, hipMemcpyDeviceToHost, rs));
   if (d->paired)
     HIPCHK (d, hipMemcpyAsync (r.h_res + d->ring_cap, d->d_m2 + first, (size_t) n * 4, hipMemcpyDeviceToHost, rs));

@@ -437,3 +437,46 @@ print("full dp ok")
         env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.dirname(here), here]), **extra)
         r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
         assert r.returncode == 0 and b"full dp ok" in r.stdout, (extra, r.stdout[-2000:])
+
+
+@pytest.mark.gpu
+def test_scheduling_knobs_do_not_change_results():
+    """every environment knob that is left (grids, wave priorities, the chunking) gives the reference's coordinates
+    and pileup on the golden read sets: they are schedules, not algorithms.  One process per setting (the knobs are read once, when
+    the library is loaded).  (Round 3 removed the knobs that moved kernels between streams: the first run of this test found one of
+    them, unused since round 1, faulting.)"""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import os, numpy as np, fixtures
+from pecaller_amd import PemapDev
+ix = fixtures.index()
+dev = PemapDev(0)
+dev.build_index(ix["genome"], ix["contig_len"])
+for name in ("r150", "r250"):
+    s = fixtures.SETS[name]
+    r1, l1, r2, l2 = fixtures.reads(name)
+    dev.set_params(paired=s["paired"], min_dist=0, max_dist=500, min_align=0.85)
+    dev.reset_pileup()
+    m1, m2, mt = dev.map_batch(r1, l1, r2, l2)
+    assert np.array_equal(m1, fixtures.golden_m(name, 1))
+    if s["paired"]:
+        assert np.array_equal(m2, fixtures.golden_m(name, 2))
+    counts, ins = dev.fetch_pileup()
+    fixtures.check_pileup_against_golden(name, counts)
+dev.close()
+print("knob ok")
+'''
+    here = os.path.dirname(os.path.abspath(__file__))
+    settings = [
+        dict(PEMAP_CHUNK_PAIRS="4096"), dict(PEMAP_LOOKUP_WAVES="3", PEMAP_LOOKUP_PRIO="2"),
+        dict(PEMAP_SW_PRIO="1", PEMAP_VOTE_PRIO="1", PEMAP_SW_WAVES_PER_CU="3", PEMAP_BAND_WAVES_PER_CU="2", PEMAP_GAPLESS_BLOCKS_PER_CU="3"),
+        dict(PEMAP_WALK_BLOCKS_PER_CU="1", PEMAP_PILE_BLOCKS_PER_CU="1"),
+        # the table layout of the reference (no replicas): the two-kernel seed stage, its vote on few waves
+        dict(PEMAP_REPLICAS="0", PEMAP_VOTE_WAVES="64", PEMAP_SEED_BLOCKS_PER_CU="2", PEMAP_BIG_BLOCKS_PER_CU="2"),
+    ]
+    for extra in settings:
+        env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.dirname(here), here]), **extra)
+        r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert r.returncode == 0 and b"knob ok" in r.stdout, (extra, r.stdout[-2000:])
