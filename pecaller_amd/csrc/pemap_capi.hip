@@ -106,8 +106,8 @@ static void read_knobs (PmKnobs & k)
   k.pipeline = env_int ("PEMAP_PIPELINE", 1);
   k.chunk_pairs = env_int ("PEMAP_CHUNK_PAIRS", 262144);
   k.band = env_int ("PEMAP_BAND", 1);
-  k.gapless_blocks_per_cu = env_int ("PEMAP_GAPLESS_BLOCKS_PER_CU", 24);     // one-wave workgroups of pm_gapless_kernel launched per CU at most
-  if (k.gapless_blocks_per_cu < 1) k.gapless_blocks_per_cu = 1;
+  k.gapless_blocks_per_cu = env_int ("PEMAP_GAPLESS_BLOCKS_PER_CU", -1);     // one-wave workgroups of pm_gapless_kernel launched per CU at most; -1: by read length
+  if (k.gapless_blocks_per_cu == 0) k.gapless_blocks_per_cu = 1;
   k.band_waves_per_cu = env_int ("PEMAP_BAND_WAVES_PER_CU", 16);
   if (k.band_waves_per_cu < 1) k.band_waves_per_cu = 1;
   k.seed_phase = 0;
@@ -1254,8 +1254,15 @@ template < int W, int LPA > static void launch_chunk (pemap_dev * d, const RunCt
       uint32_t *tasks_dp = tasks_s + d->cap_ends;
       uint32_t *tasks_band = d->kn.band ? tasks_s + 2 * (size_t) d->cap_ends : nullptr;
       int ggrid = (n_ends + PM_GL_PER_BLOCK - 1) / PM_GL_PER_BLOCK;
-      if (ggrid > d->n_cus * d->kn.gapless_blocks_per_cu)
-        ggrid = d->n_cus * d->kn.gapless_blocks_per_cu;
+      // The rule's kernel and the NEXT chunk's seed kernel are launched at the same moment (both wait for this chunk's seed kernel), and
+      // whichever gets its waves onto the SIMDs first keeps them: the seed kernel's persistent waves need 168 registers each, six of
+      // this kernel's fill a SIMD's 512.  For reads of up to 160 bases 24 workgroups per CU are the measured optimum (the seed
+      // kernel's launch is short of its 7 waves per CU for 0.4 ms at most); for longer reads the seed kernel's launches are twice
+      // as long, its waves came up late on many CUs, and the step was 69 ms with 12 or more against 54 with 6 (2 x 245 bases:
+      // profiles/r03_ab_sweeps.txt; round 2's 256-thread workgroups had hidden this: they rarely found room at all)
+      const int gbp = d->kn.gapless_blocks_per_cu > 0 ? d->kn.gapless_blocks_per_cu : (seg_template (c.L) <= 10 ? 24 : 6);
+      if (ggrid > d->n_cus * gbp)
+        ggrid = d->n_cus * gbp;
       hipLaunchKernelGGL (pm_gapless_kernel, dim3 (ggrid), dim3 (PM_GL_BLOCK), 0, d->stream, c.ix, c.b, c.prm, H, tasks_s, &ctr->n_tasks_s, tasks_dp,
                           &ctr->n_tasks_dp, pm_gapless_max_x (d), tasks_band, &ctr->n_band[0]);
       if (tasks_band)

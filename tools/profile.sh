@@ -10,7 +10,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--config $CFG --no-cpu --no-secondary --no-pecaller"
+ARGS="--config $CFG --no-cpu --no-secondary --no-pecaller --realistic-steps 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --steps 4 --warmup 1 $ARGS > $OUT/stats.log 2>&1
 echo "stats pass done"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $ROOT/bench.py --steps 2 --warmup 1 $ARGS > $OUT/fetch.log 2>&1
