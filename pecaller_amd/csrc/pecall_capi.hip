@@ -12,8 +12,7 @@
 
 static char g_pc_err[512] = "";
 #define PCS_SLOTS 3             // staging buffers of the seam's pipeline (chunks in flight between the two host copies)
-#define PCS_CALL_STREAMS_MAX 8
-#define PCS_CALL_STREAMS (d->n_call_streams)  // streams the beam searches of consecutive chunks alternate on (each with its share of the waves and of the scratch)
+#define PCS_CALL_STREAMS 4       // streams the beam searches of consecutive chunks alternate on (each with a quarter of the waves and of the scratch)
 
 // host ranges page-locked by the caller (one table for the library: pemap_capi.hip)
 bool pm_host_pin_lookup (const void *p, size_t bytes);
@@ -63,8 +62,7 @@ struct pecall_dev
   // the caller in chunks of columns (pcs_run_chunk): the shortcut kernel of chunk k + 1 runs beside the beam search of chunk k, and at
   // the seam (pecall_dev_call_sites) beside the copies of the chunks around them
   long chunk_sites;
-  hipStream_t stream_call[PCS_CALL_STREAMS_MAX], stream_h2d, stream_d2h;
-  int n_call_streams;
+  hipStream_t stream_call[PCS_CALL_STREAMS], stream_h2d, stream_d2h;
   hipEvent_t *ev_h2d, *ev_fast, *ev_call, *ev_d2h;      // [cap_chunks]
   char *h_in[PCS_SLOTS], *h_out[PCS_SLOTS];            // pinned staging for callers whose buffers are not pinned
   size_t h_in_bytes, h_out_bytes;
@@ -133,10 +131,6 @@ extern "C" int pecall_dev_create (pecall_dev ** out, int device_id)
       return pc_fail (nullptr, "device %d is %s: built for gfx950 only", device_id, prop.gcnArchName);
     }
   d->grid = (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256) * 2;
-  {
-    const char *e = getenv ("PECALL_CALL_STREAMS");
-    d->n_call_streams = (e && atoi (e) >= 1 && atoi (e) <= PCS_CALL_STREAMS_MAX) ? atoi (e) : 4;
-  }
   PCCHK (nullptr, hipStreamCreateWithFlags (&d->stream, hipStreamNonBlocking));
   double *tab = (double *) malloc (sizeof (double) * PC_TABLE);
   for (int i = 0; i < PC_TABLE; i++)
