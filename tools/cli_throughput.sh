@@ -34,5 +34,25 @@ T1=$(date +%s.%N)
 grep "files by" log_arr.txt
 python3 -c "
 import os; n=sum(os.path.getsize('part%d_1_.fastq.gz.mfile' % f)//4 for f in range(1,9)); w=$T1-$T0; print('array mode, 8 gz file pairs: pairs', n, 'wall %.2f s' % w, '= %.2f M reads/s end to end' % (2*n/w/1e6))"
+# ---- the same array-mode run on reads whose quality lines have the entropy of real ones (the fixture's are one letter repeated, which
+#      inflates three times as fast per byte): same reads, same mapping, 2.3:1 instead of 6:1 compression
+python3 - <<PY
+import gzip, numpy as np
+rng = np.random.default_rng(5)
+for k in (1, 2):
+    lines = gzip.open("$ROOT/tests/golden/g1_%d_.fastq.gz" % k, "rb").read().split(b"\n")
+    for i in range(3, len(lines), 4):
+        n = len(lines[i])
+        q = np.clip(rng.normal(36, 4, n).astype(int), 2, 40)
+        q[rng.random(n) < 0.05] = rng.integers(2, 20)
+        lines[i] = (q + 33).astype(np.uint8).tobytes()
+    open("q_%d_.fastq.gz" % k, "wb").write(gzip.compress(b"\n".join(lines), 6))
+PY
+rm -f a1.txt a2.txt
+for f in $(seq 8); do for k in 1 2; do for i in $(seq $M); do cat q_${k}_.fastq.gz; done > qpart${f}_${k}_.fastq.gz; done; echo $W/qpart${f}_1_.fastq.gz >> a1.txt; echo $W/qpart${f}_2_.fastq.gz >> a2.txt; done
+ls -la qpart1_1_.fastq.gz | awk '{print "bytes per mate file, qualities of high entropy:", $5}'
+$ROOT/pecaller_amd/pemapper_hip out_q g1.sdx pa a1.txt a2.txt 500 0 N 0.85 24 2000000000 > log_q.txt 2>&1 || { tail -3 log_q.txt; exit 1; }
+grep "files by" log_q.txt
+cmp out_q.pileup.gz out_arr.pileup.gz > /dev/null 2>&1 && echo "pileup of the run with the other quality lines: identical bytes"
 cmp out_big.pileup.gz out_plain.pileup.gz > /dev/null 2>&1 && echo "pileups of the two runs: identical bytes" || { gzip -dc out_big.pileup.gz | md5sum; gzip -dc out_plain.pileup.gz | md5sum; }
 cd /; rm -rf $W
