@@ -54,7 +54,8 @@ gzsrc_open (gzsrc * g, const char *path, size_t block, int ring)
 {
   memset (g, 0, sizeof *g);
   g->fd = -1;
-  g->block = block;
+  g->block = block < 4096 ? 4096 : block;       /* (a block must hold more than the decoder's overrun, FI_SLACK) */
+  block = g->block;
   pthread_once (&gzsrc_once, gzsrc_global_init);
   const char *force = getenv ("PEMAP_ZLIB_INFLATE");
   if (!(force && atoi (force)))
@@ -83,7 +84,17 @@ gzsrc_open (gzsrc * g, const char *path, size_t block, int ring)
                   g->buf_len = FI_WINDOW + (size_t) (2 * ring + 2) * block + FI_SLACK;
                   g->buf = (uint8_t *) malloc (g->buf_len);
                   if (!g->fi || !g->buf)
-                    return -1;
+                    {
+                      free (g->fi);
+                      free (g->buf);
+                      g->fi = NULL;
+                      g->buf = NULL;
+                      munmap (m, (size_t) st.st_size);
+                      g->map = NULL;
+                      close (g->fd);
+                      g->fd = -1;
+                      return -1;
+                    }
                   fi_init (g->fi, g->map, g->map_len);
                   g->out = g->buf + FI_WINDOW;
                 }
