@@ -485,12 +485,13 @@ def main():
         dist.destroy_process_group()
 
 
-def kernel_sources_sha():
-    """sha1 over the device sources: a counter profile belongs to the kernels it was taken on"""
+def kernel_sources_sha(prefix=""):
+    """sha1 over the device sources (prefix "pemap_": the mapper's, "pecall_": the caller's): a counter profile belongs to the
+    kernels it was taken on"""
     import glob
     import hashlib
     h = hashlib.sha1()
-    for fn in sorted(glob.glob(os.path.join(ROOT, "pecaller_amd", "csrc", "*.hip*"))):
+    for fn in sorted(glob.glob(os.path.join(ROOT, "pecaller_amd", "csrc", prefix + "*.hip*"))):
         h.update(os.path.basename(fn).encode())
         h.update(open(fn, "rb").read())
     return h.hexdigest()[:16]
@@ -511,10 +512,10 @@ def pmc_traffic(kernel, gsize, B, L, config="hg38_150"):
         pm = json.load(open(path))
     except (OSError, ValueError):
         return None, None
-    sha = kernel_sources_sha()
-    if pm.get("kernel_sources_sha") != sha:
-        return None, "profiles/%s is of other kernels (sources %s, now %s): re-run tools/profile.sh" % (name, pm.get("kernel_sources_sha"), sha)
-    src = "profiles/%s (device sources %s)" % (name, sha)
+    sha = kernel_sources_sha("pemap_")
+    if pm.get("sha_pemap") != sha:
+        return None, "profiles/%s is of other kernels (pemap_* sources %s, now %s): re-run tools/profile.sh" % (name, pm.get("sha_pemap"), sha)
+    src = "profiles/%s (device sources pemap_* %s)" % (name, sha)
     if kernel is None:
         tot = 0.0
         for cn in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -542,9 +543,9 @@ def pecall_pmc_traffic(n):
         pm = json.load(open(path))
     except (OSError, ValueError):
         return None, None
-    sha = kernel_sources_sha()
-    if pm.get("kernel_sources_sha") != sha:
-        return None, "profiles/r03_pecall_pmc.json is of other kernels (sources %s, now %s): re-run tools/profile_pecall.sh" % (pm.get("kernel_sources_sha"), sha)
+    sha = kernel_sources_sha("pecall_")
+    if pm.get("sha_pecall") != sha:
+        return None, "profiles/r03_pecall_pmc.json is of other kernels (pecall_* sources %s, now %s): re-run tools/profile_pecall.sh" % (pm.get("sha_pecall"), sha)
     if pm.get("columns") != n:
         return None, "profiles/r03_pecall_pmc.json was taken on %s columns" % pm.get("columns")
     tot = 0.0
@@ -552,7 +553,7 @@ def pecall_pmc_traffic(n):
         for k, v in pm[cn].items():
             if k.startswith("pcs_"):
                 tot += v["mean_KB_per_launch"] * v["launches"] / pm.get("steps", 5)
-    return round(tot * 1024.0), "profiles/r03_pecall_pmc.json (device sources %s)" % sha
+    return round(tot * 1024.0), "profiles/r03_pecall_pmc.json (device sources pecall_* %s)" % sha
 
 
 def cpu_baseline(dev, a, B, leg, warmup):

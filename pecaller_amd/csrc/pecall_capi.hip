@@ -12,6 +12,7 @@
 
 static char g_pc_err[512] = "";
 #define PCS_SLOTS 3             // staging buffers of the seam's pipeline (chunks in flight between the two host copies)
+#define PCS_CTRS 6               // 64-bit counters per chunk: [0] the beam search's work counter, [1..2] the PCS_BUCKETS counts of listed columns, [3] columns on the deep list, [4] the shortcut kernel's work counter
 #define PCS_CALL_STREAMS 4       // streams the beam searches of consecutive chunks alternate on (each with a quarter of the waves and of the scratch)
 
 // host ranges page-locked by the caller (one table for the library: pemap_capi.hip)
@@ -59,6 +60,7 @@ struct pecall_dev
   unsigned long long *d_next_site;      // per chunk: work counter of the per-site kernel; behind it the PCS_BUCKETS counts of listed columns
   int cap_chunks;
   unsigned *d_slow;             // columns left to the beam search
+  unsigned *d_deep;             // columns too deep for the head of the ln n! table (per chunk, at the chunk's offset)
   // the caller in chunks of columns (pcs_run_chunk): the shortcut kernel of chunk k + 1 runs beside the beam search of chunk k, and at
   // the seam (pecall_dev_call_sites) beside the copies of the chunks around them
   long chunk_sites;
@@ -179,6 +181,7 @@ extern "C" void pecall_dev_destroy (pecall_dev * d)
   hipFree (d->d_dyad);
   hipFree (d->d_trio);
   hipFree (d->d_slow);
+  hipFree (d->d_deep);
   hipFree (d->d_next_site);
   if (d->ev_site[0])
     {
@@ -370,8 +373,10 @@ static int pcs_ensure (pecall_dev * d, long n_sites, int indiv)
   if (n_sites > d->cap_ssites || items > d->cap_sitems)
     {
       hipFree (d->d_sreads); hipFree (d->d_dom); hipFree (d->d_chromy); hipFree (d->d_call); hipFree (d->d_type);
-      hipFree (d->d_npass); hipFree (d->d_post); hipFree (d->d_ac); hipFree (d->d_den); hipFree (d->d_slow);
+      hipFree (d->d_npass); hipFree (d->d_post); hipFree (d->d_ac); hipFree (d->d_den); hipFree (d->d_slow); hipFree (d->d_deep);
+      d->d_deep = nullptr;
       PCCHK (d, hipMalloc ((void **) &d->d_slow, (size_t) PCS_BUCKETS * n_sites * sizeof (unsigned)));
+      PCCHK (d, hipMalloc ((void **) &d->d_deep, (size_t) n_sites * sizeof (unsigned)));
       PCCHK (d, hipMalloc ((void **) &d->d_sreads, items * PCS_NA * sizeof (uint16_t)));
       PCCHK (d, hipMalloc ((void **) &d->d_dom, n_sites));
       PCCHK (d, hipMalloc ((void **) &d->d_chromy, n_sites));
@@ -595,7 +600,7 @@ static int pcs_ensure_chunks (pecall_dev * d, long n_sites)
       PCCHK (d, hipDeviceSynchronize ());
       hipFree (d->d_next_site);
       d->d_next_site = nullptr;
-      PCCHK (d, hipMalloc ((void **) &d->d_next_site, (size_t) nch * 4 * sizeof (unsigned long long)));
+      PCCHK (d, hipMalloc ((void **) &d->d_next_site, (size_t) nch * PCS_CTRS * sizeof (unsigned long long)));
       d->ev_h2d = (hipEvent_t *) realloc (d->ev_h2d, sizeof (hipEvent_t) * nch);
       d->ev_fast = (hipEvent_t *) realloc (d->ev_fast, sizeof (hipEvent_t) * nch);
       d->ev_call = (hipEvent_t *) realloc (d->ev_call, sizeof (hipEvent_t) * nch);
@@ -612,43 +617,41 @@ static int pcs_ensure_chunks (pecall_dev * d, long n_sites)
   return 0;
 }
 
-// Chunk k = columns [off, off + m): its counters, the deepest sample of its columns (the shortcut kernel has two forms: the head of
-// the ln n! table in LDS, three workgroups per CU, or the whole table, one per CU -- which one serves depends on the depth), the
-// shortcut kernel (with the small beam) on the object's stream, and the beam search of the columns it lists on one of
-// PCS_CALL_STREAMS streams, so that it runs beside the next chunks' shortcut kernels.
-// Nothing here waits for the device.  The form with the table's head is launched without knowing the depth; it tests the depth
-// itself and leaves a chunk that is too deep untouched (an empty list for the beam search).  The host looks at the depths once, when
-// all chunks are through, and gives those chunks -- columns beyond ~1400 reads in one sample, rare -- a second pass with
-// whole_table = true.  (Waiting for each chunk's depth before its launch cost the seam half its rate: the 4-byte copy to the host
-// queued behind the chunks' 150 MB copies.)
-static int pcs_chunk_depth (pecall_dev * d, const PcsParams & P, int k, long off, long m)
+// Chunk k = columns [off, off + m): its counters, the shortcut kernel (with the small beam) on the object's stream, and the beam search
+// of the columns it lists on one of PCS_CALL_STREAMS streams, so that it runs beside the next chunks' shortcut kernels.
+// The shortcut kernel has two forms: the head of the ln n! table in LDS (three workgroups per CU), or the whole table (one per CU).
+// Which one a column needs depends on its deepest sample.  Nothing here waits for the device: the form with the table's head runs
+// over every chunk and puts the columns that are too deep for it -- beyond ~1,400 reads in one sample, rare -- on a list of the chunk;
+// the host looks at the lists' lengths once, when all chunks are through, and gives the chunks with a list a second pass
+// (whole_table = true: the other form over the listed columns, and the beam search of what that lists).
+// (History: a kernel of its own looked for the deepest sample of a chunk first, 0.12 ms and the chunk's 200 MB a second time per
+// chunk; before that the host waited for each chunk's depth, which cost the seam half its rate -- the 4-byte copy queued behind
+// the chunks' 150 MB copies.)
+static int pcs_chunk_reset (pecall_dev * d, const PcsParams & P, int k, long off, long m)
 {
-  const int N = P.indiv;
-  unsigned long long *ctr = d->d_next_site + (size_t) k * 4;
-  PCCHK (d, hipMemsetAsync (ctr, 0, 4 * sizeof (unsigned long long), d->stream));
-  if (N <= 64)
-    {
-      long dgrid = (m * N + 255) / 256;
-      if (dgrid > d->grid * 4)
-        dgrid = d->grid * 4;
-      hipLaunchKernelGGL (pcs_depth_kernel, dim3 ((unsigned) dgrid), dim3 (256), 0, d->stream, d->d_sreads + off * N * PCS_NA, m * N, (unsigned *) (ctr + 3));
-    }
+  // (the chunk's counters)
+  (void) P;
+  (void) off;
+  (void) m;
+  PCCHK (d, hipMemsetAsync (d->d_next_site + (size_t) k * PCS_CTRS, 0, PCS_CTRS * sizeof (unsigned long long), d->stream));
   return 0;
 }
 
 static int pcs_chunk_kernels (pecall_dev * d, const PcsParams & P, int k, long off, long m, bool whole_table)
 {
   const int N = P.indiv;
-  unsigned long long *ctr = d->d_next_site + (size_t) k * 4;
+  unsigned long long *ctr = d->d_next_site + (size_t) k * PCS_CTRS;
   unsigned *n_slow = (unsigned *) (ctr + 1);
   unsigned *slow = d->d_slow + (size_t) PCS_BUCKETS * off;
-  unsigned *depth_max = (unsigned *) (ctr + 3);
+  unsigned *n_deep = (unsigned *) (ctr + 3), *next_piece = (unsigned *) (ctr + 4);
+  unsigned *deep_list = d->d_deep + off;
   const int nch = N <= 64 ? 1 : N <= 128 ? 2 : 4;
-  // (second pass: behind the first pass's beam search of the chunk, which shares these counters; the depth stays)
+  // (second pass: behind the first pass's beam search of the chunk, which shares these counters; the deep list's length stays)
   if (whole_table)
     {
       PCCHK (d, hipStreamWaitEvent (d->stream, d->ev_call[k], 0));
       PCCHK (d, hipMemsetAsync (ctr, 0, 3 * sizeof (unsigned long long), d->stream));
+      PCCHK (d, hipMemsetAsync (ctr + 4, 0, sizeof (unsigned long long), d->stream));
     }
   if (nch == 1)
     {
@@ -660,7 +663,7 @@ static int pcs_chunk_kernels (pecall_dev * d, const PcsParams & P, int k, long o
             fgrid = (long) d->grid / 2 * 3;     // three workgroups of 4 waves per CU
           hipLaunchKernelGGL (HIP_KERNEL_NAME (pcs_fast_kernel < PCS_FAST_TAB >), dim3 ((unsigned) fgrid), dim3 (B), PCS_FAST_LDS_BYTES_OF (PCS_FAST_TAB), d->stream, P,
                               d->d_sreads + off * N * PCS_NA, d->d_dom + off, d->d_chromy + off, m, d->d_call + off * N, d->d_post + off * N, d->d_type + off,
-                              d->d_ac + off * PCS_NA, d->d_npass + off, d->d_den + off, slow, n_slow, depth_max, d->d_ta);
+                              d->d_ac + off * PCS_NA, d->d_npass + off, d->d_den + off, slow, n_slow, deep_list, n_deep, next_piece, d->d_ta);
         }
       else
         {
@@ -670,7 +673,7 @@ static int pcs_chunk_kernels (pecall_dev * d, const PcsParams & P, int k, long o
             fgrid = d->grid / 2;        // one workgroup per CU: the whole ln n! table takes half its LDS
           hipLaunchKernelGGL (HIP_KERNEL_NAME (pcs_fast_kernel < PC_TABLE >), dim3 ((unsigned) fgrid), dim3 (B), PCS_FAST_LDS_BYTES_OF (PC_TABLE), d->stream, P,
                               d->d_sreads + off * N * PCS_NA, d->d_dom + off, d->d_chromy + off, m, d->d_call + off * N, d->d_post + off * N, d->d_type + off,
-                              d->d_ac + off * PCS_NA, d->d_npass + off, d->d_den + off, slow, n_slow, depth_max, d->d_ta);
+                              d->d_ac + off * PCS_NA, d->d_npass + off, d->d_den + off, slow, n_slow, deep_list, n_deep, next_piece, d->d_ta);
         }
     }
   else if (whole_table)
@@ -708,10 +711,10 @@ static int pcs_deep_chunks (pecall_dev * d, const PcsParams & P, int nch, std::v
   deep.assign ((size_t) nch, 0);
   if (P.indiv > 64)
     return 0;
-  std::vector < unsigned long long >c ((size_t) nch * 4);
+  std::vector < unsigned long long >c ((size_t) nch * PCS_CTRS);
   PCCHK (d, hipMemcpy (c.data (), d->d_next_site, c.size () * sizeof (unsigned long long), hipMemcpyDeviceToHost));
   for (int k = 0; k < nch; k++)
-    if (!((unsigned) c[(size_t) k * 4 + 3] + 6u * 100u + 1u < (unsigned) PCS_FAST_TAB))
+    if ((unsigned) c[(size_t) k * PCS_CTRS + 3] > 0u)
       {
         deep[k] = 1;
         (*n_deep)++;
@@ -738,9 +741,9 @@ extern "C" int pecall_dev_sites_run (pecall_dev * d, int haploid, double thresho
   std::vector < char >deep ((size_t) k, 0);
   for (int pass = 0; pass < 2; pass++)
     {
-      // (the depths of all chunks first: a small kernel between two shortcut kernels costs the end of one and the start of the next)
+      // (the counters of all chunks first)
       for (int q = 0; q < k && pass == 0; q++)
-        if ((rc = pcs_chunk_depth (d, P, q, (long) q * C, n_sites - (long) q * C < C ? n_sites - (long) q * C : C)))
+        if ((rc = pcs_chunk_reset (d, P, q, (long) q * C, n_sites - (long) q * C < C ? n_sites - (long) q * C : C)))
           return rc;
       for (int q = 0; q < k; q++)
         if (pass == 0 || deep[q])
@@ -775,7 +778,7 @@ extern "C" int pecall_dev_sites_run (pecall_dev * d, int haploid, double thresho
       for (int q = 0; q < k; q++)
         {
           unsigned c[PCS_BUCKETS];
-          if (hipMemcpy (c, (unsigned *) (d->d_next_site + (size_t) q * 4 + 1), sizeof c, hipMemcpyDeviceToHost) == hipSuccess)
+          if (hipMemcpy (c, (unsigned *) (d->d_next_site + (size_t) q * PCS_CTRS + 1), sizeof c, hipMemcpyDeviceToHost) == hipSuccess)
             for (int b = 0; b < PCS_BUCKETS; b++)
               tot[b] += c[b];
         }
@@ -919,7 +922,7 @@ extern "C" int pecall_dev_call_sites (pecall_dev * d, const uint16_t * reads, co
   auto kernels_and_out = [&] (int j, bool whole_table) -> int
   {
     const long off = (long) j * C, m = n_sites - off < C ? n_sites - off : C;
-    int rc2 = whole_table ? 0 : pcs_chunk_depth (d, P, j, off, m);
+    int rc2 = whole_table ? 0 : pcs_chunk_reset (d, P, j, off, m);
     if (rc2 || (rc2 = pcs_chunk_kernels (d, P, j, off, m, whole_table)))
       return rc2;
     PCCHK (d, hipStreamWaitEvent (d->stream_d2h, d->ev_call[j], 0));

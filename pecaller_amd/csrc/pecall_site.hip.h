@@ -1603,33 +1603,19 @@ static void pcs_ta_table (uint32_t * out)
       }
 }
 
-// the deepest sample of a range of columns: max of A + C + G + T + Del + Ins over (column, sample)
-__global__ __launch_bounds__ (256) void pcs_depth_kernel (const uint16_t * reads, long n_items, unsigned *depth_max)
-{
-  unsigned m = 0;
-  for (long it = (long) blockIdx.x * blockDim.x + threadIdx.x; it < n_items; it += (long) gridDim.x * blockDim.x)
-    {
-      const uint32_t *w = (const uint32_t *) (reads + it * PCS_NA);      // six u16 = three words
-      const uint32_t a = w[0], b = w[1], c = w[2];
-      m = max (m, (a & 0xFFFFu) + (a >> 16) + (b & 0xFFFFu) + (b >> 16) + (c & 0xFFFFu) + (c >> 16));
-    }
-  for (int o = 32; o; o >>= 1)
-    m = max (m, (unsigned) __shfl_xor ((int) m, o));
-  if ((threadIdx.x & 63) == 0 && m)
-    atomicMax (depth_max, m);
-}
-
 template < int TABN > __global__ __launch_bounds__ (PCS_FAST_BLOCK_OF (TABN), TABN == PCS_FAST_TAB ? 3 : 2)
 void pcs_fast_kernel (PcsParams P, const uint16_t * reads, const uint8_t * dom_of, const uint8_t * chrom_of,
                       long n_sites, int8_t * call, double *post_out, int8_t * type_out,
                       int32_t * allele_count, int8_t * n_pass, int32_t * denovo_out,
-                      unsigned *slow_list, unsigned *n_slow, unsigned *depth_max, const uint32_t * ta_table)
+                      unsigned *slow_list, unsigned *n_slow, unsigned *deep_list, unsigned *n_deep, unsigned *next_piece,
+                      const uint32_t * ta_table)
 {
   constexpr int PCS_FAST_BLOCK = PCS_FAST_BLOCK_OF (TABN);
-  // (every n the columns look up: <= 6 x 100 + depth; the form with the table's head serves when that stays inside it)
-  const bool head_serves = *depth_max + 6u * 100u + 1u < (unsigned) PCS_FAST_TAB;
-  if (head_serves != (TABN == PCS_FAST_TAB))
-    return;
+  // Two forms.  TABN = PCS_FAST_TAB: the head of the ln n! table in LDS, every column of the range; a column in which a sample is too
+  // deep for the head (every n it looks up is <= 6 x 100 + depth) is put on deep_list and left alone.  TABN = PC_TABLE: the whole
+  // table, the columns of deep_list only (a second launch, made when the host has seen that the list is not empty).
+  constexpr bool LISTED = TABN != PCS_FAST_TAB;
+  const long n_items = LISTED ? (long) *n_deep : n_sites;
   extern __shared__ double pcs_fast_lds[];
   double *tab = pcs_fast_lds;
   uint32_t *ta_lo = (uint32_t *) (pcs_fast_lds + TABN + 1);            // [4][PCS_TA_SCALES][PCS_NG]: ta of alleles 0..3, a byte each
@@ -1645,12 +1631,11 @@ void pcs_fast_kernel (PcsParams P, const uint16_t * reads, const uint8_t * dom_o
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint8_t *w_sord = (uint8_t *) (ta_hi + PCS_TA_ROWS) + (size_t) wave * PCS_FAST_WAVE_BYTES;
   double *w_like = (double *) (w_sord + 64);
-  // Columns are handed out PCS_FAST_GRAB at a time through a counter (depth_max[1]; the first grid-ful of pieces by wave index).
+  // Columns are handed out PCS_FAST_GRAB at a time through a counter (next_piece; the first grid-ful of pieces by wave index).
   // With a fixed stride the launch took as long as its unluckiest workgroup: beside the beam searches of earlier chunks, whose
   // waves hold 40 KB of LDS each for milliseconds, a CU now and then has room for two of these workgroups instead of three, the third
   // starts when another one ends -- and then still had its full share to do (2.2 ms per chunk alone, 3.5 ms beside them).
-  unsigned *const next_piece = depth_max + 1;
-  const long n_pieces = (n_sites + PCS_FAST_GRAB - 1) / PCS_FAST_GRAB;
+  const long n_pieces = (n_items + PCS_FAST_GRAB - 1) / PCS_FAST_GRAB;
   const long first_free = (long) gridDim.x * (PCS_FAST_BLOCK / 64);
   for (long piece = (long) blockIdx.x * (PCS_FAST_BLOCK / 64) + wave; piece < n_pieces;)
     {
@@ -1658,9 +1643,10 @@ void pcs_fast_kernel (PcsParams P, const uint16_t * reads, const uint8_t * dom_o
       unsigned nx = 0u;
       if (lane == 0)
         nx = atomicAdd (next_piece, 1u);
-      const long site_end = min ((piece + 1) * PCS_FAST_GRAB, n_sites);
-      for (long site = piece * PCS_FAST_GRAB; site < site_end; site++)
+      const long item_end = min ((piece + 1) * PCS_FAST_GRAB, n_items);
+      for (long item = piece * PCS_FAST_GRAB; item < item_end; item++)
     {
+      const long site = LISTED ? (long) deep_list[item] : item;
       const int dom = dom_of[site];
       const int chrom = chrom_of[site] & 3;
       int decided = 1;          // 1: written here, 0: left to the beam
@@ -1675,6 +1661,13 @@ void pcs_fast_kernel (PcsParams P, const uint16_t * reads, const uint8_t * dom_o
           for (int a = 0; a < PCS_NA; a++)
             r[a] = lane < N ? (int) reads[(site * N + lane) * PCS_NA + a] : 0;
           tot = r[0] + r[1] + r[2] + r[3] + r[4];
+          if (!LISTED && __any (tot + r[5] + 6 * 100 + 1 >= TABN))
+            {
+              // (a sample too deep for the table's head: the column waits for the form with the whole table)
+              if (lane == 0)
+                deep_list[atomicAdd (n_deep, 1u)] = (unsigned) site;
+              continue;
+            }
           int tsum = tot;
           for (int o = 32; o; o >>= 1)
             tsum += __shfl_xor (tsum, o);

@@ -100,7 +100,7 @@ def test_gpu_site_caller_64_samples_and_haploid():
 @pytest.mark.gpu
 def test_gpu_site_caller_deep_columns():
     """columns with samples thousands of reads deep: the shortcut kernel then stages the whole ln n! table instead of its head
-    (pcs_depth_kernel picks the form per chunk), and counts above 10,000 take the table's log formula; mixed with ordinary columns
+    (the head form leaves the deep columns on a list for a second launch with the whole table), and counts above 10,000 take the table's log formula; mixed with ordinary columns
     in the same call, a second call with only shallow columns (the head serves again)"""
     from pecaller_amd.pecall import PecallDev
     rng = np.random.default_rng(11)

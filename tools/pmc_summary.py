@@ -39,5 +39,11 @@ for fn in sorted(glob.glob(os.path.join(root, "pecaller_amd", "csrc", "*.hip*"))
     h.update(os.path.basename(fn).encode())
     h.update(open(fn, "rb").read())
 out["kernel_sources_sha"] = h.hexdigest()[:16]
+for pre in ("pemap_", "pecall_"):           # the mapper's and the caller's sources apart: a change in one leaves the other's profile valid
+    h = hashlib.sha1()
+    for fn in sorted(glob.glob(os.path.join(root, "pecaller_amd", "csrc", pre + "*.hip*"))):
+        h.update(os.path.basename(fn).encode())
+        h.update(open(fn, "rb").read())
+    out["sha_" + pre.rstrip("_")] = h.hexdigest()[:16]
 json.dump(out, open(os.path.join(d, "pmc.json"), "w"), indent=1)
 print("wrote", os.path.join(d, "pmc.json"), {k: len(v) for k, v in out.items() if isinstance(v, dict)})
