@@ -693,7 +693,7 @@ def pecaller_leg(a):
     achieved = PECALL_BYTES_PER_SITE * n / (kernel_ms * 1e-3) / 1e9
     traffic, tsrc = pecall_pmc_traffic(n)
     return {"metric": "M pileup columns called/sec, 64 samples, 30x", "value": round(n / (kernel_ms * 1e-3) / 1e6, 4), "unit": "M columns/s",
-            "timed_region": "pcs_depth_kernel + pcs_fast_kernel + pcs_call_kernel on columns resident in HBM, in chunks of 2^18 columns, the beam searches of the chunks on four streams beside the next chunks' shortcut kernels (HIP events around all of them, mean of 3 runs)",
+            "timed_region": "pcs_fast_kernel + pcs_call_kernel on columns resident in HBM, in chunks of 2^18 columns, the beam searches of the chunks on four streams beside the next chunks' shortcut kernels (HIP events around all of them, mean of 3 runs)",
             "seam_value": round(n / seam_dt / 1e6, 4), "seam_timed_region": "pecall_dev_call_sites: host columns in, calls + posteriors out (PCIe included; the caller's buffers page-locked once, copies and kernels of neighbouring chunks side by side)",
             "seam_pageable_value": round(n / seam_pageable_dt / 1e6, 4),
             "dtype": "f64", "data": "synthetic", "n_gpus": 1,
