@@ -1553,10 +1553,10 @@ __device__ bool pcs_mini_beam (const PcsParams & P, const double *tab_unused, co
 // posterior 1 after one pass, site type REF -- and is written here; so are the columns the site filters drop (every call N,
 // zero passes) and the ones whose reference base is not A/C/G/T.  Everything else goes to slow_list for pcs_call_kernel.
 #define PCS_FAST_WAVE_BYTES (64 + PCS_NG * 8 + 16)        // per wave: the samples' order, one sample's likelihoods (pcs_mini_beam)
-// The ln n! table in LDS comes in two sizes.  Pass 1 looks up n <= 600 + the sample's depth (ta <= 100 per allele): when no sample of
-// the columns at hand is deeper than ~1,400 reads (pcs_depth_kernel finds out), 2,048 entries serve, a workgroup is 4 waves with 20 KB
-// and 12 waves per CU run (the registers' limit) beside whatever else is resident; otherwise the whole table (80 KB) is staged by
-// workgroups of 8 waves, one per CU, as before round 3.  Both forms are launched; the one the depth does not select returns at once.
+// The ln n! table in LDS comes in two sizes.  Pass 1 looks up n <= 600 + the sample's depth (ta <= 100 per allele): for a column with
+// no sample deeper than ~1,400 reads 2,048 entries serve, a workgroup is 4 waves with 30 KB and 12 waves per CU run (the registers'
+// limit) beside whatever else is resident; the form with the whole table (80 KB, workgroups of 8 waves, one per CU, as before round 3)
+// takes the columns the first form found too deep and listed, in a launch of its own when there are any.
 #define PCS_FAST_TAB 2048
 #define PCS_FAST_GRAB 8                // columns a wave of the shortcut kernel takes per fetch of the work counter
 #define PCS_FAST_WAVE_BYTES (64 + PCS_NG * 8 + 16)        // per wave: the samples' order, one sample's likelihoods (pcs_mini_beam)
