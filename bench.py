@@ -649,7 +649,18 @@ def pecaller_leg(a):
     t0 = time.perf_counter()
     call, post, typ, ac, npass = pc.call_sites(reads, dom, out=out)
     seam_dt = time.perf_counter() - t0
-    for arr in (reads, dom) + out:
+    # ... and with the posteriors as a list of the columns in which one is not 1 (pecall_dev_call_sites_sparse): 94 bytes per column
+    # come back instead of 606
+    sp_site, sp_rows = np.zeros(max(1024, n // 8), np.uint32), np.zeros((max(1024, n // 8), S))
+    pc.pin_host(sp_site)
+    pc.pin_host(sp_rows)
+    pc.call_sites_sparse(reads, dom, out=out, sparse_out=(sp_site, sp_rows))
+    t0 = time.perf_counter()
+    s_call, (s_site, s_rows), s_typ, s_ac, s_np = pc.call_sites_sparse(reads, dom, out=out, sparse_out=(sp_site, sp_rows))
+    seam_sparse_dt = time.perf_counter() - t0
+    sparse_cols = len(s_site)
+    s_call = s_call.copy()
+    for arr in (reads, dom, sp_site, sp_rows) + out:
         pc.unpin_host(arr)
     # the same call from pageable memory (the library stages through its own pinned buffers)
     out2 = pc.out_arrays(n, S)
@@ -657,6 +668,8 @@ def pecaller_leg(a):
     c3, p3 = pc.call_sites(reads, dom, out=out2)[:2]
     seam_pageable_dt = time.perf_counter() - t0
     assert np.array_equal(c3, call) and np.array_equal(p3, post)
+    want = np.nonzero((p3 != 1.0).any(axis=1))[0]
+    assert np.array_equal(s_call, c3) and np.array_equal(s_site, want.astype(np.uint32)) and np.array_equal(s_rows, p3[want])
     del out2, c3, p3
     pc.sites_stage(reads, dom)
     kms = [pc.sites_run() for _ in range(3)]
@@ -696,6 +709,7 @@ def pecaller_leg(a):
             "timed_region": "pcs_fast_kernel + pcs_call_kernel on columns resident in HBM, in chunks of 2^18 columns, the beam searches of the chunks on four streams beside the next chunks' shortcut kernels (HIP events around all of them, mean of 3 runs)",
             "seam_value": round(n / seam_dt / 1e6, 4), "seam_timed_region": "pecall_dev_call_sites: host columns in, calls + posteriors out (PCIe included; the caller's buffers page-locked once, copies and kernels of neighbouring chunks side by side)",
             "seam_pageable_value": round(n / seam_pageable_dt / 1e6, 4),
+            "seam_sparse_value": round(n / seam_sparse_dt / 1e6, 4), "seam_sparse_region": "pecall_dev_call_sites_sparse: as seam_value, the posteriors as the list of the %d columns (of %d) in which one differs from 1; checked against the dense call" % (sparse_cols, n),
             "dtype": "f64", "data": "synthetic", "n_gpus": 1,
             "config": {"workload": "%d pileup columns x %d samples, 30x Poisson depth, 0.4%% error, 1 variant/kb under HWE, seed 777, "
                                    "prob_to_call 0.95, theta 0.001, diploid, no pedigree" % (n, S), "generated_in_s": round(t_gen, 1)},

@@ -239,6 +239,16 @@ int pecall_dev_collect (pecall_dev * dev, int n_sites, int indiv, double *like, 
 int pecall_dev_call_sites (pecall_dev * dev, const uint16_t * reads, const uint8_t * ref_base, const uint8_t * chrom_type, long n_sites,
                            int indiv, int haploid, double threshold, double theta, int8_t * call, double *posterior,
                            int8_t * site_type, int32_t * allele_count, int8_t * n_pass, int32_t * denovo);
+/* The same call with the posteriors as a list: nearly every column of real data has posterior 1 for every sample (the shortcut of
+ * the pass loop), and of the 606 bytes a 64-sample column sends back 512 are these doubles -- at the rate of the PCIe link they are
+ * what the call takes.  Here only the columns in which SOME posterior differs from 1 come back: post_site[k] = the column's number
+ * (ascending), post_rows[k][indiv] = its samples' posteriors; every column that is not listed has posterior exactly 1 for every
+ * sample.  post_cap = rows the two arrays hold; *n_post = columns listed.  More columns than post_cap: the call fails (its message
+ * says so) with *n_post = the number needed; nothing else of the results is to be used then.  The other arrays are as above. */
+int pecall_dev_call_sites_sparse (pecall_dev * dev, const uint16_t * reads, const uint8_t * ref_base, const uint8_t * chrom_type, long n_sites,
+                                  int indiv, int haploid, double threshold, double theta, int8_t * call, uint32_t * post_site,
+                                  double *post_rows, uint64_t post_cap, uint64_t * n_post, int8_t * site_type, int32_t * allele_count,
+                                  int8_t * n_pass, int32_t * denovo);
 /* Page-lock a host range the caller will hand to pecall_dev_call_sites again and again (its tile buffers): the same table of
  * ranges as pemap_dev_pin_host's; a range stays until its last unpin.  Unpin before freeing the memory. */
 int pecall_dev_pin_host (pecall_dev * dev, const void *host_ptr, uint64_t n_bytes);

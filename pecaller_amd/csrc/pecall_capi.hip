@@ -6,6 +6,7 @@
 #include <math.h>
 #include <chrono>
 #include <vector>
+#include <algorithm>
 #include "../../include/pemap_hip.h"
 #include "pecall_kernels.hip.h"
 #include "pecall_site.hip.h"
@@ -61,6 +62,13 @@ struct pecall_dev
   int cap_chunks;
   unsigned *d_slow;             // columns left to the beam search
   unsigned *d_deep;             // columns too deep for the head of the ln n! table (per chunk, at the chunk's offset)
+  // pecall_dev_call_sites_sparse: the columns with a posterior that is not 1 (pcs_sparse_kernel)
+  unsigned *d_sp_cols;
+  double *d_sp_rows;
+  unsigned long long *d_sp_n;
+  unsigned long long *h_ctrs;   // page-locked: the chunks' counters and the list's length on their way to the host ([cap_chunks * PCS_CTRS + 1])
+  unsigned long long sp_cap;
+  int sp_indiv;
   // the caller in chunks of columns (pcs_run_chunk): the shortcut kernel of chunk k + 1 runs beside the beam search of chunk k, and at
   // the seam (pecall_dev_call_sites) beside the copies of the chunks around them
   long chunk_sites;
@@ -182,6 +190,11 @@ extern "C" void pecall_dev_destroy (pecall_dev * d)
   hipFree (d->d_trio);
   hipFree (d->d_slow);
   hipFree (d->d_deep);
+  hipFree (d->d_sp_cols);
+  hipFree (d->d_sp_rows);
+  hipFree (d->d_sp_n);
+  if (d->h_ctrs)
+    hipHostFree (d->h_ctrs);
   hipFree (d->d_next_site);
   if (d->ev_site[0])
     {
@@ -601,6 +614,10 @@ static int pcs_ensure_chunks (pecall_dev * d, long n_sites)
       hipFree (d->d_next_site);
       d->d_next_site = nullptr;
       PCCHK (d, hipMalloc ((void **) &d->d_next_site, (size_t) nch * PCS_CTRS * sizeof (unsigned long long)));
+      if (d->h_ctrs)
+        hipHostFree (d->h_ctrs);
+      d->h_ctrs = nullptr;
+      PCCHK (d, hipHostMalloc ((void **) &d->h_ctrs, ((size_t) nch * PCS_CTRS + 1) * sizeof (unsigned long long), hipHostMallocDefault));
       d->ev_h2d = (hipEvent_t *) realloc (d->ev_h2d, sizeof (hipEvent_t) * nch);
       d->ev_fast = (hipEvent_t *) realloc (d->ev_fast, sizeof (hipEvent_t) * nch);
       d->ev_call = (hipEvent_t *) realloc (d->ev_call, sizeof (hipEvent_t) * nch);
@@ -637,7 +654,7 @@ static int pcs_chunk_reset (pecall_dev * d, const PcsParams & P, int k, long off
   return 0;
 }
 
-static int pcs_chunk_kernels (pecall_dev * d, const PcsParams & P, int k, long off, long m, bool whole_table)
+static int pcs_chunk_kernels (pecall_dev * d, const PcsParams & P, int k, long off, long m, bool whole_table, bool sparse = false)
 {
   const int N = P.indiv;
   unsigned long long *ctr = d->d_next_site + (size_t) k * PCS_CTRS;
@@ -699,6 +716,14 @@ static int pcs_chunk_kernels (pecall_dev * d, const PcsParams & P, int k, long o
   else
     PCS_CALL (4, (const unsigned *) nullptr, (const unsigned *) nullptr);
 #undef PCS_CALL
+  if (sparse)
+    {
+      // behind the beam search, on its stream: the chunk's columns with a posterior that is not 1 (second pass: of the deep list only)
+      const long sgrid = whole_table ? d->grid : ((m + 3) / 4 < (long) d->grid * 4 ? (m + 3) / 4 : (long) d->grid * 4);
+      hipLaunchKernelGGL (pcs_sparse_kernel, dim3 ((unsigned) (sgrid > 0 ? sgrid : 1)), dim3 (256), 0, sc, d->d_post + off * N, m,
+                          whole_table ? (const unsigned *) deep_list : (const unsigned *) nullptr, (const unsigned *) n_deep, N, (unsigned) off,
+                          d->d_sp_cols, d->d_sp_rows, d->sp_cap, d->d_sp_n);
+    }
   PCCHK (d, hipGetLastError ());
   PCCHK (d, hipEventRecord (d->ev_call[k], sc));
   return 0;
@@ -711,8 +736,9 @@ static int pcs_deep_chunks (pecall_dev * d, const PcsParams & P, int nch, std::v
   deep.assign ((size_t) nch, 0);
   if (P.indiv > 64)
     return 0;
-  std::vector < unsigned long long >c ((size_t) nch * PCS_CTRS);
-  PCCHK (d, hipMemcpy (c.data (), d->d_next_site, c.size () * sizeof (unsigned long long), hipMemcpyDeviceToHost));
+  // (into page-locked memory of the object's own: a pageable target that shares a page with an array the caller registered is refused)
+  unsigned long long *c = d->h_ctrs;
+  PCCHK (d, hipMemcpy (c, d->d_next_site, (size_t) nch * PCS_CTRS * sizeof (unsigned long long), hipMemcpyDeviceToHost));
   for (int k = 0; k < nch; k++)
     if ((unsigned) c[(size_t) k * PCS_CTRS + 3] > 0u)
       {
@@ -839,15 +865,41 @@ extern "C" int pecall_dev_unpin_host (pecall_dev * d, const void *host_ptr)
 // kernels of chunk k and the device-to-host copy of chunk k - 1 run side by side (three streams behind each other through events).
 // Buffers the caller pinned (pecall_dev_pin_host) are copied from and to directly; others pass through PCS_SLOTS pinned staging
 // buffers, filled and emptied by a few host threads (one core moves ~10 GB/s; a 64-sample column is 768 bytes in, ~620 out).
-extern "C" int pecall_dev_call_sites (pecall_dev * d, const uint16_t * reads, const uint8_t * ref_base, const uint8_t * chrom_type, long n_sites,
-                                      int indiv, int haploid, double threshold, double theta, int8_t * call, double *posterior,
-                                      int8_t * site_type, int32_t * allele_count, int8_t * n_pass, int32_t * denovo)
+// sparse = the posteriors come back as the list of the columns in which one differs from 1 (post_site / post_rows / post_cap / n_post)
+// instead of the dense array `posterior`
+static int pcs_call_sites_impl (pecall_dev * d, const uint16_t * reads, const uint8_t * ref_base, const uint8_t * chrom_type, long n_sites,
+                                int indiv, int haploid, double threshold, double theta, int8_t * call, double *posterior,
+                                int8_t * site_type, int32_t * allele_count, int8_t * n_pass, int32_t * denovo,
+                                bool sparse, uint32_t * post_site, double *post_rows, uint64_t post_cap, uint64_t * n_post)
 {
   PCCHK (d, hipSetDevice (d->device));
   if (n_sites <= 0 || indiv <= 0 || indiv > PCS_MAXN)
     return pc_fail (d, "call_sites: n_sites %ld, indiv %d (1..%d samples per call)", n_sites, indiv, PCS_MAXN);
-  if (!reads || !ref_base || !call || !posterior)
+  if (!reads || !ref_base || !call || (!sparse && !posterior))
     return pc_fail (d, "call_sites: a required pointer is NULL");
+  if (sparse && (!post_site || !post_rows || !n_post || post_cap == 0))
+    return pc_fail (d, "call_sites_sparse: the list of posteriors needs post_site, post_rows, a capacity and n_post");
+  if (sparse)
+    {
+      *n_post = 0;
+      if (d->sp_cap < post_cap || d->sp_indiv < indiv)
+        {
+          PCCHK (d, hipDeviceSynchronize ());
+          hipFree (d->d_sp_cols);
+          hipFree (d->d_sp_rows);
+          d->d_sp_cols = nullptr;
+          d->d_sp_rows = nullptr;
+          d->sp_cap = 0;
+          const unsigned long long cap = post_cap > d->sp_cap ? post_cap : d->sp_cap;
+          const int wide = indiv > d->sp_indiv ? indiv : d->sp_indiv;
+          PCCHK (d, hipMalloc ((void **) &d->d_sp_cols, (size_t) cap * sizeof (unsigned)));
+          PCCHK (d, hipMalloc ((void **) &d->d_sp_rows, (size_t) cap * (size_t) wide * sizeof (double)));
+          if (!d->d_sp_n)
+            PCCHK (d, hipMalloc ((void **) &d->d_sp_n, sizeof (unsigned long long)));
+          d->sp_cap = cap;
+          d->sp_indiv = wide;
+        }
+    }
   // (the tables first: the parameter block carries their device addresses)
   int rc = pcs_ensure (d, n_sites, indiv);
   if (rc)
@@ -863,10 +915,10 @@ extern "C" int pecall_dev_call_sites (pecall_dev * d, const uint16_t * reads, co
   const int nch = (int) ((n_sites + C - 1) / C);
   const size_t N = (size_t) indiv;
   // per column: in = reads + reference base + chromosome class; out = calls + posteriors + type + passes + allele counts + de-novo count
-  const size_t in_col = N * PCS_NA * 2 + 2, out_col = N * 9 + 2 + PCS_NA * 4 + 4;
+  const size_t in_col = N * PCS_NA * 2 + 2, out_col = N * (sparse ? 1 : 9) + 2 + PCS_NA * 4 + 4;
   const bool in_direct = pm_host_pin_lookup (reads, (size_t) n_sites * N * PCS_NA * 2) && pm_host_pin_lookup (ref_base, (size_t) n_sites)
     && (!chrom_type || pm_host_pin_lookup (chrom_type, (size_t) n_sites));
-  const bool out_direct = pm_host_pin_lookup (call, (size_t) n_sites * N) && pm_host_pin_lookup (posterior, (size_t) n_sites * N * 8)
+  const bool out_direct = pm_host_pin_lookup (call, (size_t) n_sites * N) && (sparse || pm_host_pin_lookup (posterior, (size_t) n_sites * N * 8))
     && (!site_type || pm_host_pin_lookup (site_type, (size_t) n_sites)) && (!allele_count || pm_host_pin_lookup (allele_count, (size_t) n_sites * PCS_NA * 4))
     && (!n_pass || pm_host_pin_lookup (n_pass, (size_t) n_sites)) && (!denovo || pm_host_pin_lookup (denovo, (size_t) n_sites * 4));
   const long cmax = n_sites < C ? n_sites : C;
@@ -903,8 +955,11 @@ extern "C" int pecall_dev_call_sites (pecall_dev * d, const uint16_t * reads, co
     const char *o = d->h_out[j % PCS_SLOTS];
     pm_par_memcpy ((char *) (call + off * N), o, (size_t) m * N);
     o += (size_t) m * N;
-    pm_par_memcpy ((char *) (posterior + off * N), o, (size_t) m * N * 8);
-    o += (size_t) m * N * 8;
+    if (!sparse)
+      {
+        pm_par_memcpy ((char *) (posterior + off * N), o, (size_t) m * N * 8);
+        o += (size_t) m * N * 8;
+      }
     if (site_type)
       memcpy (site_type + off, o, (size_t) m);
     o += m;
@@ -923,14 +978,15 @@ extern "C" int pecall_dev_call_sites (pecall_dev * d, const uint16_t * reads, co
   {
     const long off = (long) j * C, m = n_sites - off < C ? n_sites - off : C;
     int rc2 = whole_table ? 0 : pcs_chunk_reset (d, P, j, off, m);
-    if (rc2 || (rc2 = pcs_chunk_kernels (d, P, j, off, m, whole_table)))
+    if (rc2 || (rc2 = pcs_chunk_kernels (d, P, j, off, m, whole_table, sparse)))
       return rc2;
     PCCHK (d, hipStreamWaitEvent (d->stream_d2h, d->ev_call[j], 0));
     char *o = out_direct ? nullptr : d->h_out[j % PCS_SLOTS];
 #define PCS_OUT(dst_host, dev_ptr, bytes) do { void *dst_ = out_direct ? (void *) (dst_host) : (void *) o; if (out_direct ? (dst_host) != nullptr : true) \
     PCCHK (d, hipMemcpyAsync (dst_, dev_ptr, bytes, hipMemcpyDeviceToHost, d->stream_d2h)); if (!out_direct) o += (bytes); } while (0)
     PCS_OUT (call + off * N, d->d_call + off * N, (size_t) m * N);
-    PCS_OUT (posterior + off * N, d->d_post + off * N, (size_t) m * N * 8);
+    if (!sparse)
+      PCS_OUT (posterior + off * N, d->d_post + off * N, (size_t) m * N * 8);
     PCS_OUT (site_type ? site_type + off : nullptr, d->d_type + off, (size_t) m);
     PCS_OUT (n_pass ? n_pass + off : nullptr, d->d_npass + off, (size_t) m);
     PCS_OUT (allele_count ? allele_count + off * PCS_NA : nullptr, d->d_ac + off * PCS_NA, (size_t) m * PCS_NA * 4);
@@ -939,6 +995,8 @@ extern "C" int pecall_dev_call_sites (pecall_dev * d, const uint16_t * reads, co
     PCCHK (d, hipEventRecord (d->ev_d2h[j], d->stream_d2h));
     return 0;
   };
+  if (sparse)
+    PCCHK (d, hipMemsetAsync (d->d_sp_n, 0, sizeof (unsigned long long), d->stream));
   const bool trace = getenv ("PECALL_SEAM_TRACE") != nullptr;
   const auto t_start = std::chrono::steady_clock::now ();
   auto since = [&] () { return std::chrono::duration < double, std::milli > (std::chrono::steady_clock::now () - t_start).count (); };
@@ -1005,7 +1063,61 @@ extern "C" int pecall_dev_call_sites (pecall_dev * d, const uint16_t * reads, co
   PCCHK (d, hipStreamSynchronize (d->stream));
   for (int i = 0; i < PCS_CALL_STREAMS; i++)
     PCCHK (d, hipStreamSynchronize (d->stream_call[i]));
+  if (sparse)
+    {
+      // the listed columns, in ascending order of their numbers (the kernels appended them as they came)
+      PCCHK (d, hipMemcpy (d->h_ctrs + (size_t) d->cap_chunks * PCS_CTRS, d->d_sp_n, sizeof (unsigned long long), hipMemcpyDeviceToHost));
+      const unsigned long long n = d->h_ctrs[(size_t) d->cap_chunks * PCS_CTRS];
+      *n_post = n;
+      if (n > post_cap)
+        return pc_fail (d, "call_sites_sparse: %llu columns have a posterior that is not 1, the list holds %llu (n_post says how many are needed)", n,
+                        (unsigned long long) post_cap);
+      if (n > 0)
+        {
+          // (through a page-locked block of this call's own: a copy into pageable memory that shares a page with one of the caller's
+          // registered arrays is refused by the runtime -- tools/micro/hostreg.hip -- and a small heap block may well do that)
+          char *blk = nullptr;
+          const size_t rows_bytes = (size_t) n * N * sizeof (double), cols_bytes = ((size_t) n * sizeof (unsigned) + 63) & ~(size_t) 63;
+          PCCHK (d, hipHostMalloc ((void **) &blk, rows_bytes + cols_bytes, hipHostMallocDefault));
+          const double *rows = (const double *) blk;
+          const unsigned *cols = (const unsigned *) (blk + rows_bytes);
+          hipError_t e1 = hipMemcpy ((void *) cols, d->d_sp_cols, (size_t) n * sizeof (unsigned), hipMemcpyDeviceToHost);
+          hipError_t e2 = hipMemcpy ((void *) rows, d->d_sp_rows, rows_bytes, hipMemcpyDeviceToHost);
+          if (e1 != hipSuccess || e2 != hipSuccess)
+            {
+              hipHostFree (blk);
+              return pc_fail (d, "call_sites_sparse: copying the list back: %s", hipGetErrorString (e1 != hipSuccess ? e1 : e2));
+            }
+          std::vector < unsigned >order ((size_t) n);
+          for (size_t i = 0; i < (size_t) n; i++)
+            order[i] = (unsigned) i;
+          std::sort (order.begin (), order.end (), [&] (unsigned a, unsigned b) { return cols[a] < cols[b]; });
+          for (size_t i = 0; i < (size_t) n; i++)
+            {
+              post_site[i] = cols[order[i]];
+              memcpy (post_rows + i * N, rows + (size_t) order[i] * N, N * sizeof (double));
+            }
+          hipHostFree (blk);
+        }
+    }
   if (trace)
     fprintf (stderr, "[pecall seam] done at %.2f ms\n", since ());
   return 0;
+}
+
+extern "C" int pecall_dev_call_sites (pecall_dev * d, const uint16_t * reads, const uint8_t * ref_base, const uint8_t * chrom_type, long n_sites,
+                                      int indiv, int haploid, double threshold, double theta, int8_t * call, double *posterior,
+                                      int8_t * site_type, int32_t * allele_count, int8_t * n_pass, int32_t * denovo)
+{
+  return pcs_call_sites_impl (d, reads, ref_base, chrom_type, n_sites, indiv, haploid, threshold, theta, call, posterior, site_type, allele_count, n_pass,
+                              denovo, false, nullptr, nullptr, 0, nullptr);
+}
+
+extern "C" int pecall_dev_call_sites_sparse (pecall_dev * d, const uint16_t * reads, const uint8_t * ref_base, const uint8_t * chrom_type, long n_sites,
+                                             int indiv, int haploid, double threshold, double theta, int8_t * call, uint32_t * post_site,
+                                             double *post_rows, uint64_t post_cap, uint64_t * n_post, int8_t * site_type, int32_t * allele_count,
+                                             int8_t * n_pass, int32_t * denovo)
+{
+  return pcs_call_sites_impl (d, reads, ref_base, chrom_type, n_sites, indiv, haploid, threshold, theta, call, nullptr, site_type, allele_count, n_pass,
+                              denovo, true, post_site, post_rows, post_cap, n_post);
 }

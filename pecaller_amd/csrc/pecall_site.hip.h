@@ -1663,9 +1663,12 @@ void pcs_fast_kernel (PcsParams P, const uint16_t * reads, const uint8_t * dom_o
           tot = r[0] + r[1] + r[2] + r[3] + r[4];
           if (!LISTED && __any (tot + r[5] + 6 * 100 + 1 >= TABN))
             {
-              // (a sample too deep for the table's head: the column waits for the form with the whole table)
+              // (a sample too deep for the table's head: the column waits for the form with the whole table; its posteriors read 1
+              // until then, so that pcs_sparse_kernel does not take what an earlier call left there)
               if (lane == 0)
                 deep_list[atomicAdd (n_deep, 1u)] = (unsigned) site;
+              if (lane < N)
+                post_out[site * N + lane] = 1.0;
               continue;
             }
           int tsum = tot;
@@ -1788,5 +1791,37 @@ void pcs_fast_kernel (PcsParams P, const uint16_t * reads, const uint8_t * dom_o
         }
     }
       piece = first_free + (long) (unsigned) __shfl ((int) nx, 0);
+    }
+}
+
+// The posteriors that are not exactly 1, column by column: nearly every column of real data is settled by the shortcut with posterior
+// 1 for every sample, and a caller that prints them (%g) or thresholds them needs the others only -- 512 of the 606 bytes a 64-sample
+// column sends back are these doubles.  One wave per column of [0, n_items) (or per column of `list`): if any sample's posterior
+// differs from 1, the column takes the next free row of `rows` (its samples' posteriors) and its number goes to `cols`, in no
+// particular order (the host sorts the few thousand column numbers).  `bias` is added to the column number (the chunk's offset).
+__global__ __launch_bounds__ (256) void pcs_sparse_kernel (const double *post, long n_items, const unsigned *list, const unsigned *n_list, int N, unsigned bias,
+                                                           unsigned *cols, double *rows, unsigned long long cap, unsigned long long *n_rows)
+{
+  const int lane = threadIdx.x & 63;
+  const long wave = ((long) blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((long) gridDim.x * blockDim.x) >> 6;
+  const long n = list ? (long) *n_list : n_items;
+  for (long it = wave; it < n; it += n_waves)
+    {
+      const long site = list ? (long) list[it] : it;
+      bool any = false;
+      for (int i = lane; i < N; i += 64)
+        any = any || post[site * N + i] != 1.0;
+      if (!__any (any))
+        continue;
+      unsigned long long row = 0ull;
+      if (lane == 0)
+        row = atomicAdd (n_rows, 1ull);
+      row = (unsigned long long) __shfl ((long long) row, 0);
+      if (row >= cap)
+        continue;               // (counted all the same: the host sees that the list was too short)
+      if (lane == 0)
+        cols[row] = (unsigned) site + bias;
+      for (int i = lane; i < N; i += 64)
+        rows[row * (unsigned long long) N + i] = post[site * N + i];
     }
 }

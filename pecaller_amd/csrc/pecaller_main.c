@@ -125,7 +125,10 @@ typedef struct
   int *contig;
   unsigned int *pos;
   int8_t *call, *type;
-  double *post;
+  /* the posteriors that are not 1: the columns that have one (ascending) and their samples' posteriors (pecall_dev_call_sites_sparse) */
+  uint32_t *post_site;
+  double *post_rows;
+  uint64_t n_post, post_cap;
   int32_t *ac, *denovo;
   long n;
 } tile_t;
@@ -157,13 +160,26 @@ static void
 emit_rows (const tile_t * t, long s0, long s1, int indiv, char **contig_names, sbuf * ob, sbuf * sb, sbuf * pb)
 {
   char minor[80], am_count[80], tmp[64];
+  /* the first listed column at or behind s0 */
+  uint64_t lp = 0, hi = t->n_post;
+  while (lp < hi)
+    {
+      const uint64_t mid = (lp + hi) / 2;
+      if ((long) t->post_site[mid] < s0)
+        lp = mid + 1;
+      else
+        hi = mid;
+    }
   for (long s = s0; s < s1; s++)
     {
+      /* the column's posteriors: a row of the list, or all 1 (p = NULL) */
+      const double *p = NULL;
+      if (lp < t->n_post && (long) t->post_site[lp] == s)
+        p = t->post_rows + (size_t) lp++ * indiv;
       if (t->type[s] < 0)
         continue;               /* reference base not A/C/G/T: the worker skips the column (pecaller.c:1208, 1718) */
       const char *frag = contig_names[t->contig[s]];
       const int8_t *call = t->call + s * indiv;
-      const double *p = t->post + s * indiv;
       const size_t fl = strlen (frag);
       {
         char *w = sb_room (ob, fl + 32 + (size_t) indiv * 32);
@@ -182,7 +198,7 @@ emit_rows (const tile_t * t, long s0, long s1, int indiv, char **contig_names, s
               {
                 *w++ = GEN[call[i]];
                 *w++ = '\t';
-                if (p[i] == 1.0)
+                if (!p || p[i] == 1.0)
                   *w++ = '1';
                 else
                   w += sprintf (w, "%g", p[i]);
@@ -217,7 +233,7 @@ emit_rows (const tile_t * t, long s0, long s1, int indiv, char **contig_names, s
       pb->n += (size_t) sprintf (sb_room (pb, fl + 64), "\n%s\t%d\t%c", frag, (int) t->pos[s], t->ref_char[s]);
       for (int i = 0; i < indiv; i++)
         {
-          sb->n += (size_t) sprintf (sb_room (sb, 64), "\t%c\t%g", GEN[call[i]], p[i]);
+          sb->n += (size_t) sprintf (sb_room (sb, 64), "\t%c\t%g", GEN[call[i]], p ? p[i] : 1.0);
           const uint16_t *r = t->reads + ((size_t) s * indiv + i) * NA;
           for (int a = 0; a < NA; a++)
             pb->n += (size_t) sprintf (sb_room (pb, 16), "\t%d", (int) r[a]);
@@ -552,8 +568,23 @@ consumer_main (void *arg)
       clock_gettime (CLOCK_MONOTONIC, &a);
       if (c->role == 0)
         {
-          if (pecall_dev_call_sites (c->pc, t->reads, t->ref_base, t->chrom, t->n, c->indiv, c->haploid, c->threshold, c->theta, t->call, t->post, t->type,
-                                     t->ac, NULL, t->denovo))
+          int rc = pecall_dev_call_sites_sparse (c->pc, t->reads, t->ref_base, t->chrom, t->n, c->indiv, c->haploid, c->threshold, c->theta, t->call,
+                                                 t->post_site, t->post_rows, t->post_cap, &t->n_post, t->type, t->ac, NULL, t->denovo);
+          if (rc && t->n_post > t->post_cap)
+            {
+              /* more columns with a posterior that is not 1 than the list holds (one per 8 columns to begin with): a list of the size
+                 the call asked for, not page-locked, and once more */
+              (void) pecall_dev_unpin_host (c->pc, t->post_site);
+              (void) pecall_dev_unpin_host (c->pc, t->post_rows);
+              t->post_cap = t->n_post + t->n_post / 8 + 1024;
+              t->post_site = (uint32_t *) realloc (t->post_site, t->post_cap * sizeof (uint32_t));
+              t->post_rows = (double *) realloc (t->post_rows, t->post_cap * (size_t) c->indiv * sizeof (double));
+              if (!t->post_site || !t->post_rows)
+                die ("\n pecaller_hip: out of memory for %s", "the list of posteriors");
+              rc = pecall_dev_call_sites_sparse (c->pc, t->reads, t->ref_base, t->chrom, t->n, c->indiv, c->haploid, c->threshold, c->theta, t->call,
+                                                 t->post_site, t->post_rows, t->post_cap, &t->n_post, t->type, t->ac, NULL, t->denovo);
+            }
+          if (rc)
             die ("\n pecaller_hip: %s", pecall_dev_last_error (c->pc));
           clock_gettime (CLOCK_MONOTONIC, &b);
           c->sec_dev += (double) (b.tv_sec - a.tv_sec) + 1e-9 * (double) (b.tv_nsec - a.tv_nsec);
@@ -597,11 +628,20 @@ tile_alloc (tile_t * t, int indiv)
   t->contig = (int *) malloc (TILE * sizeof (int));
   t->pos = (unsigned int *) malloc (TILE * sizeof (unsigned int));
   t->call = (int8_t *) malloc ((size_t) TILE * indiv);
-  t->post = (double *) malloc ((size_t) TILE * indiv * sizeof (double));
+  t->post_cap = TILE / 8 > 1024 ? TILE / 8 : 1024;
+  {
+    /* (tests: a list that is too short for the first tiles, so that the second call with the size asked for is taken) */
+    const char *e = getenv ("PECALLER_POST_CAP");
+    if (e && atol (e) >= 1)
+      t->post_cap = (uint64_t) atol (e);
+  }
+  t->post_site = (uint32_t *) malloc (t->post_cap * sizeof (uint32_t));
+  t->post_rows = (double *) malloc (t->post_cap * (size_t) indiv * sizeof (double));
+  t->n_post = 0;
   t->type = (int8_t *) malloc (TILE);
   t->ac = (int32_t *) malloc ((size_t) TILE * NA * sizeof (int32_t));
   t->n = 0;
-  if (!t->reads || !t->ref_base || !t->chrom || !t->denovo || !t->ref_char || !t->contig || !t->pos || !t->call || !t->post || !t->type || !t->ac)
+  if (!t->reads || !t->ref_base || !t->chrom || !t->denovo || !t->ref_char || !t->contig || !t->pos || !t->call || !t->post_site || !t->post_rows || !t->type || !t->ac)
     die ("\n pecaller_hip: out of memory for %s", "a tile");
 }
 
@@ -880,8 +920,8 @@ main (int argc, char *argv[])
       TILE = (size_t) 1 << atoi (tl);
     else
       {
-        /* the host arrays hold ~57 bytes per (column, sample) -- the merge's planes, three tiles of reads, calls and posteriors: 2^20
-           columns are 3.8 GB with 64 samples; with more samples the tile shrinks so that columns x samples stays at that product */
+        /* the host arrays hold ~54 bytes per (column, sample) -- the merge's planes, three tiles of reads and calls, the lists of the
+           posteriors that are not 1: 2^20 columns are 3.6 GB with 64 samples; with more samples the tile shrinks so that columns x samples stays at that product */
         while (TILE > ((size_t) 1 << 16) && TILE * (size_t) no_files > ((size_t) 1 << 26))
           TILE >>= 1;
       }
@@ -906,7 +946,8 @@ main (int argc, char *argv[])
       (void) pecall_dev_pin_host (pc, tt->ref_base, (uint64_t) TILE);
       (void) pecall_dev_pin_host (pc, tt->chrom, (uint64_t) TILE);
       (void) pecall_dev_pin_host (pc, tt->call, (uint64_t) TILE * indiv);
-      (void) pecall_dev_pin_host (pc, tt->post, (uint64_t) TILE * indiv * sizeof (double));
+      (void) pecall_dev_pin_host (pc, tt->post_site, (uint64_t) tt->post_cap * sizeof (uint32_t));
+      (void) pecall_dev_pin_host (pc, tt->post_rows, (uint64_t) tt->post_cap * indiv * sizeof (double));
       (void) pecall_dev_pin_host (pc, tt->type, (uint64_t) TILE);
       (void) pecall_dev_pin_host (pc, tt->ac, (uint64_t) TILE * NA * sizeof (int32_t));
       (void) pecall_dev_pin_host (pc, tt->denovo, (uint64_t) TILE * sizeof (int32_t));

@@ -25,6 +25,7 @@ class PecallDev:
         L.pecall_dev_run.argtypes = [vp, i, i, i, i, dbl, i]
         L.pecall_dev_collect.argtypes = [vp, i, i, vp, vp, vp]
         L.pecall_dev_call_sites.argtypes = [vp, vp, vp, vp, C.c_long, i, i, dbl, dbl, vp, vp, vp, vp, vp, vp]
+        L.pecall_dev_call_sites_sparse.argtypes = [vp, vp, vp, vp, C.c_long, i, i, dbl, dbl, vp, vp, vp, C.c_uint64, vp, vp, vp, vp, vp]
         L.pecall_dev_set_pedigree.argtypes = [vp, i, vp, vp, vp, vp, vp, dbl]
         L.pecall_dev_sites_stage.argtypes = [vp, vp, vp, vp, C.c_long, i]
         L.pecall_dev_sites_run.argtypes = [vp, i, dbl, dbl, C.POINTER(C.c_float)]
@@ -117,13 +118,38 @@ class PecallDev:
         self._ck(self.L.pecall_dev_unpin_host(self.h, a.ctypes.data))
 
     @staticmethod
-    def out_arrays(n_sites, indiv):
-        """the six result arrays of call_sites, touched (np.zeros leaves the pages to the first write)"""
-        out = (np.zeros((n_sites, indiv), np.int8), np.zeros((n_sites, indiv)), np.zeros(n_sites, np.int8), np.zeros((n_sites, ALLELES), np.int32),
+    def out_arrays(n_sites, indiv, posterior=True):
+        """the six result arrays of call_sites, touched (np.zeros leaves the pages to the first write); posterior=False: a token
+        array in its place (call_sites_sparse does not fill it)"""
+        out = (np.zeros((n_sites, indiv), np.int8), np.zeros((n_sites, indiv) if posterior else (1, 1)), np.zeros(n_sites, np.int8), np.zeros((n_sites, ALLELES), np.int32),
                np.zeros(n_sites, np.int8), np.zeros(n_sites, np.int32))
         for a in out:
             a.fill(0)
         return out
+
+    def call_sites_sparse(self, reads, ref_base, threshold=0.95, theta=0.001, haploid=False, chrom=None, cap=None, out=None, sparse_out=None):
+        """call_sites with the posteriors as a list (pecall_dev_call_sites_sparse): -> call, (post_site [k] ascending, post_rows [k][indiv]),
+        site_type, allele_count, n_pass; columns that are not listed have posterior 1 for every sample.  cap = rows the list may take
+        (default: one per 8 columns, at least 1024); out / sparse_out: arrays to reuse (out as for call_sites, its posterior unused)"""
+        reads = np.ascontiguousarray(reads, np.uint16)
+        ref_base = np.ascontiguousarray(ref_base, np.uint8)
+        n_sites, indiv = reads.shape[:2]
+        cy = None if chrom is None else np.ascontiguousarray(chrom, np.uint8)
+        call, _, typ, ac, npass, den = out if out is not None else self.out_arrays(n_sites, indiv, posterior=False)
+        if sparse_out is not None:
+            site, rows = sparse_out
+            cap = len(site)
+        else:
+            cap = int(cap) if cap is not None else max(1024, n_sites // 8)
+            site, rows = np.empty(cap, np.uint32), np.empty((cap, indiv), np.float64)
+        n = C.c_uint64(0)
+        self.denovo = den
+        self.sparse_needed = 0
+        rc = self.L.pecall_dev_call_sites_sparse(self.h, _p(reads), _p(ref_base), _p(cy), n_sites, indiv, int(haploid), float(threshold),
+                                                 float(theta), _p(call), _p(site), _p(rows), cap, C.byref(n), _p(typ), _p(ac), _p(npass), _p(den))
+        self.sparse_needed = int(n.value)
+        self._ck(rc)
+        return call, (site[:n.value], rows[:n.value]), typ, ac, npass
 
     def call_sites(self, reads, ref_base, threshold=0.95, theta=0.001, haploid=False, chrom=None, out=None):
         """the whole per-site caller (pecaller.c:1207-1691): reads [n_sites][indiv][6] u16, ref_base [n_sites] (0..3 = ACGT, else

@@ -24,7 +24,7 @@ SYMBOLS = [
     "pemap_dev_free", "pemap_dev_fetch_pileup", "pemap_dev_fetch_records", "pemap_dev_reset_pileup", "pemap_dev_summary",
     "pemap_dev_run_stats", "pemap_dev_debug_hits",
     "pecall_dev_create", "pecall_dev_destroy", "pecall_dev_last_error", "pecall_dev_site_like", "pecall_dev_stage",
-    "pecall_dev_run", "pecall_dev_collect", "pecall_dev_call_sites", "pecall_dev_set_pedigree",
+    "pecall_dev_run", "pecall_dev_collect", "pecall_dev_call_sites", "pecall_dev_call_sites_sparse", "pecall_dev_set_pedigree",
     "pecall_dev_sites_stage", "pecall_dev_sites_run", "pecall_dev_sites_collect", "pecall_dev_pin_host", "pecall_dev_unpin_host",
 ]
 

@@ -16,14 +16,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "pecaller_amd", "pecaller_hip")
 
 
-@pytest.mark.parametrize("tile_log2,threads", [(None, "2"), (None, "8"), ("10", "8")])
+@pytest.mark.parametrize("tile_log2,threads", [(None, "2"), (None, "8"), ("10", "8"), ("11", "4")])
 def test_pecaller_cli_outputs(tmp_path, tile_log2, threads, monkeypatch):
-    """(tile_log2 = 10: the stream merge and the device calls take the fixture's 6,000 positions in six ranges of 1,024 -- records
+    """(tile_log2 = 11 also sets PECALLER_POST_CAP=3: the list of the columns with a posterior that is not 1 is too short for every
+    tile, and the call is made again with the size the library asked for; tile_log2 = 10: the stream merge and the device calls take the fixture's 6,000 positions in six ranges of 1,024 -- records
     of a stream on both sides of a range boundary, streams without a record in a range, the last range partly empty; threads = 8:
     seven threads walk the 20 streams and format the rows, 2: one does)"""
     assert os.path.exists(EXE), "build with make -C pecaller_amd/csrc"
     if tile_log2:
         monkeypatch.setenv("PECALLER_TILE_LOG2", tile_log2)
+    if tile_log2 == "11":
+        monkeypatch.setenv("PECALLER_POST_CAP", "3")
     z = np.load(os.path.join(fx.GOLD, "pecall_sites.npz"))
     names = [str(x) for x in z["names"]]
     reads, pos, pad = z["reads"], z["pos"], int(z["pad"][0])

@@ -274,3 +274,58 @@ def test_gpu_site_caller_more_than_64_samples(n, ped):
         with pytest.raises(PemapError):
             dev.call_sites(np.zeros((4, 257, 6), np.uint16), dom[:4])
     dev.close()
+
+
+@pytest.mark.gpu
+def test_gpu_site_caller_sparse_posteriors():
+    """pecall_dev_call_sites_sparse: the same calls, types and allele counts as the dense call, and its list holds exactly the columns
+    in which the dense call has a posterior that is not 1, ascending, with the dense call's posteriors to the last bit -- on the
+    reference's fixture, on columns with samples too deep for the table's head (the second pass appends), with more than 64 samples,
+    through pinned and pageable buffers; a list that is too short fails and says how many rows are needed"""
+    from pecaller_amd.pecall import PecallDev
+    dev = PecallDev(0)
+
+    def check(reads, dom, **kw):
+        dense = dev.call_sites(reads, dom, **kw)
+        post = dense[1].copy()
+        call, (site, rows), typ, ac, npass = dev.call_sites_sparse(reads, dom, **kw)
+        assert np.array_equal(call, dense[0]) and np.array_equal(typ, dense[2]) and np.array_equal(ac, dense[3]) and np.array_equal(npass, dense[4])
+        want = np.nonzero((post != 1.0).any(axis=1))[0]
+        assert np.array_equal(site, want.astype(np.uint32)), (len(site), len(want))
+        assert np.array_equal(rows, post[want])
+        return len(want)
+
+    f = fx.load()
+    n1 = check(f["reads"], f["dom"])
+    assert n1 > 100
+    # deep columns: the head form defers them, the form with the whole table calls them in a second pass
+    rng = np.random.default_rng(12)
+    n_sites, n = 2500, 20
+    dom = rng.integers(0, 4, n_sites).astype(np.uint8)
+    depth = np.where(rng.random((n_sites, n)) < 0.03, rng.integers(1500, 9000, (n_sites, n)), rng.poisson(30, (n_sites, n)))
+    reads = np.zeros((n_sites, n, 6), np.int64)
+    idx = np.arange(n_sites)
+    alt = (dom + rng.integers(1, 4, n_sites)) % 4
+    is_var = rng.random(n_sites) < 0.05
+    for i in range(n):
+        dose = np.where(is_var, rng.binomial(2, 0.3, n_sites), 0)
+        err = rng.binomial(depth[:, i], 0.004)
+        ar = rng.binomial(depth[:, i] - err, dose / 2.0)
+        reads[idx, i, dom] += depth[:, i] - err - ar
+        reads[idx, i, alt] += ar
+        reads[idx, i, rng.integers(0, 4, n_sites)] += err
+    reads = np.minimum(reads, 65535).astype(np.uint16)
+    assert check(reads, dom) > 0
+    # a call right after it on shallow columns of the same shape: nothing of the deep call's posteriors is left in the list
+    shallow = np.minimum(reads, 40)
+    check(shallow, dom)
+    # more than 64 samples (every column through the beam search's kernel)
+    w = fx.load("pecall_wide")
+    check(w["reads"][:600], w["dom"][:600])
+    # a list that is too short
+    with pytest.raises(Exception) as e:
+        dev.call_sites_sparse(f["reads"], f["dom"], cap=8)
+    assert "list holds 8" in str(e.value) and dev.sparse_needed == n1
+    # and the object still works
+    check(f["reads"][:500], f["dom"][:500])
+    dev.close()
