@@ -156,7 +156,7 @@ struct pemap_dev
   unsigned long long *d_path, *d_path2;        // recorded traceback steps per winning alignment (two sets)
   uint16_t *d_nsteps, *d_nsteps2;
   int path_words, path_cap_ends;
-  hipEvent_t ev_alu_done[2], ev_walk_done[2];
+  hipEvent_t ev_walk_done[2];
   uint32_t *d_m1, *d_m2;
   int *d_mtype;
   int cap_out;
@@ -476,7 +476,6 @@ extern "C" void pemap_dev_destroy (pemap_dev * d)
         {
           hipEventDestroy (d->ev_lists_ready[i]);
           hipEventDestroy (d->ev_lists_free[i]);
-          hipEventDestroy (d->ev_alu_done[i]);
           hipEventDestroy (d->ev_walk_done[i]);
           hipFree (d->lists[i].hdr);
           hipFree (d->lists[i].key);
@@ -1419,7 +1418,6 @@ static int ensure_pipeline (pemap_dev * d, int chunk_ends)
         {
           HIPCHK (d, hipEventCreateWithFlags (&d->ev_lists_ready[i], hipEventDisableTiming));
           HIPCHK (d, hipEventCreateWithFlags (&d->ev_lists_free[i], hipEventDisableTiming));
-          HIPCHK (d, hipEventCreateWithFlags (&d->ev_alu_done[i], hipEventDisableTiming));
           HIPCHK (d, hipEventCreateWithFlags (&d->ev_walk_done[i], hipEventDisableTiming));
         }
       TRY (dev_alloc (d, &d->d_chunk_ctr, (size_t) PM_MAX_CHUNKS));
