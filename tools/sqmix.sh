@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for ctrs in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
   i=$((i+1))
-  rocprofv3 --pmc $ctrs --output-format csv -d $ROOT/gpurun_out/sqmix_$i -- python3 $ROOT/bench.py --steps 1 --warmup 1 --no-cpu --no-secondary --no-pecaller > $ROOT/gpurun_out/sqmix.log 2>&1 || { tail -3 $ROOT/gpurun_out/sqmix.log; exit 1; }
+  rocprofv3 --pmc $ctrs --output-format csv -d $ROOT/gpurun_out/sqmix_$i -- python3 $ROOT/bench.py --steps 1 --warmup 1 --no-cpu --no-secondary --no-pecaller --realistic-steps 0 > $ROOT/gpurun_out/sqmix.log 2>&1 || { tail -3 $ROOT/gpurun_out/sqmix.log; exit 1; }
 done
 cd $ROOT
 python3 - <<'PY'
