@@ -223,7 +223,7 @@ def test_gpu_site_caller_more_than_64_samples(n, ped):
     from pecaller_amd.pecall import PecallDev
     from pecaller_amd.pemap import PemapError
     rng = np.random.default_rng(300 + n)
-    n_sites = 400
+    n_sites = 400 if n <= 128 else 160          # (the CPU oracle's time grows faster than the sample count)
     dom = rng.integers(0, 4, n_sites).astype(np.uint8)
     dom[::53] = 14
     depth = rng.integers(12, 40, n)
