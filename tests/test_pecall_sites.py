@@ -269,7 +269,7 @@ def test_gpu_site_caller_more_than_64_samples(n, ped):
         assert np.array_equal(a, b)
     if pd:
         assert np.array_equal(gden, oracle_py.call_sites.denovo)
-    assert (got[2] > 0).sum() > 50 and got[4].max() >= 2
+    assert (got[2] > 0).sum() > n_sites // 8 and got[4].max() >= 2
     if n == 256:
         with pytest.raises(PemapError):
             dev.call_sites(np.zeros((4, 257, 6), np.uint16), dom[:4])
