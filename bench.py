@@ -536,8 +536,9 @@ def pmc_traffic(kernel, gsize, B, L, config="hg38_150"):
 def pecall_pmc_traffic(n):
     """HBM bytes of one resident run of the caller's kernels over the n columns, from profiles/r03_pecall_pmc.json (tools/profile_pecall.sh:
     separate --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pecall_kernel_time.py, 5 runs each) -- valid while the columns and the device
-    sources are the profiled ones.  The kernels stream their columns (coalesced 768-byte rows in, 600 bytes out): FETCH_SIZE / WRITE_SIZE are
-    taken as rocprofv3 reports them, in KB."""
+    sources are the profiled ones.  The kernels stream their columns (coalesced 768-byte rows in, 600 bytes out): WRITE_SIZE is taken as
+    rocprofv3 reports it (KB); FETCH_SIZE is DOUBLED, as MI355X_MICROARCH.md prescribes for coalesced streaming reads on gfx950 (128-byte
+    requests tallied at 64) -- the counter shows 395 bytes per column for rows of 770 bytes that the shortcut kernel reads whole."""
     path = os.path.join(ROOT, "profiles", "r03_pecall_pmc.json")
     try:
         pm = json.load(open(path))
@@ -549,11 +550,11 @@ def pecall_pmc_traffic(n):
     if pm.get("columns") != n:
         return None, "profiles/r03_pecall_pmc.json was taken on %s columns" % pm.get("columns")
     tot = 0.0
-    for cn in ("FETCH_SIZE", "WRITE_SIZE"):
+    for cn, factor in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
         for k, v in pm[cn].items():
             if k.startswith("pcs_"):
-                tot += v["mean_KB_per_launch"] * v["launches"] / pm.get("steps", 5)
-    return round(tot * 1024.0), "profiles/r03_pecall_pmc.json (device sources pecall_* %s)" % sha
+                tot += factor * v["mean_KB_per_launch"] * v["launches"] / pm.get("steps", 5)
+    return round(tot * 1024.0), "profiles/r03_pecall_pmc.json (device sources pecall_* %s; FETCH_SIZE x 2, the guide's correction for coalesced streams)" % sha
 
 
 def cpu_baseline(dev, a, B, leg, warmup):
