@@ -37,6 +37,9 @@
 // fetch: 4.3 ms per launch with 8 waves per CU alone on the GPU (6.65 with 5: per wave the kernel is latency-bound as before).
 #define PM_S3_GRAB 4            // consecutive read-ends a wave takes per fetch of the work counter
 #endif
+#ifndef PM_S3_CAP
+#define PM_S3_CAP PM_SEED_CAP   // positions a strand's list holds for reads of up to 160 bases
+#endif
 #ifndef PM_S3_BIGCAP
 #define PM_S3_BIGCAP 0          // 1: reads of up to 160 bases get the long reads' list capacity too (2,048 per strand, 256 near candidates)
 #endif
@@ -47,7 +50,7 @@ template < int SMAX > struct __align__ (16) PmSeed3Shared
   // positions a strand's list holds: 1,024 for reads of up to 160 bases (10 segments x 49 look-ups, most of them empty or single);
   // twice that for longer reads, whose 13..19 segments gather in proportion (2 x 250 bp: 5 % of the ends passed 1,024 and took the slow
   // monolithic kernel, half of that configuration's seed time)
-  static constexpr int CAP = (SMAX <= 10 && !PM_S3_BIGCAP) ? PM_SEED_CAP : 2 * PM_SEED_CAP;
+  static constexpr int CAP = (SMAX <= 10 && !PM_S3_BIGCAP) ? PM_S3_CAP : 2 * PM_SEED_CAP;
   // cells of the bin table and positions kept next to candidate anchors: more of both for the longer reads' fuller lists
   static constexpr int NH_LOG2 = SMAX <= 10 ? PM_S3_NH_LOG2 : PM_S3_NH_LOG2 + 1;
   static constexpr int NH = 1 << NH_LOG2;
