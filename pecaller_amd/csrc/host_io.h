@@ -103,8 +103,19 @@ gzsrc_open (gzsrc * g, const char *path, size_t block, int ring)
               return 0;
             }
         }
-      close (g->fd);
-      g->fd = -1;
+      /* not a regular file (a pipe, a FIFO) or not mappable: zlib reads the descriptor that is open already -- a second open of a
+         FIFO could find the writer gone.  (A mapped regular file that shrinks while it is read raises SIGBUS, not a read error.) */
+      g->mode = 0;
+      g->f = gzdopen (g->fd, "rb");
+      if (!g->f)
+        {
+          close (g->fd);
+          g->fd = -1;
+          return -1;
+        }
+      g->fd = -1;               /* (zlib's now: gzclose closes it) */
+      gzbuffer (g->f, 1 << 20);
+      return 0;
     }
   g->mode = 0;
   g->f = gzopen (path, "rb");

@@ -387,7 +387,11 @@ static int pcs_ensure (pecall_dev * d, long n_sites, int indiv)
     {
       hipFree (d->d_sreads); hipFree (d->d_dom); hipFree (d->d_chromy); hipFree (d->d_call); hipFree (d->d_type);
       hipFree (d->d_npass); hipFree (d->d_post); hipFree (d->d_ac); hipFree (d->d_den); hipFree (d->d_slow); hipFree (d->d_deep);
-      d->d_deep = nullptr;
+      // (nothing dangles if one of the allocations below fails: the next call allocates again, destroy frees nullptr)
+      d->d_sreads = nullptr; d->d_dom = nullptr; d->d_chromy = nullptr; d->d_call = nullptr; d->d_type = nullptr;
+      d->d_npass = nullptr; d->d_post = nullptr; d->d_ac = nullptr; d->d_den = nullptr; d->d_slow = nullptr; d->d_deep = nullptr;
+      d->cap_ssites = 0;
+      d->cap_sitems = 0;
       PCCHK (d, hipMalloc ((void **) &d->d_slow, (size_t) PCS_BUCKETS * n_sites * sizeof (unsigned)));
       PCCHK (d, hipMalloc ((void **) &d->d_deep, (size_t) n_sites * sizeof (unsigned)));
       PCCHK (d, hipMalloc ((void **) &d->d_sreads, items * PCS_NA * sizeof (uint16_t)));

@@ -322,6 +322,8 @@ typedef struct
      gwhich; the columns are appended to the tile from col0 on */
   int guide, gwhich;
   long col0;
+  /* out: the last slot at which one of this thread's streams, live when the walk began, came to its end (-1: none did) */
+  long end_slot;
 } merge_ctx;
 
 static size_t MG_CHUNK = 65536;        /* slots per work item of the column pass (<= TILE) */
@@ -352,11 +354,13 @@ merge_streams (void *arg)
   memset (mark, 0, TILE);
   if (c->guide && c->k == 0)
     memset (mark, 1, (size_t) (c->p1 - c->p0));
+  c->end_slot = -1;
   for (int i = c->k; i < c->no_files; i += c->T)
     {
       sample_t *s = &c->sm[i];
       uint16_t *plane = c->planes + (size_t) i * TILE * NA;
       size_t done = 0;          /* slots of the plane written so far */
+      const int live = s->cur != 0;
       if (c->guide)
         {
           /* records in front of the interval are passed over (pecaller.c:975-976); every position of the stretch counts as seen */
@@ -409,6 +413,14 @@ merge_streams (void *arg)
       if (!c->guide)
         s->base_count += n_rec;
       memset (plane + done * NA, 0, ((size_t) TILE - done) * NA * sizeof (uint16_t));
+      /* the stream ended inside this range: at the slot of its last record, or -- all its records lying in front of the range -- at
+         the range's first position, where the reference reads past them (pecaller.c:975-993) */
+      if (live && s->cur == 0)
+        {
+          const long at = done ? (long) done - 1 : 0;
+          if (at > c->end_slot)
+            c->end_slot = at;
+        }
     }
   return NULL;
 }
@@ -573,9 +585,7 @@ consumer_main (void *arg)
           if (rc && t->n_post > t->post_cap)
             {
               /* more columns with a posterior that is not 1 than the list holds (one per 8 columns to begin with): a list of the size
-                 the call asked for, not page-locked, and once more */
-              (void) pecall_dev_unpin_host (c->pc, t->post_site);
-              (void) pecall_dev_unpin_host (c->pc, t->post_rows);
+                 the call asked for, and once more */
               t->post_cap = t->n_post + t->n_post / 8 + 1024;
               t->post_site = (uint32_t *) realloc (t->post_site, t->post_cap * sizeof (uint32_t));
               t->post_rows = (double *) realloc (t->post_rows, t->post_cap * (size_t) c->indiv * sizeof (double));
@@ -946,8 +956,7 @@ main (int argc, char *argv[])
       (void) pecall_dev_pin_host (pc, tt->ref_base, (uint64_t) TILE);
       (void) pecall_dev_pin_host (pc, tt->chrom, (uint64_t) TILE);
       (void) pecall_dev_pin_host (pc, tt->call, (uint64_t) TILE * indiv);
-      (void) pecall_dev_pin_host (pc, tt->post_site, (uint64_t) tt->post_cap * sizeof (uint32_t));
-      (void) pecall_dev_pin_host (pc, tt->post_rows, (uint64_t) tt->post_cap * indiv * sizeof (double));
+      /* (the list of posteriors is filled by the library with plain copies: not page-locked, so that it can be re-allocated freely) */
       (void) pecall_dev_pin_host (pc, tt->type, (uint64_t) TILE);
       (void) pecall_dev_pin_host (pc, tt->ac, (uint64_t) TILE * NA * sizeof (int32_t));
       (void) pecall_dev_pin_host (pc, tt->denovo, (uint64_t) TILE * sizeof (int32_t));
@@ -1101,6 +1110,30 @@ main (int argc, char *argv[])
               mc[k].col0 = t.n;
             }
           run_threads (merge_streams, mc, MT);
+          /* The reference's loop runs while a stream is open (pecaller.c:952): the column at which the last stream ends is the last one.
+             The walk above went over the whole stretch: cut it there, and take the positions behind the cut out of every stream's
+             count of positions seen again. */
+          {
+            int still = 0;
+            for (int i = 0; i < no_files; i++)
+              still += sm[i].cur != 0;
+            if (still == 0)
+              {
+                long last = 0;
+                for (int k = 0; k < MT; k++)
+                  if (mc[k].end_slot > last)
+                    last = mc[k].end_slot;
+                const unsigned long long keep = (unsigned long long) last + 1;
+                if (keep < n)
+                  {
+                    memset (marks + keep, 0, (size_t) (n - keep));
+                    for (int i = 0; i < no_files; i++)
+                      sm[i].base_count -= (unsigned int) (n - keep);
+                    n = keep;
+                  }
+                running = 0;
+              }
+          }
           run_threads (merge_count, mc, MT);
           long ncol = 0;
           for (size_t ch = 0; ch < TILE / MG_CHUNK; ch++)
@@ -1113,7 +1146,7 @@ main (int argc, char *argv[])
           t.n += ncol;
           tot_bases += (unsigned int) ncol;
           lowest += (unsigned int) n;
-          if (lowest > gend && !next_guide_interval (guide_file, contig_names, no_contigs, frag_pos, &gwhich, &lowest, &gend))
+          if (running > 0 && lowest > gend && !next_guide_interval (guide_file, contig_names, no_contigs, frag_pos, &gwhich, &lowest, &gend))
             running = 0;
         }
       else if (running > 0)

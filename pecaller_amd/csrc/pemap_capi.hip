@@ -136,6 +136,9 @@ struct pemap_dev
   uint32_t *d_counts;           // the pileup counter planes (PmPile): 6 planes of pile_plane_words words
   size_t pile_plane_words;
   bool rest_on_alu;
+  // each chunk's seed-stage remainder (big read-ends + emit) is enqueued exactly once: checked in launch_vote (the round-3 fault)
+  uint64_t run_serial, rest_id[2];
+  bool rest_twice;
   // params
   int paired, min_dist, max_dist, bisulfite;
   double min_align;
@@ -1160,6 +1163,18 @@ static void launch_vote (pemap_dev * d, const RunCtx & c, bool split, int slot, 
   const int n_ends = c.b.n_ends;
   PmCounters *ctr = &cc->c;
   const int phase_limit = d->kn.seed_phase;  // timing probe, 0 unless built with -DPEMAP_TIMING_PROBES
+  if (part != 1)
+    {
+      // The remainder appends to the chunk's task lists and uses the one spill scratch: a second launch for the same chunk doubles the
+      // appended tasks past the lists' ends (the fault PEMAP_REST_STREAM3=1 produced in round 3).  Refused here, reported by run_slice.
+      const uint64_t id = (d->run_serial << 24) | (uint64_t) (cc - d->d_chunk_ctr);
+      if (d->rest_id[slot & 1] == id)
+        {
+          d->rest_twice = true;
+          return;
+        }
+      d->rest_id[slot & 1] = id;
+    }
   if (part != 2)
     {
       hipLaunchKernelGGL (pm_nop_kernel, dim3 (1), dim3 (1), 0, st);
@@ -1566,6 +1581,7 @@ static int run_slice (pemap_dev * d, int first, int n, int sync, const hipEvent_
       d->last_big = 0;
       d->run_ends = 0;
     }
+  d->run_serial++;
   d->run_first = first;
   d->run_n = n;
   d->run_ends += (uint64_t) n * per;
@@ -1679,6 +1695,8 @@ static int run_slice (pemap_dev * d, int first, int n, int sync, const hipEvent_
       if (split && !d->serial_split && k + 2 < nch)
         TRY (enqueue_lookup (k + 2));
     }
+  if (d->rest_twice)
+    return fail (d, "internal: the seed-stage remainder of a chunk was enqueued twice");
   d->run_pending = true;
   if (sync)
     {

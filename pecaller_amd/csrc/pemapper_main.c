@@ -931,7 +931,7 @@ main (int argc, char *argv[])
     }
 
   char basename[1024];
-  strncpy (basename, argv[1], 1000);
+  snprintf (basename, sizeof basename, "%s", argv[1]);
   /* workers: a file pair keeps ~4 host threads busy (two inflate threads, two line scans); at most 8 files at a time */
   int n_workers = c.io_threads / 3;
   if (n_workers > 8)
@@ -972,7 +972,7 @@ main (int argc, char *argv[])
               dump_output (&c, basename, pool.tot_pairs);
               pool.tot_pairs = 0;
             }
-          strncpy (basename, outs[iter], 1000);
+          snprintf (basename, sizeof basename, "%s", outs[iter]);
         }
       /* the files that follow with the same output name (all of them, for the plain pemapper): one output set */
       int last = iter + 1;

@@ -240,3 +240,50 @@ def test_pecaller_cli_guide_mode(tmp_path, range_min, monkeypatch):
             assert dict(zip(got_d[0][1:], g[1:])) == dict(zip(exp_d[0][1:], e[1:])), g[0]
     if cols == f["columns"]:
         assert rows == f["base_rows"] and srows == f["snp_rows"]
+
+
+@pytest.mark.parametrize("range_min", [None, "64"])
+def test_pecaller_cli_guide_mode_ends_with_the_last_stream(tmp_path, range_min, monkeypatch):
+    """the BED goes on behind the last record of every pileup stream: the reference's loop runs while a stream is open
+    (pecaller.c:952), so the column at which the last stream ends is the last row and <out>.dist counts the positions up to it --
+    through the per-column scan and through the parallel walk of a stretch (range_min = 64), which has to cut the stretch there.
+    Fixture: tests/golden/make_golden_pecall_guide_end.py (the unmodified reference on the guide fixture's records up to chrMT:300)"""
+    import json
+    if range_min:
+        monkeypatch.setenv("PECALLER_GUIDE_RANGE_MIN", range_min)
+        monkeypatch.setenv("PECALLER_TILE_LOG2", "10")
+    cut = json.load(open(os.path.join(fx.GOLD, "pecall_guide_end.json")))["cut"]
+    z = np.load(os.path.join(fx.GOLD, "pecall_guide.npz"))
+    lens, cn, _ = refio.read_sdx(os.path.join(fx.GOLD, "pecall_guide.sdx"))
+    starts = np.concatenate([[0], np.cumsum(np.array(lens) + 15)])
+    limit = int(starts[cn.index("chrMT")]) + cut - 1
+    _, seqs = refio.read_fasta(os.path.join(fx.GOLD, "g1.fa.gz"))
+    shutil.copy(os.path.join(fx.GOLD, "pecall_guide.sdx"), tmp_path / "g1.sdx")
+    with gzip.open(tmp_path / "g1.seq", "wb", compresslevel=1) as fh:
+        fh.write(np.concatenate(seqs).tobytes())
+    run = tmp_path / "run"
+    run.mkdir()
+    for s, nm in enumerate([str(x) for x in z["names"]]):
+        recs = [struct.pack("<I6H", int(z["pos"][i]), *[int(x) for x in z["reads"][i, s]]) for i in range(len(z["pos"]))
+                if z["reads"][i, s].sum() > 0 and int(z["pos"][i]) <= limit]
+        with gzip.open(run / ("%s.pileup.gz" % nm), "wb", compresslevel=1) as fh:
+            fh.write(b"".join(recs))
+    subprocess.check_call([EXE, "pileup", str(tmp_path / "g1.sdx"), "20", "out", "0.95", "0.001", "n", "2", "n", os.path.join(fx.GOLD, "pecall_guide.bed")],
+                          cwd=run, stdout=subprocess.DEVNULL)
+    base = gzip.open(run / "out.base.gz", "rt").read().split("\n")
+    exp = gzip.open(os.path.join(fx.GOLD, "pecall_guide_end.base.txt.gz"), "rt").read().split("\n")
+    cols = [c for c in base[0].split("\t")[3:] if c]
+    ecols = [c for c in exp[0].split("\t")[3:] if c]
+    got_keys = sorted((x.split("\t")[0], int(x.split("\t")[1])) for x in base[1:] if x)
+    exp_keys = sorted((x.split("\t")[0], int(x.split("\t")[1])) for x in exp[1:] if x)
+    assert got_keys == exp_keys                                 # 902 rows, the last one chrMT:300
+    assert max(p for c, p in got_keys if c == "chrMT") == cut
+    if cols == ecols:
+        assert sorted(x for x in base[1:] if x) == [x for x in exp[1:] if x]
+    got_d = [x.split("\t") for x in open(run / "out.dist").read().split("\n")]
+    exp_d = [x.split("\t") for x in open(os.path.join(fx.GOLD, "pecall_guide_end.dist.txt")).read().split("\n")]
+    assert len(got_d) == len(exp_d)
+    for g, e in zip(got_d, exp_d):
+        assert g[0] == e[0]
+        if len(g) > 1:
+            assert dict(zip(got_d[0][1:], g[1:])) == dict(zip(exp_d[0][1:], e[1:])), g[0]

@@ -57,8 +57,9 @@ def test_gpu_site_caller_matches_reference_text_and_oracle(tag):
         exp = f["base_rows"].get(pos1)
         if exp is not None and fx.base_row("chr1", pos1, chr(f["ref"][i]), call[i], p[i]) != exp:
             bad.append((pos1, exp))
-    # %g prints six significant digits: a posterior may differ from the CPU's in the last bits (device exp / pow)
-    assert len(bad) <= 2, bad[:3]
+    # every row as the reference printed it (%g, six significant digits): the device's posteriors have been bit-equal to the CPU's on
+    # every column compared so far (bench.py: max_abs_dposterior 0.0 over 1.8 M columns)
+    assert not bad, bad[:3]
     dev.close()
 
 
