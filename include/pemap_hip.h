@@ -174,12 +174,13 @@ int pemap_dev_summary (pemap_dev * dev, long *out13);
  * stats[0] = read-ends, [1] = positions gathered from .mdx (P), [2] = SW problems scored (H), [3] = SW problems
  * scored with direction nibbles (single-hit ends + re-scored winners), [4] = DP cells without nibbles, [5] = DP cells
  * with nibbles, [6] = pileup increments, [7] = insertions logged, [8] = alignments walked back, [9] = winners re-scored,
- * [10] = read-ends with a strand of more than 1024 positions (handled by the monolithic seed kernel),
+ * [10] = read-ends the fused seed kernel's first tier passed over (more positions than its list holds, or too many next to candidate
+ *        anchors): taken by its second tier; [15] = of them, the ones left to the monolithic seed kernel,
  * [11] = chunks the run was cut into (= launches of every kernel),
  * [12] = problems decided without the DP (a diagonal with at most one mismatch; with PEMAP_GAPLESS=0 none):
  *        [3], [5] count the DP's share only.
  * [13] = problems scored by the DP restricted to a band of 32 diagonals (exact for them: pemap_band.hip.h), part of [2] and,
- *        for the single-hit ends, of [3]; [14] = band cells computed (not part of [4], [5]); [15] reserved.
+ *        for the single-hit ends, of [3]; [14] = band cells computed (not part of [4], [5]).
  * times_ms[0..7] = seed stage (look-up + vote), SW single-hit (with nibbles), SW multi-hit, select, SW re-score,
  * walk+pileup, look-up kernel alone, vote kernel alone (the list-mode remainder of the big read-ends and the emit kernel count
  * towards [0] only): kernel durations from HIP events on the object's streams, summed over the run's chunks (the streams of

@@ -73,6 +73,7 @@ struct PmKnobs
   int gapless_blocks_per_cu;
   int band, band_waves_per_cu;  // the banded DP (pm_band_kernel) for the problems it is exact for; its waves per CU
   int seed_phase;               // always 0 without PEMAP_TIMING_PROBES
+  int tier2_waves;              // persistent waves per CU of the fused seed kernel's second tier (the first tier's big-end list)
 };
 
 static int env_int (const char *name, int dflt)
@@ -95,6 +96,7 @@ static void read_knobs (PmKnobs & k)
   { const char *e = getenv ("PEMAP_DIR_BUDGET_GB"); k.dir_budget_gb = e ? atof (e) : 40.0; if (k.dir_budget_gb < 0.25) k.dir_budget_gb = 0.25; }
   k.lookup_waves = env_int ("PEMAP_LOOKUP_WAVES", -1);
   k.lookup_prio = env_int ("PEMAP_LOOKUP_PRIO", 0);
+  k.tier2_waves = env_int ("PEMAP_TIER2_WAVES", 3);
   k.vote_prio = env_int ("PEMAP_VOTE_PRIO", 0);
   k.sw_prio = env_int ("PEMAP_SW_PRIO", 0);
   k.vote_waves = env_int ("PEMAP_VOTE_WAVES", 1024);
@@ -192,7 +194,7 @@ struct pemap_dev
   PmChunkCtr *d_chunk_ctr;
   std::vector < hipEvent_t > evs;
   int big_grid, scratch_blocks;
-  uint64_t last_big;
+  uint64_t last_big, last_big2;  // read-ends the fused seed kernel's first tier passed over; of them, left to the monolithic kernel
   PmCounters last_ctr;          // summed over the chunks of the last run
   PmInsCursor last_cur;
   // batches in flight
@@ -1083,6 +1085,8 @@ struct PmChunkCtr
   unsigned long long positions;
   unsigned n_big;
   unsigned next_end;            // work counter of the persistent look-up waves
+  unsigned n_big2;              // read-ends the second tier of the fused seed kernel leaves to the monolithic kernel
+  unsigned next_end2;           // the second tier's work counter
 };
 
 #define PM_MAX_CHUNKS 256
@@ -1115,14 +1119,37 @@ static void launch_lookup (pemap_dev * d, const RunCtx & c, int slot, PmChunkCtr
   // PEMAP_LOOKUP_WAVES=n: n persistent one-wave workgroups per CU.  Default 7 of the 8 the fused kernel's LDS admits.  With the other
   // stream's kernels in one-wave workgroups (round 3) the step follows the seed kernel: 12 steps of the default workload take
   // 26.4 / 25.1 / 25.0 ms each on resident reads with 6 / 7 / 8, 27.8 / 27.4 / 27.9 at the seam (profiles/r03_ab_sweeps.txt)
-  const int lw = d->kn.lookup_waves > 0 ? d->kn.lookup_waves : 7;
+  int lw = d->kn.lookup_waves > 0 ? d->kn.lookup_waves : 7;
+  if (c.ix.n_rep == 8)
+    {
+      // (no more workgroups than are resident at once: a workgroup owns its first ends by its number, and one that starts when
+      // another ends -- at the launch's end -- would be the launch's tail)
+      size_t lds = 0;
+      int per_simd = 2;
+      switch (seg_template (c.L))
+        {
+        case 7: lds = sizeof (PmSeed4Shared < 7, 0 >); per_simd = PM_S4_WAVES_PER_EU; break;
+        case 10: lds = sizeof (PmSeed4Shared < 10, 0 >); per_simd = PM_S4_WAVES_PER_EU; break;
+        case 13: lds = sizeof (PmSeed4Shared < 13, 0 >); break;
+        case 16: lds = sizeof (PmSeed4Shared < 16, 0 >); break;
+        default: lds = sizeof (PmSeed4Shared < 19, 0 >); break;
+        }
+      const int fit = (int) ((size_t) 160 * 1024 / lds);
+      if (lw > fit)
+        lw = fit;
+      if (lw > 4 * per_simd)
+        lw = 4 * per_simd;
+    }
   int lgrid = lw * d->n_cus;
   if (lgrid > c.b.n_ends)
     lgrid = c.b.n_ends;
   const int lprio = d->kn.lookup_prio;
   const bool set2 = split && slot;
   const PmHits & H = set2 ? d->hits2 : d->hits;
-#define PM_LK(SM) do { if (c.ix.n_rep == 8) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_seed3_kernel < SM >), dim3 (lgrid), dim3 (64), sizeof (PmSeed3Shared < SM >), st, c.ix, c.b, c.prm, H, L, lprio); \
+  // the fused seed kernel (pm_seed4_kernel, tier 0) ...
+#define PM_LK(SM) do { if (c.ix.n_rep == 8) \
+      hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_seed4_kernel < SM, 0 >), dim3 (lgrid), dim3 (64), sizeof (PmSeed4Shared < SM, 0 >), st, c.ix, c.b, c.prm, H, L, \
+                          (const uint32_t *) nullptr, (const unsigned *) nullptr, lprio); \
     else hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_lookup_wave_kernel < SM, 4 >), dim3 (lgrid), dim3 (64), 0, st, c.ix, c.b, c.prm, L, lprio); } while (0)
   switch (seg_template (c.L))
     {
@@ -1134,6 +1161,27 @@ static void launch_lookup (pemap_dev * d, const RunCtx & c, int slot, PmChunkCtr
     }
 #undef PM_LK
   hipEventRecord (ev[1], st);
+  if (pm_fused (d))
+    {
+      // ... then its second tier over the ends it passed over: the same kernel with four times the list (twice, for reads over 160
+      // bases), a few waves per CU -- most launches find a few thousand ends; what THAT leaves goes to the monolithic kernel (launch_vote)
+      PmLists L2 = L;
+      L2.big_list = L.big_list + d->lists_cap;
+      L2.n_big = &cc->n_big2;
+      L2.next_end = &cc->next_end2;
+      const int grid2 = d->kn.tier2_waves * d->n_cus;
+#define PM_LK2(SM) hipLaunchKernelGGL (HIP_KERNEL_NAME (pm_seed4_kernel < SM, 1 >), dim3 (grid2), dim3 (64), sizeof (PmSeed4Shared < SM, 1 >), st, c.ix, c.b, c.prm, \
+                                       H, L2, (const uint32_t *) L.big_list, (const unsigned *) L.n_big, lprio)
+      switch (seg_template (c.L))
+        {
+        case 7: PM_LK2 (7); break;
+        case 10: PM_LK2 (10); break;
+        case 13: PM_LK2 (13); break;
+        case 16: PM_LK2 (16); break;
+        default: PM_LK2 (19); break;
+        }
+#undef PM_LK2
+    }
   if (pm_fused (d))
     {
       // the vote is part of the kernel: its interval is empty
@@ -1154,7 +1202,7 @@ static bool pm_vote_rest_on_alu (const pemap_dev * d)
   return d->rest_on_alu;        // set per run (run_slice)
 }
 
-// part 0: the whole stage; 1: the vote kernel only; 2: what follows it
+// part 0: the whole stage; 1: the vote kernel only; 2: what follows it; 3: of that, the list-mode remainder only; 4: the emit kernel only
 static void launch_vote (pemap_dev * d, const RunCtx & c, bool split, int slot, PmChunkCtr * cc, hipEvent_t * ev, hipStream_t st, int part = 0)
 {
   const bool set2 = split && slot;
@@ -1163,7 +1211,7 @@ static void launch_vote (pemap_dev * d, const RunCtx & c, bool split, int slot, 
   const int n_ends = c.b.n_ends;
   PmCounters *ctr = &cc->c;
   const int phase_limit = d->kn.seed_phase;  // timing probe, 0 unless built with -DPEMAP_TIMING_PROBES
-  if (part != 1)
+  if (part != 1 && part != 4)
     {
       // The remainder appends to the chunk's task lists and uses the one spill scratch: a second launch for the same chunk doubles the
       // appended tasks past the lists' ends (the fault PEMAP_REST_STREAM3=1 produced in round 3).  Refused here, reported by run_slice.
@@ -1175,15 +1223,23 @@ static void launch_vote (pemap_dev * d, const RunCtx & c, bool split, int slot, 
         }
       d->rest_id[slot & 1] = id;
     }
-  if (part != 2)
+  if (part < 2)
     {
       hipLaunchKernelGGL (pm_nop_kernel, dim3 (1), dim3 (1), 0, st);
       hipEventRecord (ev[2], st);
     }
-  if (split)
+  if (part == 4)
+    ;
+  else if (split)
     {
       PmLists L = d->lists[slot];
       L.n_big = &cc->n_big;
+      if (pm_fused (d))
+        {
+          // (the fused seed kernel's second tier has taken most of the first tier's list: the monolithic kernel gets what it left)
+          L.big_list += d->lists_cap;
+          L.n_big = &cc->n_big2;
+        }
       L.positions = &cc->positions;
       // PEMAP_VOTE_WAVES=n: at most n one-wave workgroups per CU, each striding over the ends.  Default 1024 = one wave per end: the
       // dispatcher then places vote waves wherever the look-up and SW waves of the other stream leave room (measured 71.6 ms per
@@ -1201,11 +1257,11 @@ static void launch_vote (pemap_dev * d, const RunCtx & c, bool split, int slot, 
       switch (seg_template (c.L))
         {
         // ev[2]..ev[3] = the vote kernel alone; the list-mode remainder and the emit kernel end at ev[10]
-        case 7: if (part != 2) { PM_VT (7); hipEventRecord (ev[3], st); } if (part != 1) PM_SEEDL (7); break;
-        case 10: if (part != 2) { PM_VT (10); hipEventRecord (ev[3], st); } if (part != 1) PM_SEEDL (10); break;
-        case 13: if (part != 2) { PM_VT (13); hipEventRecord (ev[3], st); } if (part != 1) PM_SEEDL (13); break;
-        case 16: if (part != 2) { PM_VT (16); hipEventRecord (ev[3], st); } if (part != 1) PM_SEEDL (16); break;
-        default: if (part != 2) { PM_VT (19); hipEventRecord (ev[3], st); } if (part != 1) PM_SEEDL (19); break;
+        case 7: if (part < 2) { PM_VT (7); hipEventRecord (ev[3], st); } if (part != 1) PM_SEEDL (7); break;
+        case 10: if (part < 2) { PM_VT (10); hipEventRecord (ev[3], st); } if (part != 1) PM_SEEDL (10); break;
+        case 13: if (part < 2) { PM_VT (13); hipEventRecord (ev[3], st); } if (part != 1) PM_SEEDL (13); break;
+        case 16: if (part < 2) { PM_VT (16); hipEventRecord (ev[3], st); } if (part != 1) PM_SEEDL (16); break;
+        default: if (part < 2) { PM_VT (19); hipEventRecord (ev[3], st); } if (part != 1) PM_SEEDL (19); break;
         }
 #undef PM_VT
 #undef PM_SEEDL
@@ -1230,7 +1286,7 @@ static void launch_vote (pemap_dev * d, const RunCtx & c, bool split, int slot, 
         }
 #undef PM_SEED
     }
-  if (part == 1)
+  if (part == 1 || part == 3)
     return;
   hipLaunchKernelGGL (pm_emit_kernel, dim3 ((n_ends + 63) / 64), dim3 (64), 0, st, c.ix, c.b, H, tasks_s, tasks_m, ctr);
   if (!split)
@@ -1257,7 +1313,7 @@ template < int W, int LPA > static void launch_chunk (pemap_dev * d, const RunCt
       // the seed stage ran on the look-up's stream (enqueue_lookup); PEMAP_VOTE_REST_ON_ALU=1 leaves the big read-ends' remainder
       // and the emit kernel to this stream
       if (pm_vote_rest_on_alu (d) && !d->serial_split)
-        launch_vote (d, c, split, slot, cc, ev, d->stream, 2);
+        launch_vote (d, c, split, slot, cc, ev, d->stream, 4);
     }
   else if (!(split && d->vote_on_mem))
     launch_vote (d, c, split, slot, cc, ev, d->stream);
@@ -1401,6 +1457,7 @@ static int absorb_run (pemap_dev * d)
       t.pile_incs += c.pile_incs;
       t.n_ins += c.n_ins;
       d->last_big += hc[k].n_big;
+      d->last_big2 += hc[k].n_big2;
       hipEvent_t *ev = &d->evs[(size_t) k * PM_NEV];
       float ms = 0.f;
       if (d->run_split && hipEventElapsedTime (&ms, ev[0], ev[1]) == hipSuccess)
@@ -1465,7 +1522,8 @@ static int ensure_pipeline (pemap_dev * d, int chunk_ends)
           TRY (dev_alloc (d, &d->lists[i].hdr, list_ends));
           TRY (dev_alloc (d, &d->lists[i].key, list_ends * 2 * PM_SEED_CAP));
           TRY (dev_alloc (d, &d->lists[i].seg, list_ends * 2 * PM_SEED_CAP));
-          TRY (dev_alloc (d, &d->lists[i].big_list, (size_t) chunk_ends));
+          // (first half: the ends the fused seed kernel passes over; second half: what its second tier leaves of them)
+          TRY (dev_alloc (d, &d->lists[i].big_list, 2 * (size_t) chunk_ends));
         }
       d->lists_arrays = !pm_fused (d);
       d->lists_cap = chunk_ends;
@@ -1578,7 +1636,7 @@ static int run_slice (pemap_dev * d, int first, int n, int sync, const hipEvent_
     {
       memset (&d->last_ctr, 0, sizeof (d->last_ctr));
       memset (d->last_ms, 0, sizeof (d->last_ms));
-      d->last_big = 0;
+      d->last_big = d->last_big2 = 0;
       d->run_ends = 0;
     }
   d->run_serial++;
@@ -1625,8 +1683,10 @@ static int run_slice (pemap_dev * d, int first, int n, int sync, const hipEvent_
         if (g >= 2 && !d->serial_split)
           HIPCHK (d, hipStreamWaitEvent (fs, d->ev_walk_done[slot], 0));
         launch_lookup (d, cl, slot, d->d_chunk_ctr + g, &d->evs[(size_t) g * PM_NEV], true);
-        if (!(pm_vote_rest_on_alu (d) && !d->serial_split))
-          launch_vote (d, cl, true, slot, d->d_chunk_ctr + g, &d->evs[(size_t) g * PM_NEV], fs, 2);
+        // the monolithic kernel for what both tiers passed over: 256-thread workgroups with 31 KB of LDS, which find no room beside the
+        // next chunk's persistent seed waves -- here, between two seed launches, they do (and mostly find nothing to do).  The emit
+        // kernel goes to the ALU stream in front of the chunk's DP (rest_on_alu), or follows here
+        launch_vote (d, cl, true, slot, d->d_chunk_ctr + g, &d->evs[(size_t) g * PM_NEV], fs, (pm_vote_rest_on_alu (d) && !d->serial_split) ? 3 : 2);
         HIPCHK (d, hipEventRecord (d->ev_lists_ready[slot], fs));
         return 0;
       }
@@ -2202,7 +2262,7 @@ extern "C" int pemap_dev_run_stats (pemap_dev * d, uint64_t * s, float *t)
       s[12] = ((uint64_t) c.n_tasks_s - c.n_tasks_dp - c.n_band[0]) + ((uint64_t) c.n_tasks_m - c.sw_next[3] - c.n_band[1]);
       s[13] = (uint64_t) c.n_band[0] + c.n_band[1];
       s[14] = c.cells_band;
-      s[15] = 0;
+      s[15] = d->last_big2;
     }
   if (t)
     memcpy (t, d->last_ms, sizeof (d->last_ms));

@@ -20,6 +20,7 @@
 // to the big-end list and through pm_seed_kernel in list mode, as before.
 #pragma once
 #include <type_traits>
+#include "pemap_wave.hip.h"
 
 #ifndef PM_S3_NH_LOG2
 #define PM_S3_NH_LOG2 11
@@ -106,53 +107,6 @@ template < int SMAX > __device__ __forceinline__ uint32_t pm_s3_mask_get (const 
   if (SMAX <= 16)
     return (tab[h >> 1] >> (16u * (h & 1u))) & 0xFFFFu;
   return tab[h];
-}
-
-__device__ __forceinline__ int pm_lanes_below (unsigned long long m)
-{
-  return (int) __builtin_amdgcn_mbcnt_hi ((unsigned) (m >> 32), __builtin_amdgcn_mbcnt_lo ((unsigned) m, 0u));
-}
-
-// Wave-wide scan / reduction on the DPP path (row shifts inside the 16-lane rows, then the row broadcasts of gfx9): six VALU
-// instructions, against six round trips through the LDS crossbar (~100 cycles each, queued behind the wave's other LDS traffic)
-// for the __shfl forms.  Lanes without a source lane take `ident`.
-template < int CTRL, int ROW_MASK > __device__ __forceinline__ int pm_dpp_or (int ident, int v)
-{
-  return __builtin_amdgcn_update_dpp (ident, v, CTRL, ROW_MASK, 0xF, false);
-}
-
-__device__ __forceinline__ uint32_t pm_wave_incl_sum (uint32_t v)       // inclusive prefix sum over the lanes; lane 63 = the total
-{
-  v += (uint32_t) pm_dpp_or < 0x111, 0xF > (0, (int) v);        // row_shr:1
-  v += (uint32_t) pm_dpp_or < 0x112, 0xF > (0, (int) v);        // row_shr:2
-  v += (uint32_t) pm_dpp_or < 0x114, 0xF > (0, (int) v);        // row_shr:4
-  v += (uint32_t) pm_dpp_or < 0x118, 0xF > (0, (int) v);        // row_shr:8
-  v += (uint32_t) pm_dpp_or < 0x142, 0xA > (0, (int) v);        // row_bcast:15 into rows 1 and 3
-  v += (uint32_t) pm_dpp_or < 0x143, 0xC > (0, (int) v);        // row_bcast:31 into rows 2 and 3
-  return v;
-}
-
-__device__ __forceinline__ int pm_wave_incl_max (int v)       // inclusive prefix maximum of non-negative values
-{
-  v = max (v, pm_dpp_or < 0x111, 0xF > (0, v));
-  v = max (v, pm_dpp_or < 0x112, 0xF > (0, v));
-  v = max (v, pm_dpp_or < 0x114, 0xF > (0, v));
-  v = max (v, pm_dpp_or < 0x118, 0xF > (0, v));
-  v = max (v, pm_dpp_or < 0x142, 0xA > (0, v));
-  v = max (v, pm_dpp_or < 0x143, 0xC > (0, v));
-  return v;
-}
-
-__device__ __forceinline__ int pm_wave_min (int v)      // the minimum over the wave (uniform)
-{
-  const int big = 0x7FFFFFFF;
-  v = min (v, pm_dpp_or < 0x111, 0xF > (big, v));
-  v = min (v, pm_dpp_or < 0x112, 0xF > (big, v));
-  v = min (v, pm_dpp_or < 0x114, 0xF > (big, v));
-  v = min (v, pm_dpp_or < 0x118, 0xF > (big, v));
-  v = min (v, pm_dpp_or < 0x142, 0xA > (big, v));
-  v = min (v, pm_dpp_or < 0x143, 0xC > (big, v));
-  return __builtin_amdgcn_readlane (v, 63);
 }
 
 // LDS is passed as dynamic shared memory (sizeof (PmSeed3Shared < SMAX >)): from a static 30 KB the compiler concludes that two waves

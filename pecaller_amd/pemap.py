@@ -298,7 +298,7 @@ class PemapDev:
         s = np.zeros(16, np.uint64)
         t = np.zeros(8, np.float32)
         self._ck(self.L.pemap_dev_run_stats(self.h, _p(s), _p(t)))
-        keys = ["ends", "positions", "sw_score", "sw_dirs", "cells_score", "cells_dirs", "pile_incs", "n_ins", "walks", "redo", "big_ends", "chunks", "gapless", "banded", "cells_band", "reserved"]
+        keys = ["ends", "positions", "sw_score", "sw_dirs", "cells_score", "cells_dirs", "pile_incs", "n_ins", "walks", "redo", "big_ends", "chunks", "gapless", "banded", "cells_band", "mono_ends"]
         tk = ["seed", "sw_single", "sw_multi", "select", "sw_redo", "walk", "lookup", "vote"]
         return dict(zip(keys, (int(x) for x in s))), dict(zip(tk, (float(x) for x in t)))
 
