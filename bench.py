@@ -58,7 +58,7 @@ def sw_geometry(L):
 
 def lookup_kernel_name(n_rep):
     """the kernel that serves the look-ups: with the 8 table replicas the fused look-up + vote kernel"""
-    return "pm_seed3_kernel" if n_rep else "pm_lookup_wave_kernel"
+    return "pm_seed4_kernel" if n_rep else "pm_lookup_wave_kernel"
 
 
 def mapper_leg(dev, a, L, B, steps, warmup, rank, world, barrier, allmax, indel_read_frac=0.0, seed_off=7, seam=True):
@@ -504,14 +504,14 @@ def kernel_sources_sha(prefix=""):
 
 def pmc_traffic(kernel, gsize, B, L, config="hg38_150"):
     """HBM bytes per launch of `kernel` (or, kernel=None, per step over all kernels) from the committed rocprofv3 PMC passes
-    (separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, profiles/r03_bench_pmc_<config>.json, written by
+    (separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, profiles/r04_bench_pmc_<config>.json, written by
     tools/profile.sh with the sha1 of the device sources it ran), valid for the default workload only -- and only while the kernels
     are the ones profiled: a different sha gives None and says so.  FETCH_SIZE is taken at face value: on this path's random 8- to
     64-byte reads it equals TCC_EA0_RDREQ x 64 B, one 64-byte request each (calibrated with tools/micro/gather_calib.hip; the 1/2
     factor of MI355X_MICROARCH.md applies to coalesced streams)."""
     if not (gsize == 3100000000 and B == 1000000 and L == (150 if config == "hg38_150" else 245)):
         return None, None
-    name = "r03_bench_pmc_%s.json" % config
+    name = "r04_bench_pmc_%s.json" % config
     path = os.path.join(ROOT, "profiles", name)
     try:
         pm = json.load(open(path))
@@ -539,27 +539,27 @@ def pmc_traffic(kernel, gsize, B, L, config="hg38_150"):
 
 
 def pecall_pmc_traffic(n):
-    """HBM bytes of one resident run of the caller's kernels over the n columns, from profiles/r03_pecall_pmc.json (tools/profile_pecall.sh:
+    """HBM bytes of one resident run of the caller's kernels over the n columns, from profiles/r04_pecall_pmc.json (tools/profile_pecall.sh:
     separate --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pecall_kernel_time.py, 5 runs each) -- valid while the columns and the device
     sources are the profiled ones.  The kernels stream their columns (coalesced 768-byte rows in, 600 bytes out): WRITE_SIZE is taken as
     rocprofv3 reports it (KB); FETCH_SIZE is DOUBLED, as MI355X_MICROARCH.md prescribes for coalesced streaming reads on gfx950 (128-byte
     requests tallied at 64) -- the counter shows 395 bytes per column for rows of 770 bytes that the shortcut kernel reads whole."""
-    path = os.path.join(ROOT, "profiles", "r03_pecall_pmc.json")
+    path = os.path.join(ROOT, "profiles", "r04_pecall_pmc.json")
     try:
         pm = json.load(open(path))
     except (OSError, ValueError):
         return None, None
     sha = kernel_sources_sha("pecall_")
     if pm.get("sha_pecall") != sha:
-        return None, "profiles/r03_pecall_pmc.json is of other kernels (pecall_* sources %s, now %s): re-run tools/profile_pecall.sh" % (pm.get("sha_pecall"), sha)
+        return None, "profiles/r04_pecall_pmc.json is of other kernels (pecall_* sources %s, now %s): re-run tools/profile_pecall.sh" % (pm.get("sha_pecall"), sha)
     if pm.get("columns") != n:
-        return None, "profiles/r03_pecall_pmc.json was taken on %s columns" % pm.get("columns")
+        return None, "profiles/r04_pecall_pmc.json was taken on %s columns" % pm.get("columns")
     tot = 0.0
     for cn, factor in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
         for k, v in pm[cn].items():
             if k.startswith("pcs_"):
                 tot += factor * v["mean_KB_per_launch"] * v["launches"] / pm.get("steps", 5)
-    return round(tot * 1024.0), "profiles/r03_pecall_pmc.json (device sources pecall_* %s; FETCH_SIZE x 2, the guide's correction for coalesced streams)" % sha
+    return round(tot * 1024.0), "profiles/r04_pecall_pmc.json (device sources pecall_* %s; FETCH_SIZE x 2, the guide's correction for coalesced streams)" % sha
 
 
 def physical_cores():

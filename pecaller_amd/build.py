@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpemap_hip.so")
 SOURCES = ["pemap_capi.hip", "pecall_capi.hip"]
-DEPS = ["pemap_kernels.hip.h", "pemap_seed.hip.h", "pemap_seed2.hip.h", "pemap_seed3.hip.h", "pemap_sw.hip.h", "pemap_band.hip.h", "pemap_aux.hip.h", "pecall_kernels.hip.h", "pecall_site.hip.h", os.path.join("..", "..", "include", "pemap_hip.h")]
+DEPS = ["pemap_kernels.hip.h", "pemap_seed.hip.h", "pemap_seed2.hip.h", "pemap_seed4.hip.h", "pemap_wave.hip.h", "pemap_sw.hip.h", "pemap_band.hip.h", "pemap_aux.hip.h", "pecall_kernels.hip.h", "pecall_site.hip.h", os.path.join("..", "..", "include", "pemap_hip.h")]
 # -fno-honor-nans -mno-amdgpu-ieee: no NaN can arise on this path; without IEEE mode v_max_f64 needs no canonicalising copy
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-honor-nans", "-mno-amdgpu-ieee", "-fPIC", "-shared", "-Wall",
          "-Wno-unused-function", "-Wno-unused-value", "-Wno-uninitialized"]

@@ -1099,7 +1099,7 @@ static int seg_template (int L)
 }
 
 // ---- the memory stream's work for one chunk: look-ups + slice gather into the slot's lists
-// is the seed stage of this run the fused kernel (pm_seed3_kernel: look-ups and vote of a read-end in one wave)?
+// is the seed stage of this run the fused kernel (pm_seed4_kernel: look-ups and vote of a read-end in one wave)?
 static bool pm_fused (const pemap_dev * d)
 {
   return d->n_rep == 8;
@@ -1116,10 +1116,11 @@ static void launch_lookup (pemap_dev * d, const RunCtx & c, int slot, PmChunkCtr
   // kernel makes the stamp the moment the look-up kernel can start, so that ev[0]..ev[1] is the kernel's own duration)
   hipLaunchKernelGGL (pm_nop_kernel, dim3 (1), dim3 (1), 0, st);
   hipEventRecord (ev[0], st);
-  // PEMAP_LOOKUP_WAVES=n: n persistent one-wave workgroups per CU.  Default 7 of the 8 the fused kernel's LDS admits.  With the other
-  // stream's kernels in one-wave workgroups (round 3) the step follows the seed kernel: 12 steps of the default workload take
-  // 26.4 / 25.1 / 25.0 ms each on resident reads with 6 / 7 / 8, 27.8 / 27.4 / 27.9 at the seam (profiles/r03_ab_sweeps.txt)
-  int lw = d->kn.lookup_waves > 0 ? d->kn.lookup_waves : 7;
+  // PEMAP_LOOKUP_WAVES=n: n persistent one-wave workgroups per CU.  Default 9 (pm_seed4_kernel: 14.6 KB of LDS and 128 VGPRs a wave): 8
+  // steps of the default workload take 23.4 / 21.3 / 20.7 / 21.3 ms each on resident reads with 7 / 8 / 9 / 10 (profiles/r04_ab_sweeps.txt;
+  // the third form, 19.6 KB and 168 VGPRs, took 25.2 at its best, 7) -- the kernel itself keeps gaining (5.06 / 4.53 / 4.05 / 3.84 ms per
+  // launch) while the other stream's DP kernels lose the SIMDs' registers to it
+  int lw = d->kn.lookup_waves > 0 ? d->kn.lookup_waves : 9;
   if (c.ix.n_rep == 8)
     {
       // (no more workgroups than are resident at once: a workgroup owns its first ends by its number, and one that starts when
@@ -1413,24 +1414,23 @@ static int absorb_run (pemap_dev * d)
   const int nch = d->run_chunks;
 #ifdef PEMAP_TIMING_PROBES
   {
-    // the fused seed kernel's phase probes (pemap_seed3.hip.h): cycles summed over waves, printed per run
+    // the fused seed kernel's phase probes (pemap_seed4.hip.h): cycles summed over waves, printed per run
     unsigned long long pr[32], z[32] = { 0ull };
-    if (hipMemcpyFromSymbol (pr, HIP_SYMBOL (pm_s3_probe), sizeof pr) == hipSuccess)
+    if (hipMemcpyFromSymbol (pr, HIP_SYMBOL (pm_s4_probe), sizeof pr) == hipSuccess)
       {
         unsigned long long tot = 0;
         for (int i = 0; i < 16; i++)
           tot += pr[i];
         if (tot)
           {
-            static const char *nm[16] = { "lines0+wait", "decode0", "lines1", "decode1", "records-rest", "stage next", "segmask", "candidates", "relevant", "pairs", "rank+walk", "out", "rec:headers", "rec:scan+3", "rec:unit2", "rec:tails" };
-            fprintf (stderr, "[pm_s3_probe]");
+            static const char *nm[16] = { "lines0+wait", "decode0", "lines1", "decode1", "records-end", "stage next", "segmask", "candidates", "relevant", "pairs", "rank+walk", "out", "rec:headers", "rec:scan+3", "-", "rec:tails" };
+            fprintf (stderr, "[pm_s4_probe]");
             for (int i = 0; i < 16; i++)
               fprintf (stderr, " %s %.1f%%", nm[i], 100.0 * (double) pr[i] / (double) tot);
             fprintf (stderr, " | total %.3f G wave-cycles | segments %llu, dropped for a too-many bucket %llu, of them by the k-mer's own bucket %llu\n", (double) tot / 1e9, pr[16], pr[17], pr[18]);
-            fprintf (stderr, "[pm_s3_probe] ends decoded %llu; to the big-end kernel: records' room %llu, list capacity %llu, candidates %llu | records of 2-3 / 4-7 / 8-15 / 16+ positions: %llu / %llu / %llu / %llu | "
-                     "ends with a record of 8+ %llu, of 16+ %llu, of 4+ %llu, with any record %llu\n", pr[20], pr[21], pr[22], pr[23], pr[24], pr[25], pr[26], pr[27], pr[28], pr[29], pr[30], pr[31]);
+            fprintf (stderr, "[pm_s4_probe] ends decoded %llu; passed over: the list's room %llu, positions next to candidates %llu\n", pr[20], pr[21], pr[23]);
           }
-        (void) hipMemcpyToSymbol (HIP_SYMBOL (pm_s3_probe), z, sizeof z);
+        (void) hipMemcpyToSymbol (HIP_SYMBOL (pm_s4_probe), z, sizeof z);
       }
   }
 #endif

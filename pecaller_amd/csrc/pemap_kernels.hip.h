@@ -265,7 +265,6 @@ __device__ __forceinline__ void pm_set_prio (int p)
 
 #include "pemap_seed.hip.h"
 #include "pemap_seed2.hip.h"
-#include "pemap_seed3.hip.h"
 #include "pemap_seed4.hip.h"
 #include "pemap_sw.hip.h"
 #include "pemap_band.hip.h"

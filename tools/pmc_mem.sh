@@ -36,7 +36,7 @@ for kind in ("bench", "micro"):
         for (f, k, d) in seen:
             cnt[(f, k)] += 1
     for k in sorted(agg, key=lambda k: -agg[k].get("TCP_TCC_READ_REQ_sum", 0)):
-        if not (k.startswith("void pm_seed3") or k.startswith("pm_") or "gather" in k):
+        if not (k.startswith("void pm_seed4") or k.startswith("pm_") or "gather" in k):
             continue
         n = max(v for (f, kk), v in cnt.items() if kk == k)
         print(kind, k[:50], "dispatches/pass", n)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 passes behind profiles/: kernel-trace stats, then FETCH_SIZE and WRITE_SIZE in separate --pmc runs.
 # Run on the GPU box from the repo root:  tools/profile.sh <tag> [config]   (config: hg38_150 (default) or tsw250)
-#   -> gpurun_out/prof_<tag>/{stats.csv, pmc.json, ...}; copy pmc.json to profiles/r03_bench_pmc_<config>.json
+#   -> gpurun_out/prof_<tag>/{stats.csv, pmc.json, ...}; copy pmc.json to profiles/r04_bench_pmc_<config>.json
 # (the program itself follows `--`: no env / bash -c hop between the profiler and python3)
 set -e
 TAG=${1:-r03}

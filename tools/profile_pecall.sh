@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 passes of the per-site caller on BASELINE config 4's columns (resident runs of tools/pecall_kernel_time.py): kernel stats,
 # then FETCH_SIZE and WRITE_SIZE in separate --pmc runs.  tools/profile_pecall.sh <tag> [columns=2000000]
-#   -> gpurun_out/prof_pecall_<tag>/{stats.csv, pmc.json, timeline.txt}; copy pmc.json to profiles/r03_pecall_pmc.json
+#   -> gpurun_out/prof_pecall_<tag>/{stats.csv, pmc.json, timeline.txt}; copy pmc.json to profiles/r04_pecall_pmc.json
 set -e
 TAG=${1:-r03}
 N=${2:-2000000}

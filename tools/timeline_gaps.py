@@ -19,10 +19,10 @@ for r in rows[1:]:
 phases.append(cur)
 for pi, ph in enumerate(phases):
     t0, t1 = ph[0][0], max(r[1] for r in ph)
-    n_seed = sum(1 for r in ph if r[2].startswith("pm_seed3"))
+    n_seed = sum(1 for r in ph if r[2].startswith("pm_seed4"))
     if n_seed < 8:
         continue
-    print("== phase %d: %.1f ms, %d kernels, %d pm_seed3 launches" % (pi, (t1 - t0) / 1e6, len(ph), n_seed))
+    print("== phase %d: %.1f ms, %d kernels, %d pm_seed4 launches" % (pi, (t1 - t0) / 1e6, len(ph), n_seed))
     # device-wide idle
     idle, e = 0, ph[0][1]
     for r in ph[1:]:
@@ -30,11 +30,11 @@ for pi, ph in enumerate(phases):
             idle += r[0] - e
         e = max(e, r[1])
     print("   device idle (no pm_ kernel running): %.2f ms" % (idle / 1e6))
-    # the seed kernel's own stream: gaps between consecutive pm_seed3 launches
-    seeds = [r for r in ph if r[2].startswith("pm_seed3")]
+    # the seed kernel's own stream: gaps between consecutive pm_seed4 launches
+    seeds = [r for r in ph if r[2].startswith("pm_seed4")]
     busy = sum(r[1] - r[0] for r in seeds)
     gaps = [(b[0] - a[1], a[1] - t0) for a, b in zip(seeds, seeds[1:])]
-    print("   pm_seed3: busy %.2f ms (avg %.3f), sum of gaps between launches %.2f ms, largest gaps (ms at ms): %s" % (
+    print("   pm_seed4: busy %.2f ms (avg %.3f), sum of gaps between launches %.2f ms, largest gaps (ms at ms): %s" % (
         busy / 1e6, busy / len(seeds) / 1e6, sum(g for g, _ in gaps) / 1e6,
         ", ".join("%.2f@%.1f" % (g / 1e6, at / 1e6) for g, at in sorted(gaps, reverse=True)[:8])))
     byq = {}
