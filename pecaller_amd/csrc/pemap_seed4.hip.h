@@ -336,20 +336,22 @@ void pm_seed4_kernel (PmIndex ix, PmBatch b, PmParams prm, PmHits h, PmLists out
 #endif
                 if (__ballot (ent == 0xFFFFFFFEu) != 0ull)
                   continue;
-                const bool single = ent < multi_base, multi = ent >= multi_base && ent != 0xFFFFFFFFu;
+                // (one compare each: an entry is the bucket's only position, or -- 0xFFFFFFFE being too many, seen above, and 0xFFFFFFFF
+                // empty -- a record's unit number above multi_base; the two kinds share one pair of stores, front and back of the list)
+                const uint32_t unit = ent - multi_base;
+                const bool single = ent < multi_base, multi = unit < 0xFFFFFFFEu - multi_base;
                 const unsigned long long bs = __ballot (single), bm = __ballot (multi);
                 const int off = (seg < cuts || cuts == 0) ? seg * idepth : last_off;
                 const uint32_t tg = (uint32_t) (seg | (strand << 5));
-                if (single)
+                // (both ranks and both values computed by every lane, then selected: no divergent arms)
+                const int rs = pm_lanes_below_here (bs), rm = pm_lanes_below_here (bm);
+                int at = nf + rs;
+                at = multi ? SH::KCAP - 1 - nm - rm : at;
+                uint32_t val = ent + (uint32_t) (PM_DIAG_BIAS - off);
+                val = multi ? unit : val;                       // (a record: its first 16-byte unit)
+                if (single || multi)
                   {
-                    const int at = nf + pm_lanes_below (bs);
-                    sh.key[at] = ent + (uint32_t) (PM_DIAG_BIAS - off);
-                    sh.tag[at] = (uint8_t) tg;
-                  }
-                if (multi)
-                  {
-                    const int at = SH::KCAP - 1 - (nm + pm_lanes_below (bm));
-                    sh.key[at] = ent - multi_base;      // the record's first 16-byte unit
+                    sh.key[at] = val;
                     sh.tag[at] = (uint8_t) tg;
                   }
                 const int ns = (int) __popcll (bs);
@@ -538,6 +540,13 @@ void pm_seed4_kernel (PmIndex ix, PmBatch b, PmParams prm, PmHits h, PmLists out
       // ---- P: the next end's k-mers and line requests (its bytes arrived during the previous iteration); R: the bytes of the end after
       int SP = 0, lenP = 0, endP = 0;
       uint32_t kP = 0;
+      // Every load issued so far has landed or is about to be needed (the next end's bytes were requested an iteration ago, behind
+      // this end's lines; the records were consumed above): said HERE, on every path, so that the compiler's wait-count model is
+      // clean before the line requests go out.  Without it the zeroing of rb[] in load_bytes -- registers a load of the previous
+      // iteration MAY still own on the path that skipped stage_p -- carries `s_waitcnt vmcnt(1)` right behind the line requests
+      // (conditional, so uncounted), and the wave sat out their whole HBM latency: 31 % of its cycles (the third form had the same
+      // wait; the lines were never in flight across the vote as its comments said)
+      __builtin_amdgcn_s_waitcnt (0x0F70);      // vmcnt(0)
       if (eP < n_work)
         SP = stage_p (kP, lenP, endP, out_and_next);
       else

@@ -6,6 +6,16 @@ __device__ __forceinline__ int pm_lanes_below (unsigned long long m)
   return (int) __builtin_amdgcn_mbcnt_hi ((unsigned) (m >> 32), __builtin_amdgcn_mbcnt_lo ((unsigned) m, 0u));
 }
 
+// the same, opaque to the optimiser: where two ranks feed a select, the compiler otherwise sinks each mbcnt pair into an arm of its own and
+// makes divergent control flow of the select (exec flipped twice per decoded segment in the seed kernel)
+__device__ __forceinline__ int pm_lanes_below_here (unsigned long long m)
+{
+  int r;
+  const unsigned lo = (unsigned) m, hi = (unsigned) (m >> 32);
+  asm volatile ("v_mbcnt_lo_u32_b32 %0, %1, 0\n\tv_mbcnt_hi_u32_b32 %0, %2, %0" : "=&v" (r) : "s" (lo), "s" (hi));
+  return r;
+}
+
 // Wave-wide scan / reduction on the DPP path (row shifts inside the 16-lane rows, then the row broadcasts of gfx9): six VALU
 // instructions, against six round trips through the LDS crossbar for the __shfl forms.  Lanes without a source lane take `ident`.
 template < int CTRL, int ROW_MASK > __device__ __forceinline__ int pm_dpp_or (int ident, int v)
