@@ -61,6 +61,14 @@ struct pecall_dev
   unsigned long long *d_next_site;      // per chunk: work counter of the per-site kernel; behind it the PCS_BUCKETS counts of listed columns
   int cap_chunks;
   unsigned *d_slow;             // columns left to the beam search
+  // the columns pcs_heavy_kernel lists for the beam search before the shortcut kernels start (up to 64 samples): flags, the list in
+  // PCS_BUCKETS parts, its counters (the layout of a chunk's), a stream and a share of the scratch of its own
+  uint8_t *d_heavy_flag;
+  unsigned *d_heavy_list;
+  unsigned long long *d_heavy_ctr;      // [1 + cap_chunks][PCS_CTRS]: slot 0 for a whole run's list (resident columns), slot 1 + k for chunk k's (the seam)
+  hipStream_t stream_heavy;
+  hipEvent_t ev_heavy[2], *ev_heavy_k;  // list made / its beam search done; per chunk: done
+  int heavy_min, heavy_grid;
   unsigned *d_deep;             // columns too deep for the head of the ln n! table (per chunk, at the chunk's offset)
   // pecall_dev_call_sites_sparse: the columns with a posterior that is not 1 (pcs_sparse_kernel)
   unsigned *d_sp_cols;
@@ -189,6 +197,9 @@ extern "C" void pecall_dev_destroy (pecall_dev * d)
   hipFree (d->d_dyad);
   hipFree (d->d_trio);
   hipFree (d->d_slow);
+  hipFree (d->d_heavy_flag);
+  hipFree (d->d_heavy_list);
+  hipFree (d->d_heavy_ctr);
   hipFree (d->d_deep);
   hipFree (d->d_sp_cols);
   hipFree (d->d_sp_rows);
@@ -206,11 +217,13 @@ extern "C" void pecall_dev_destroy (pecall_dev * d)
       hipEventDestroy (d->ev_h2d[k]);
       hipEventDestroy (d->ev_fast[k]);
       hipEventDestroy (d->ev_call[k]);
+      hipEventDestroy (d->ev_heavy_k[k]);
       hipEventDestroy (d->ev_d2h[k]);
     }
   free (d->ev_h2d);
   free (d->ev_fast);
   free (d->ev_call);
+  free (d->ev_heavy_k);
   free (d->ev_d2h);
   for (int i = 0; i < PCS_SLOTS; i++)
     {
@@ -225,6 +238,9 @@ extern "C" void pecall_dev_destroy (pecall_dev * d)
         hipStreamDestroy (d->stream_call[i]);
       hipStreamDestroy (d->stream_h2d);
       hipStreamDestroy (d->stream_d2h);
+      hipStreamDestroy (d->stream_heavy);
+      hipEventDestroy (d->ev_heavy[0]);
+      hipEventDestroy (d->ev_heavy[1]);
     }
   hipStreamDestroy (d->stream);
   free (d);
@@ -379,7 +395,13 @@ static int pcs_ensure (pecall_dev * d, long n_sites, int indiv)
       hipFree (d->d_scratch);
       d->d_scratch = nullptr;
       d->site_grid = d->grid * 4;       // 8 waves per CU; LDS admits 4 resident, the rest queue
-      PCCHK (d, hipMalloc ((void **) &d->d_scratch, (size_t) d->site_grid * (2 * PCS_BIG_BYTES_OF (row) + PCS_BIGCAP)));
+      d->heavy_grid = d->grid;          // (the early beam search of the listed heavy columns: 2 waves per CU, behind the site_grid shares)
+      {
+        const char *e = getenv ("PECALL_HEAVY_WAVES");  // waves per CU of that launch (1 .. 4)
+        const int w = (e && *e) ? atoi (e) : 3;
+        d->heavy_grid = d->grid / 2 * (w < 1 ? 1 : w > 4 ? 4 : w);
+      }
+      PCCHK (d, hipMalloc ((void **) &d->d_scratch, (size_t) (d->site_grid + d->heavy_grid) * (2 * PCS_BIG_BYTES_OF (row) + PCS_BIGCAP)));
       d->scratch_row = row;
     }
   long items = n_sites * indiv;
@@ -387,6 +409,8 @@ static int pcs_ensure (pecall_dev * d, long n_sites, int indiv)
     {
       hipFree (d->d_sreads); hipFree (d->d_dom); hipFree (d->d_chromy); hipFree (d->d_call); hipFree (d->d_type);
       hipFree (d->d_npass); hipFree (d->d_post); hipFree (d->d_ac); hipFree (d->d_den); hipFree (d->d_slow); hipFree (d->d_deep);
+      hipFree (d->d_heavy_flag); hipFree (d->d_heavy_list);
+      d->d_heavy_flag = nullptr; d->d_heavy_list = nullptr;
       // (nothing dangles if one of the allocations below fails: the next call allocates again, destroy frees nullptr)
       d->d_sreads = nullptr; d->d_dom = nullptr; d->d_chromy = nullptr; d->d_call = nullptr; d->d_type = nullptr;
       d->d_npass = nullptr; d->d_post = nullptr; d->d_ac = nullptr; d->d_den = nullptr; d->d_slow = nullptr; d->d_deep = nullptr;
@@ -394,6 +418,8 @@ static int pcs_ensure (pecall_dev * d, long n_sites, int indiv)
       d->cap_sitems = 0;
       PCCHK (d, hipMalloc ((void **) &d->d_slow, (size_t) PCS_BUCKETS * n_sites * sizeof (unsigned)));
       PCCHK (d, hipMalloc ((void **) &d->d_deep, (size_t) n_sites * sizeof (unsigned)));
+      PCCHK (d, hipMalloc ((void **) &d->d_heavy_flag, (size_t) n_sites));
+      PCCHK (d, hipMalloc ((void **) &d->d_heavy_list, (size_t) PCS_BUCKETS * n_sites * sizeof (unsigned)));
       PCCHK (d, hipMalloc ((void **) &d->d_sreads, items * PCS_NA * sizeof (uint16_t)));
       PCCHK (d, hipMalloc ((void **) &d->d_dom, n_sites));
       PCCHK (d, hipMalloc ((void **) &d->d_chromy, n_sites));
@@ -603,6 +629,14 @@ static int pcs_ensure_chunks (pecall_dev * d, long n_sites)
         PCCHK (d, hipStreamCreateWithFlags (&d->stream_call[i], hipStreamNonBlocking));
       PCCHK (d, hipStreamCreateWithFlags (&d->stream_h2d, hipStreamNonBlocking));
       PCCHK (d, hipStreamCreateWithFlags (&d->stream_d2h, hipStreamNonBlocking));
+      PCCHK (d, hipStreamCreateWithFlags (&d->stream_heavy, hipStreamNonBlocking));
+      PCCHK (d, hipEventCreateWithFlags (&d->ev_heavy[0], hipEventDisableTiming));
+      PCCHK (d, hipEventCreateWithFlags (&d->ev_heavy[1], hipEventDisableTiming));
+      {
+        // PECALL_HEAVY_MIN: samples with variant reads from which a column's beam search is started ahead of the shortcut kernels; 0 = never
+        const char *e = getenv ("PECALL_HEAVY_MIN");
+        d->heavy_min = (e && *e) ? atoi (e) : 1;
+      }
       PCCHK (d, hipFuncSetAttribute ((const void *) pcs_fast_kernel < PC_TABLE >, hipFuncAttributeMaxDynamicSharedMemorySize, PCS_FAST_LDS_BYTES_OF (PC_TABLE)));
       PCCHK (d, hipFuncSetAttribute ((const void *) pcs_call_kernel < 4 >, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof (PcsShared < 4 >)));
     }
@@ -618,6 +652,9 @@ static int pcs_ensure_chunks (pecall_dev * d, long n_sites)
       hipFree (d->d_next_site);
       d->d_next_site = nullptr;
       PCCHK (d, hipMalloc ((void **) &d->d_next_site, (size_t) nch * PCS_CTRS * sizeof (unsigned long long)));
+      hipFree (d->d_heavy_ctr);
+      d->d_heavy_ctr = nullptr;
+      PCCHK (d, hipMalloc ((void **) &d->d_heavy_ctr, (size_t) (nch + 1) * PCS_CTRS * sizeof (unsigned long long)));
       if (d->h_ctrs)
         hipHostFree (d->h_ctrs);
       d->h_ctrs = nullptr;
@@ -626,12 +663,14 @@ static int pcs_ensure_chunks (pecall_dev * d, long n_sites)
       d->ev_fast = (hipEvent_t *) realloc (d->ev_fast, sizeof (hipEvent_t) * nch);
       d->ev_call = (hipEvent_t *) realloc (d->ev_call, sizeof (hipEvent_t) * nch);
       d->ev_d2h = (hipEvent_t *) realloc (d->ev_d2h, sizeof (hipEvent_t) * nch);
+      d->ev_heavy_k = (hipEvent_t *) realloc (d->ev_heavy_k, sizeof (hipEvent_t) * nch);
       for (int k = d->cap_chunks; k < nch; k++)
         {
           PCCHK (d, hipEventCreateWithFlags (&d->ev_h2d[k], hipEventDisableTiming));
           PCCHK (d, hipEventCreateWithFlags (&d->ev_fast[k], hipEventDisableTiming));
           PCCHK (d, hipEventCreateWithFlags (&d->ev_call[k], hipEventDisableTiming));
           PCCHK (d, hipEventCreateWithFlags (&d->ev_d2h[k], hipEventDisableTiming));
+          PCCHK (d, hipEventCreateWithFlags (&d->ev_heavy_k[k], hipEventDisableTiming));
         }
       d->cap_chunks = nch;
     }
@@ -658,7 +697,10 @@ static int pcs_chunk_reset (pecall_dev * d, const PcsParams & P, int k, long off
   return 0;
 }
 
-static int pcs_chunk_kernels (pecall_dev * d, const PcsParams & P, int k, long off, long m, bool whole_table, bool sparse = false)
+static int pcs_heavy_start (pecall_dev * d, const PcsParams & P, long off, long m, int slot, hipEvent_t done);
+// heavy: 0 no early beam search; 1 the run made its list already (pcs_heavy_start over all columns): the shortcut kernel passes the flagged
+// columns over; 2 the chunk makes its own list here (the seam: columns arrive chunk by chunk) and its results wait for that beam search too
+static int pcs_chunk_kernels (pecall_dev * d, const PcsParams & P, int k, long off, long m, bool whole_table, bool sparse = false, int heavy = 0)
 {
   const int N = P.indiv;
   unsigned long long *ctr = d->d_next_site + (size_t) k * PCS_CTRS;
@@ -674,6 +716,14 @@ static int pcs_chunk_kernels (pecall_dev * d, const PcsParams & P, int k, long o
       PCCHK (d, hipMemsetAsync (ctr, 0, 3 * sizeof (unsigned long long), d->stream));
       PCCHK (d, hipMemsetAsync (ctr + 4, 0, sizeof (unsigned long long), d->stream));
     }
+  if (nch != 1)
+    heavy = 0;
+  if (heavy == 2 && !whole_table)
+    {
+      const int rc = pcs_heavy_start (d, P, off, m, 1 + k, d->ev_heavy_k[k]);
+      if (rc)
+        return rc;
+    }
   if (nch == 1)
     {
       if (!whole_table)
@@ -684,7 +734,8 @@ static int pcs_chunk_kernels (pecall_dev * d, const PcsParams & P, int k, long o
             fgrid = (long) d->grid / 2 * 3;     // three workgroups of 4 waves per CU
           hipLaunchKernelGGL (HIP_KERNEL_NAME (pcs_fast_kernel < PCS_FAST_TAB >), dim3 ((unsigned) fgrid), dim3 (B), PCS_FAST_LDS_BYTES_OF (PCS_FAST_TAB), d->stream, P,
                               d->d_sreads + off * N * PCS_NA, d->d_dom + off, d->d_chromy + off, m, d->d_call + off * N, d->d_post + off * N, d->d_type + off,
-                              d->d_ac + off * PCS_NA, d->d_npass + off, d->d_den + off, slow, n_slow, deep_list, n_deep, next_piece, d->d_ta);
+                              d->d_ac + off * PCS_NA, d->d_npass + off, d->d_den + off, slow, n_slow, deep_list, n_deep, next_piece, d->d_ta,
+                              heavy ? (const uint8_t *) d->d_heavy_flag + off : (const uint8_t *) nullptr);
         }
       else
         {
@@ -694,7 +745,8 @@ static int pcs_chunk_kernels (pecall_dev * d, const PcsParams & P, int k, long o
             fgrid = d->grid / 2;        // one workgroup per CU: the whole ln n! table takes half its LDS
           hipLaunchKernelGGL (HIP_KERNEL_NAME (pcs_fast_kernel < PC_TABLE >), dim3 ((unsigned) fgrid), dim3 (B), PCS_FAST_LDS_BYTES_OF (PC_TABLE), d->stream, P,
                               d->d_sreads + off * N * PCS_NA, d->d_dom + off, d->d_chromy + off, m, d->d_call + off * N, d->d_post + off * N, d->d_type + off,
-                              d->d_ac + off * PCS_NA, d->d_npass + off, d->d_den + off, slow, n_slow, deep_list, n_deep, next_piece, d->d_ta);
+                              d->d_ac + off * PCS_NA, d->d_npass + off, d->d_den + off, slow, n_slow, deep_list, n_deep, next_piece, d->d_ta,
+                              heavy ? (const uint8_t *) d->d_heavy_flag + off : (const uint8_t *) nullptr);
         }
     }
   else if (whole_table)
@@ -720,6 +772,8 @@ static int pcs_chunk_kernels (pecall_dev * d, const PcsParams & P, int k, long o
   else
     PCS_CALL (4, (const unsigned *) nullptr, (const unsigned *) nullptr);
 #undef PCS_CALL
+  if (heavy == 2)
+    PCCHK (d, hipStreamWaitEvent (sc, d->ev_heavy_k[k], 0));    // (the chunk's results are whole when its early beam search is through too)
   if (sparse)
     {
       // behind the beam search, on its stream: the chunk's columns with a posterior that is not 1 (second pass: of the deep list only)
@@ -730,6 +784,33 @@ static int pcs_chunk_kernels (pecall_dev * d, const PcsParams & P, int k, long o
     }
   PCCHK (d, hipGetLastError ());
   PCCHK (d, hipEventRecord (d->ev_call[k], sc));
+  return 0;
+}
+
+// pcs_heavy_kernel over the columns [off, off + m) on the object's stream, then -- on a stream of its own, with scratch of its own --
+// the beam search of what it listed, heaviest part first; `done` closes it.  slot: the list's counters (0: a whole run, 1 + k: chunk k).
+static int pcs_heavy_start (pecall_dev * d, const PcsParams & P, long off, long m, int slot, hipEvent_t done)
+{
+  const int N = P.indiv;
+  unsigned long long *ctr = d->d_heavy_ctr + (size_t) slot * PCS_CTRS;
+  unsigned *n_list = (unsigned *) (ctr + 1);
+  unsigned *list = d->d_heavy_list + (size_t) PCS_BUCKETS * off;
+  PCCHK (d, hipMemsetAsync (ctr, 0, PCS_CTRS * sizeof (unsigned long long), d->stream));
+  PCCHK (d, hipMemsetAsync (d->d_heavy_flag + off, 0, (size_t) m, d->stream));
+  long hgrid = (m + 3) / 4;
+  if (hgrid > (long) d->grid * 4)
+    hgrid = (long) d->grid * 4;
+  hipLaunchKernelGGL (pcs_heavy_kernel, dim3 ((unsigned) hgrid), dim3 (256), 0, d->stream, d->d_sreads + off * N * PCS_NA, d->d_dom + off, m, N, d->heavy_min, list,
+                      n_list, d->d_heavy_flag + off);
+  PCCHK (d, hipEventRecord (d->ev_heavy[0], d->stream));
+  PCCHK (d, hipStreamWaitEvent (d->stream_heavy, d->ev_heavy[0], 0));
+  char *scratch = d->d_scratch + (size_t) d->site_grid * (2 * PCS_BIG_BYTES_OF (64) + PCS_BIGCAP);
+  const long grid = m < (long) d->heavy_grid ? m : (long) d->heavy_grid;
+  hipLaunchKernelGGL (HIP_KERNEL_NAME (pcs_call_kernel < 1 >), dim3 ((unsigned) grid), dim3 (64), sizeof (PcsShared < 1 >), d->stream_heavy, P,
+                      d->d_sreads + off * N * PCS_NA, d->d_dom + off, d->d_chromy + off, m, d->d_call + off * N, d->d_post + off * N, d->d_type + off,
+                      d->d_ac + off * PCS_NA, d->d_npass + off, d->d_den + off, scratch, ctr, (const unsigned *) list, (const unsigned *) n_list);
+  PCCHK (d, hipGetLastError ());
+  PCCHK (d, hipEventRecord (done, d->stream_heavy));
   return 0;
 }
 
@@ -769,6 +850,12 @@ extern "C" int pecall_dev_sites_run (pecall_dev * d, int haploid, double thresho
   const long C = d->chunk_sites;
   const int k = (int) ((n_sites + C - 1) / C);
   std::vector < char >deep ((size_t) k, 0);
+  // the long beam searches first (pcs_heavy_kernel): listed from the resident columns, started on a stream of their own beside everything
+  // that follows -- a launch of the beam search ends with its slowest column, and the last chunk's used to be the run's last 8 ms
+  const bool heavy = indiv <= 64 && d->heavy_min > 0;
+  if (heavy)
+    if ((rc = pcs_heavy_start (d, P, 0, n_sites, 0, d->ev_heavy[1])))
+      return rc;
   for (int pass = 0; pass < 2; pass++)
     {
       // (the counters of all chunks first)
@@ -777,11 +864,13 @@ extern "C" int pecall_dev_sites_run (pecall_dev * d, int haploid, double thresho
           return rc;
       for (int q = 0; q < k; q++)
         if (pass == 0 || deep[q])
-          if ((rc = pcs_chunk_kernels (d, P, q, (long) q * C, n_sites - (long) q * C < C ? n_sites - (long) q * C : C, pass == 1)))
+          if ((rc = pcs_chunk_kernels (d, P, q, (long) q * C, n_sites - (long) q * C < C ? n_sites - (long) q * C : C, pass == 1, false, heavy ? 1 : 0)))
             return rc;
       // (the object's stream ends behind the beam searches: ev_site[1] closes the interval of all streams)
       for (int q = 0; q < k; q++)
         PCCHK (d, hipStreamWaitEvent (d->stream, d->ev_call[q], 0));
+      if (heavy)
+        PCCHK (d, hipStreamWaitEvent (d->stream, d->ev_heavy[1], 0));
       if (pass == 0)
         {
           PCCHK (d, hipEventRecord (d->ev_site[1], d->stream));
@@ -813,6 +902,9 @@ extern "C" int pecall_dev_sites_run (pecall_dev * d, int haploid, double thresho
               tot[b] += c[b];
         }
       fprintf (stderr, "[pecall] %ld columns, listed for the beam by unsettled samples <3 / <8 / <20 / more: %llu %llu %llu %llu\n", n_sites, tot[0], tot[1], tot[2], tot[3]);
+      unsigned hc[PCS_BUCKETS] = { 0u, 0u, 0u, 0u };
+      if (heavy && hipMemcpy (hc, (unsigned *) (d->d_heavy_ctr + 1), sizeof hc, hipMemcpyDeviceToHost) == hipSuccess)
+        fprintf (stderr, "[pecall] started ahead of the shortcut kernels, by samples with variant reads <12 / <20 / <32 / more: %u %u %u %u\n", hc[0], hc[1], hc[2], hc[3]);
     }
   return 0;
 }
@@ -982,7 +1074,7 @@ static int pcs_call_sites_impl (pecall_dev * d, const uint16_t * reads, const ui
   {
     const long off = (long) j * C, m = n_sites - off < C ? n_sites - off : C;
     int rc2 = whole_table ? 0 : pcs_chunk_reset (d, P, j, off, m);
-    if (rc2 || (rc2 = pcs_chunk_kernels (d, P, j, off, m, whole_table, sparse)))
+    if (rc2 || (rc2 = pcs_chunk_kernels (d, P, j, off, m, whole_table, sparse, (N <= 64 && d->heavy_min > 0) ? 2 : 0)))
       return rc2;
     PCCHK (d, hipStreamWaitEvent (d->stream_d2h, d->ev_call[j], 0));
     char *o = out_direct ? nullptr : d->h_out[j % PCS_SLOTS];

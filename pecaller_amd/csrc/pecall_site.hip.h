@@ -1608,7 +1608,7 @@ void pcs_fast_kernel (PcsParams P, const uint16_t * reads, const uint8_t * dom_o
                       long n_sites, int8_t * call, double *post_out, int8_t * type_out,
                       int32_t * allele_count, int8_t * n_pass, int32_t * denovo_out,
                       unsigned *slow_list, unsigned *n_slow, unsigned *deep_list, unsigned *n_deep, unsigned *next_piece,
-                      const uint32_t * ta_table)
+                      const uint32_t * ta_table, const uint8_t * skip)
 {
   constexpr int PCS_FAST_BLOCK = PCS_FAST_BLOCK_OF (TABN);
   // Two forms.  TABN = PCS_FAST_TAB: the head of the ln n! table in LDS, every column of the range; a column in which a sample is too
@@ -1647,6 +1647,8 @@ void pcs_fast_kernel (PcsParams P, const uint16_t * reads, const uint8_t * dom_o
       for (long item = piece * PCS_FAST_GRAB; item < item_end; item++)
     {
       const long site = LISTED ? (long) deep_list[item] : item;
+      if (skip && skip[site])
+        continue;               // (pcs_heavy_kernel listed the column for the beam search before this kernel started)
       const int dom = dom_of[site];
       const int chrom = chrom_of[site] & 3;
       int decided = 1;          // 1: written here, 0: left to the beam
@@ -1791,6 +1793,50 @@ void pcs_fast_kernel (PcsParams P, const uint16_t * reads, const uint8_t * dom_o
         }
     }
       piece = first_free + (long) (unsigned) __shfl ((int) nx, 0);
+    }
+}
+
+// The columns whose beam search is long, found BEFORE anything else runs.  A launch of the beam search ends with its slowest column, a
+// variant column in which twenty or more samples carry the variant takes one wave 4 to 7 ms, and such a column of the LAST chunk used to
+// be listed when the last shortcut kernel ended: the run's last 8 ms were a few waves finishing them on an otherwise idle chip
+// (profiles/r03_pecall_timeline.txt).  This pass reads every column once (lane = sample, 12 bytes each), counts the samples with three or
+// more reads that are not the reference base's -- and at least an eighth of their depth -- and lists the columns with `thr` or more of
+// them by that count (the list's PCS_BUCKETS parts, as the shortcut kernel files its own); flag[site] = 1 tells the shortcut kernel to
+// leave the column alone.  pcs_call_kernel is the whole caller and takes any column, so the choice only moves work: the listed columns'
+// beam searches start at once, beside the shortcut kernels of all chunks.  Up to 64 samples (the shortcut's range).
+__global__ __launch_bounds__ (256) void pcs_heavy_kernel (const uint16_t * reads, const uint8_t * dom_of, long n_sites, int N, int thr, unsigned *list,
+                                                          unsigned *n_list, uint8_t * flag)
+{
+  const int lane = threadIdx.x & 63;
+  const long wave = ((long) blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((long) gridDim.x * blockDim.x) >> 6;
+  for (long site = wave; site < n_sites; site += n_waves)
+    {
+      const int dom = dom_of[site];
+      if (dom > 3)
+        continue;
+      int alt = 0, tot = 0;
+      if (lane < N)
+        {
+          const uint16_t *r = reads + (site * N + lane) * PCS_NA;
+          int ref = 0;
+#pragma unroll
+          for (int a = 0; a < PCS_NA; a++)
+            {
+              const int v = (int) r[a];
+              tot += v;
+              ref = a == dom ? v : ref;
+            }
+          alt = tot - ref;
+        }
+      const int c = (int) __popcll (__ballot (alt >= 3 && 8 * alt >= tot));
+      if (c < thr)
+        continue;
+      if (lane == 0)
+        {
+          const int b = c < 12 ? 0 : c < 20 ? 1 : c < 32 ? 2 : 3;
+          list[(size_t) b * (size_t) n_sites + atomicAdd (&n_list[b], 1u)] = (unsigned) site;
+          flag[site] = 1;
+        }
     }
 }
 
