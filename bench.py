@@ -538,6 +538,30 @@ def pmc_traffic(kernel, gsize, B, L, config="hg38_150"):
     return (round(tot * 1024.0), src) if hit else (None, src)
 
 
+def pecall_sq_fracs(n, kernel_ms, clock_ghz=2.4, simds=1024):
+    """share of a resident run of the caller in which the VALUs (SQ_ACTIVE_INST_VALU) and the LDS pipes (SQ_ACTIVE_INST_LDS) of the chip's
+    SIMDs were busy: the counters are in units of four cycles, summed over the SIMDs; per run of the n columns from
+    profiles/r04_pecall_sq.json (tools/pcs_sq.sh), valid for these columns and these device sources; the clock is taken at its 2.4 GHz
+    peak (the shares are lower bounds: under load the chip runs at 1.95-2.1)"""
+    path = os.path.join(ROOT, "profiles", "r04_pecall_sq.json")
+    try:
+        pm = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    sha = kernel_sources_sha("pecall_")
+    if pm.get("sha_pecall") != sha or pm.get("columns") != n:
+        return None
+    v = sum(k.get("SQ_ACTIVE_INST_VALU", 0.0) for k in pm["kernels"].values())
+    l = sum(k.get("SQ_ACTIVE_INST_LDS", 0.0) for k in pm["kernels"].values())
+    cyc = simds * kernel_ms * 1e-3 * clock_ghz * 1e9
+    out = {"valu_issue_frac": round(4.0 * v / cyc, 4), "lds_frac": round(4.0 * l / cyc, 4),
+           "source": "profiles/r04_pecall_sq.json (device sources pecall_* %s), %d SIMDs at %.1f GHz" % (sha, simds, clock_ghz)}
+    tr, _ = pecall_pmc_traffic(n)
+    hb = (tr / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr else 0.0
+    out["bound"] = max((("valu", out["valu_issue_frac"]), ("lds", out["lds_frac"]), ("hbm", hb)), key=lambda x: x[1])[0]
+    return out
+
+
 def pecall_pmc_traffic(n):
     """HBM bytes of one resident run of the caller's kernels over the n columns, from profiles/r04_pecall_pmc.json (tools/profile_pecall.sh:
     separate --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pecall_kernel_time.py, 5 runs each) -- valid while the columns and the device
@@ -730,6 +754,7 @@ def pecaller_leg(a):
         types_eq = types_eq and bool(np.array_equal(typ[s], otyp))
     achieved = PECALL_BYTES_PER_SITE * n / (kernel_ms * 1e-3) / 1e9
     traffic, tsrc = pecall_pmc_traffic(n)
+    sq = pecall_sq_fracs(n, kernel_ms)
     return {"metric": "M pileup columns called/sec, 64 samples, 30x", "value": round(n / (kernel_ms * 1e-3) / 1e6, 4), "unit": "M columns/s",
             "timed_region": "pcs_fast_kernel + pcs_call_kernel on columns resident in HBM, in chunks of 2^18 columns, the beam searches of the chunks on four streams beside the next chunks' shortcut kernels (HIP events around all of them, mean of 3 runs)",
             "seam_value": round(n / seam_dt / 1e6, 4), "seam_timed_region": "pecall_dev_call_sites: host columns in, calls + posteriors out (PCIe included; the caller's buffers page-locked once, copies and kernels of neighbouring chunks side by side)",
@@ -739,8 +764,14 @@ def pecaller_leg(a):
             "config": {"workload": "%d pileup columns x %d samples, 30x Poisson depth, 0.4%% error, 1 variant/kb under HWE, seed 777, "
                                    "prob_to_call 0.95, theta 0.001, diploid, no pedigree" % (n, S), "generated_in_s": round(t_gen, 1)},
             "variant_rows": int((typ > 0).sum()), "passes_histogram": np.bincount(npass).tolist(),
-            "roofline": {"bound": "hbm", "kernel": "pcs_fast_kernel+pcs_call_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": sq["bound"] if sq else "hbm", "kernel": "pcs_fast_kernel+pcs_call_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc, "avg_launch_ms": round(kernel_ms, 3),
+                         # what the kernels are bound by is not HBM (their traffic is a fifth of the algorithmic figure: the likelihood table
+                         # look-ups stay in LDS): the share of the run in which the VALUs / the LDS pipes of the 1,024 SIMDs were busy, from
+                         # the SQ counters of profiles/r04_pecall_sq.json, beside the HBM share of the counted traffic; `bound` = the largest
+                         "valu_issue_frac": sq["valu_issue_frac"] if sq else None, "lds_frac": sq["lds_frac"] if sq else None,
+                         "hbm_traffic_frac": (round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None),
+                         "sq_source": sq["source"] if sq else None,
                          "algorithmic_bytes_per_launch": PECALL_BYTES_PER_SITE * n, "bytes_per_site": PECALL_BYTES_PER_SITE},
             "cpu_baseline": {"value": round(m / cpu_dt / 1e6, 5), "unit": "M columns/s", "cores": nt, "kind": "port",
                              "sample": "%d of the same columns, %d oracle callers on %d threads, %.1f s" % (m, nt, nt, cpu_dt),

@@ -17,7 +17,7 @@
  * With a BED guide file (the last argument, pecaller.c:925-1068) every position of the listed intervals is called, covered
  * or not, and columns on chrY / chrMT are called with HAPLOID forced (955-957).
  *
- * Not supported (an error, not a silent difference): more than 256 samples (up to 64 is the device caller's fast case).  `no_threads` - 1 threads (at most 32) walk the pileup streams, format the rows and deflate <outfile>.base.gz.
+ * Not supported (an error, not a silent difference): more than 256 samples (up to 64 is the device caller's fast case).  `no_threads` - 1 threads (as many as the host has CPUs, at most 128) walk the pileup streams, format the rows and deflate <outfile>.base.gz.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -262,7 +262,7 @@ emit_thread (void *arg)
 static void
 emit_tile (const tile_t * t, int indiv, char **contig_names, int threads, sbuf * ob, FILE * snpfile, gzFile pilefile)
 {
-  enum { MAXT = 32 };
+  enum { MAXT = 128 };
   static emit_job jobs[MAXT];   /* (their buffers are kept from tile to tile) */
   pthread_t th[MAXT];
   if (threads > MAXT)
@@ -326,6 +326,10 @@ typedef struct
   long end_slot;
 } merge_ctx;
 
+/* set by the parallel stream walk when a stream is not in ascending order: the run is abandoned and repeated with the serial merge */
+static volatile int g_unordered = 0;
+#define RC_UNORDERED 77
+
 static size_t MG_CHUNK = 65536;        /* slots per work item of the column pass (<= TILE) */
 
 static void
@@ -383,7 +387,12 @@ merge_streams (void *arg)
           for (;;)
             {
               if ((unsigned long long) pos < (unsigned long long) c->p0 + done)
-                die ("\n pecaller_hip: the records of %s are not in ascending order", s->name);
+                {
+                  /* a record at or in front of the stream's previous one: the parallel walk rests on ascending streams (as pemapper
+                     writes them); the run starts over with the reference's own dispatcher, which takes what comes (run_once) */
+                  g_unordered = 1;
+                  return NULL;
+                }
               const size_t slot = (size_t) (pos - c->p0);
               if (slot != done)
                 memset (plane + done * NA, 0, (slot - done) * NA * sizeof (uint16_t));
@@ -479,7 +488,7 @@ merge_columns (void *arg)
 static void
 run_threads (void *(*fn) (void *), merge_ctx * ctx, int T)
 {
-  pthread_t th[64];
+  pthread_t th[128];
   for (int k = 1; k < T; k++)
     if (pthread_create (&th[k], NULL, fn, &ctx[k]))
       die ("\n pecaller_hip: can not start %s", "a merge thread");
@@ -686,10 +695,14 @@ next_guide_interval (FILE * guide_file, char **contig_names, int no_contigs, con
 }
 
 
-int
-main (int argc, char *argv[])
+/* serial_merge: the pileup streams are merged the reference's way, one column at a time from the lowest pending position of all
+   streams (find_lowest, pecaller.c:865-923, 1820-1833) -- whatever order the records come in; otherwise by the parallel walk, and
+   RC_UNORDERED is returned as soon as that meets a record out of order (what has been written by then is written over by the repeat) */
+static int
+run_once (int argc, char *argv[], int serial_merge)
 {
   char ss[4096], sdxname[4096];
+  g_unordered = 0;
   if (argc < 10 || argc > 13)
     {
       printf
@@ -734,7 +747,7 @@ main (int argc, char *argv[])
   sbuf ob = { NULL, 0, 0 };
   FILE *snpfile, *distfile;
   sprintf (ss, "%s.base.gz", argv[4]);
-  const int pgz_rc = pgz_open (&outfile, ss, no_threads > 32 ? 32 : no_threads);
+  const int pgz_rc = pgz_open (&outfile, ss, no_threads > 64 ? 64 : no_threads);
   /* the rows are ~280 bytes of text per column and 64 samples: at zlib's default level their deflate is the largest single item of the
      run's CPU time (12 of ~30 core-seconds per 8 M columns); level 2 takes half of that for a file 1.4 times the size */
   if (!getenv ("PEMAP_GZ_LEVEL"))
@@ -963,20 +976,20 @@ main (int argc, char *argv[])
       pool_put (&pool, one);
     }
   tile_t t = pool_get (&pool);
-  /* the threads of the merge and of the row formatting: the reference's worker threads minus its dispatcher, at most 32 */
+  /* the threads of the merge and of the row formatting: the reference's worker threads minus its dispatcher, as many as the host has CPUs and the run has streams, at most 128 */
   int MT = no_threads - 1;
   {
     const long ncpu = sysconf (_SC_NPROCESSORS_ONLN);
     if (ncpu > 0 && MT > (int) ncpu)
       MT = (int) ncpu;
-    if (MT > 32)
-      MT = 32;
+    if (MT > 128)
+      MT = 128;
     if (MT > no_files)
       MT = no_files;
     if (MT < 1)
       MT = 1;
   }
-  merge_ctx mc[32];
+  merge_ctx mc[128];
   long *chunk_base = (long *) calloc (TILE / MG_CHUNK, sizeof (long));
   uint16_t *planes = NULL;
   uint8_t *marks = NULL;
@@ -1036,6 +1049,8 @@ main (int argc, char *argv[])
   const int start_chrom = (no_contigs - 1) / 2 > 0 ? (no_contigs - 1) / 2 : 0;
   for (int k = 0; k < MT; k++)
     mc[k].start_chrom = start_chrom;
+  if (serial_merge)
+    GUIDE_RANGE_MIN = ~0ull;    /* (every guide position through the per-column scan, which is the reference's) */
   /* guide mode state: the current interval [lowest, end] of contig `gwhich` (pecaller.c:927-953, 1040-1066) */
   unsigned int lowest = 0, gend = 0;
   int gwhich = -1;
@@ -1065,7 +1080,45 @@ main (int argc, char *argv[])
   while (running > 0 || t.n > 0)
     {
       int tile_done = 0;
-      if (running > 0 && !guide_file)
+      if (running > 0 && !guide_file && serial_merge)
+        {
+          /* one column, the reference's way (pecaller.c:865-923): the lowest pending position of all streams, the streams that have a
+             record there, zeros for the others; a stream's records are taken in the order they come */
+          unsigned int lowest = 0;
+          for (int i = 0; i < no_files; i++)
+            if (sm[i].cur > 0 && (lowest == 0 || sm[i].cur < lowest))
+              lowest = sm[i].cur;
+          const int which = find_chrom (frag_pos, 0, no_contigs - 1, start_chrom, lowest);
+          const char ref = lowest < gsize ? genome[lowest] : '\0';
+          const long sl = t.n++;
+          t.ref_char[sl] = ref;
+          t.ref_base[sl] = (uint8_t) gen_to_int (ref);
+          t.contig[sl] = which;
+          t.pos[sl] = 1 + lowest - frag_pos[which - 1];
+          t.chrom[sl] = chrom_type[which];
+          tot_bases++;
+          uint16_t *col = t.reads + (size_t) sl * indiv * NA;
+          for (int i = 0; i < no_files; i++)
+            if (sm[i].cur == lowest)
+              {
+                unsigned int cov = 0;
+                for (int a = 0; a < NA; a++)
+                  {
+                    col[i * NA + a] = sm[i].data[a];
+                    cov += sm[i].data[a];
+                  }
+                sm[i].mean += (double) cov;
+                if (cov > sm[i].max_coverage)
+                  sm[i].max_coverage = cov;
+                sm[i].counts[cov < MAX_DIST - 1 ? cov : MAX_DIST - 1]++;
+                sm[i].base_count++;
+                advance (&sm[i], &running);
+              }
+            else
+              for (int a = 0; a < NA; a++)
+                col[i * NA + a] = 0;
+        }
+      else if (running > 0 && !guide_file)
         {
           /* the next range of positions: from the lowest pending position of all streams (find_lowest, pecaller.c:1820-1833) */
           unsigned int p0 = 0;
@@ -1078,6 +1131,12 @@ main (int argc, char *argv[])
               mc[k].p1 = (unsigned long long) p0 + TILE;
             }
           run_threads (merge_streams, mc, MT);
+          if (g_unordered)
+            {
+              running = 0;      /* (the run is abandoned: what is in flight is finished and closed, run_once returns RC_UNORDERED) */
+              t.n = 0;
+              continue;
+            }
           run_threads (merge_count, mc, MT);
           long ncol = 0;
           for (size_t ch = 0; ch < TILE / MG_CHUNK; ch++)
@@ -1110,6 +1169,12 @@ main (int argc, char *argv[])
               mc[k].col0 = t.n;
             }
           run_threads (merge_streams, mc, MT);
+          if (g_unordered)
+            {
+              running = 0;
+              t.n = 0;
+              continue;
+            }
           /* The reference's loop runs while a stream is open (pecaller.c:952): the column at which the last stream ends is the last one.
              The walk above went over the whole stretch: cut it there, and take the positions behind the cut out of every stream's
              count of positions seen again. */
@@ -1287,5 +1352,22 @@ main (int argc, char *argv[])
   for (int i = 0; i < no_files; i++)
     zr_close (&sm[i].f);
   pecall_dev_destroy (pc);
-  return 0;
+  if (guide_file)
+    fclose (guide_file);
+  return g_unordered ? RC_UNORDERED : 0;
+}
+
+int
+main (int argc, char *argv[])
+{
+  /* PECALLER_SERIAL_MERGE=1: the serial merge from the start (pileup files known to be out of order) */
+  const char *e = getenv ("PECALLER_SERIAL_MERGE");
+  int rc = run_once (argc, argv, e && atoi (e));
+  if (rc == RC_UNORDERED)
+    {
+      printf ("\n pecaller_hip: a pileup stream is not in ascending order: starting over with the serial merge (the reference's dispatcher) \n");
+      fflush (stdout);
+      rc = run_once (argc, argv, 1);
+    }
+  return rc;
 }

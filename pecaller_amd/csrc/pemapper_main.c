@@ -11,7 +11,7 @@
  * formats (pemapper.c:775-781, 819-900).
  *
  * Differences from the reference, all outside the hot path: `threads` bounds the host threads that deflate the pileup (the
- * batch itself goes to the GPU) and, over three, the files of an array that are read side by side (a worker per file pair, at most 8:
+ * batch itself goes to the GPU) and, over three, the files of an array that are read side by side (a worker per file pair, at most 64:
  * PEMAPPER_FILE_WORKERS); batches are handed over with pemap_dev_submit_batch, so the next one is parsed while the
  * GPU maps; <out>.pileup.gz is a sequence of gzip members (it inflates to the reference's bytes); the index arrays are rebuilt on the GPU from <sdx>.seq instead of inflating the 16 GiB <sdx>.idx (the device
  * builder is verified to produce the reference builder's arrays; set PEMAP_INDEX_FROM_FILES=1 to load .idx/.mdx);
@@ -874,8 +874,8 @@ main (int argc, char *argv[])
     c.io_threads = max_threads - 1;     /* one of the reference's threads is its reader (pemapper.c:360-365) */
     if (ncpu > 0 && c.io_threads > (int) ncpu)
       c.io_threads = (int) ncpu;
-    if (c.io_threads > 32)
-      c.io_threads = 32;
+    if (c.io_threads > 192)
+      c.io_threads = 192;
   }
   printf ("\n About to read kmers index \n\n");
   const char *from_files = getenv ("PEMAP_INDEX_FROM_FILES");
@@ -932,10 +932,10 @@ main (int argc, char *argv[])
 
   char basename[1024];
   snprintf (basename, sizeof basename, "%s", argv[1]);
-  /* workers: a file pair keeps ~4 host threads busy (two inflate threads, two line scans); at most 8 files at a time */
+  /* workers: a file pair keeps ~4 host threads busy (two inflate threads, two line scans); as many files at a time as a third of the threads (<= the host's CPUs), at most 64 */
   int n_workers = c.io_threads / 3;
-  if (n_workers > 8)
-    n_workers = 8;
+  if (n_workers > 64)
+    n_workers = 64;
   if (n_workers > file_num)
     n_workers = file_num;
   if (n_workers < 1)

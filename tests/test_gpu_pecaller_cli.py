@@ -287,3 +287,52 @@ def test_pecaller_cli_guide_mode_ends_with_the_last_stream(tmp_path, range_min, 
         assert g[0] == e[0]
         if len(g) > 1:
             assert dict(zip(got_d[0][1:], g[1:])) == dict(zip(exp_d[0][1:], e[1:])), g[0]
+
+
+@pytest.mark.parametrize("serial_from_start", [False, True])
+def test_pecaller_cli_takes_streams_that_are_not_ascending(tmp_path, serial_from_start, monkeypatch):
+    """two records swapped, one moved ten columns back and one position twice in two of the eight pileup streams: the reference's
+    dispatcher takes the lowest pending position whatever the order (pecaller.c:865-923), so the late and the repeated records become
+    columns of their own.  pecaller_hip's parallel walk of the streams notices the first record out of order, says so, and starts
+    over with the reference's serial merge (or is told to use it from the start): the unmodified reference's rows and .dist
+    (tests/golden/make_golden_pecall_unordered.py)"""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("mk_unordered", os.path.join(fx.GOLD, "make_golden_pecall_unordered.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    if serial_from_start:
+        monkeypatch.setenv("PECALLER_SERIAL_MERGE", "1")
+    monkeypatch.setenv("PECALLER_TILE_LOG2", "10")
+    z = np.load(os.path.join(fx.GOLD, "pecall_sites.npz"))
+    names = [str(x) for x in z["names"]]
+    dist_spec = json.load(open(os.path.join(fx.GOLD, "pecall_unordered.json")))
+    _, seqs = refio.read_fasta(os.path.join(fx.GOLD, "g1.fa.gz"))
+    shutil.copy(os.path.join(fx.GOLD, "g1.sdx"), tmp_path / "g1.sdx")
+    with gzip.open(tmp_path / "g1.seq", "wb", compresslevel=1) as f:
+        f.write(np.concatenate(seqs).tobytes())
+    run = tmp_path / "run"
+    run.mkdir()
+    for s, nm in enumerate(names):
+        with gzip.open(run / ("%s.pileup.gz" % nm), "wb", compresslevel=1) as f:
+            f.write(b"".join(mk.stream_records(z, s, dist_spec)))
+    out = subprocess.run([EXE, "pileup", str(tmp_path / "g1.sdx"), "20", "out", "0.95", "0.001", "n", "8", "n"], cwd=run, stdout=subprocess.PIPE, check=True).stdout
+    assert (b"starting over with the serial merge" in out) == (not serial_from_start)
+    last = int(z["pos"][-1]) + 1
+    keep = lambda rows: sorted(x for x in rows if x and int(x.split("\t")[1]) <= last)
+    base = gzip.open(run / "out.base.gz", "rt").read().split("\n")
+    exp = gzip.open(os.path.join(fx.GOLD, "pecall_unordered.base.txt.gz"), "rt").read().split("\n")
+    got_rows, exp_rows = keep(base[1:]), [x for x in exp[1:] if x]
+    assert [x.split("\t")[:2] for x in got_rows] == [x.split("\t")[:2] for x in exp_rows]       # 5,910 rows, three positions twice
+    cols = [c for c in base[0].split("\t")[3:] if c]
+    if cols == [c for c in exp[0].split("\t")[3:] if c]:
+        assert got_rows == exp_rows
+        snp = open(run / "out.snp").read().split("\n")
+        assert keep(snp[1:]) == [x for x in open(os.path.join(fx.GOLD, "pecall_unordered.snp.txt")).read().split("\n")[1:] if x]
+    got_d = [x.split("\t") for x in open(run / "out.dist").read().split("\n")]
+    exp_d = [x.split("\t") for x in open(os.path.join(fx.GOLD, "pecall_unordered.dist.txt")).read().split("\n")]
+    assert len(got_d) == len(exp_d)
+    for g, e in zip(got_d, exp_d):
+        assert g[0] == e[0]
+        if len(g) > 1:
+            assert dict(zip(got_d[0][1:], g[1:])) == dict(zip(exp_d[0][1:], e[1:])), g[0]
