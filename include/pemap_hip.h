@@ -231,8 +231,8 @@ int pecall_dev_collect (pecall_dev * dev, int n_sites, int indiv, double *like, 
  *   site_type[n_sites]  (may be NULL) 0 reference, 1 SNP, 2 DEL, 3 INS, 4 LOW, 5 MULTIALLELIC, 6 MESS
  *   allele_count[n_sites][6], n_pass[n_sites]  (may be NULL) Allele_Counts of the .snp row; passes run
  *   denovo[n_sites]     (may be NULL) d_count of the row (pecaller.c:1650-1671): > 0 = the type is printed as DENOVO_<type>
- * indiv <= 256: up to 64 samples one lane per sample (the fast case: shortcut kernel + beam search of the columns it lists);
- * 65..256 a lane stands for a sample of each chunk of 64 and every column takes the beam search's kernel.  Text formatting and
+ * indiv <= 512: up to 64 samples one lane per sample (the fast case: shortcut kernel + beam search of the columns it lists);
+ * 65..512 a lane stands for a sample of each chunk of 64 and every column takes the beam search's kernel (257..512: one wave per CU).  Text formatting and
  * the merge of the pileup streams stay on the host.
  * The columns travel in chunks of 2^18 (PECALL_CHUNK_LOG2): the host-to-device copy of chunk k + 1, the kernels of chunk k and the
  * device-to-host copy of chunk k - 1 run side by side.  Arrays the caller page-locked with pecall_dev_pin_host are copied from and

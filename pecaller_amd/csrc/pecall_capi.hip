@@ -388,7 +388,7 @@ static int pcs_ensure (pecall_dev * d, long n_sites, int indiv)
       free (off);
       d->hw_indiv = indiv;
     }
-  const int row = 64 * ((indiv + 63) / 64 > 2 ? 4 : (indiv + 63) / 64);
+  const int row = 64 * ((indiv + 63) / 64 > 4 ? 8 : (indiv + 63) / 64 > 2 ? 4 : (indiv + 63) / 64);
   if (!d->d_scratch || row > d->scratch_row)
     {
       PCCHK (d, hipDeviceSynchronize ());
@@ -639,6 +639,7 @@ static int pcs_ensure_chunks (pecall_dev * d, long n_sites)
       }
       PCCHK (d, hipFuncSetAttribute ((const void *) pcs_fast_kernel < PC_TABLE >, hipFuncAttributeMaxDynamicSharedMemorySize, PCS_FAST_LDS_BYTES_OF (PC_TABLE)));
       PCCHK (d, hipFuncSetAttribute ((const void *) pcs_call_kernel < 4 >, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof (PcsShared < 4 >)));
+      PCCHK (d, hipFuncSetAttribute ((const void *) pcs_call_kernel < 8 >, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof (PcsShared < 8 >)));
     }
   if (!d->ev_site[0])
     {
@@ -708,7 +709,7 @@ static int pcs_chunk_kernels (pecall_dev * d, const PcsParams & P, int k, long o
   unsigned *slow = d->d_slow + (size_t) PCS_BUCKETS * off;
   unsigned *n_deep = (unsigned *) (ctr + 3), *next_piece = (unsigned *) (ctr + 4);
   unsigned *deep_list = d->d_deep + off;
-  const int nch = N <= 64 ? 1 : N <= 128 ? 2 : 4;
+  const int nch = N <= 64 ? 1 : N <= 128 ? 2 : N <= 256 ? 4 : 8;
   // (second pass: behind the first pass's beam search of the chunk, which shares these counters; the deep list's length stays)
   if (whole_table)
     {
@@ -769,8 +770,10 @@ static int pcs_chunk_kernels (pecall_dev * d, const PcsParams & P, int k, long o
     PCS_CALL (1, slow, n_slow);
   else if (nch == 2)
     PCS_CALL (2, (const unsigned *) nullptr, (const unsigned *) nullptr);
-  else
+  else if (nch == 4)
     PCS_CALL (4, (const unsigned *) nullptr, (const unsigned *) nullptr);
+  else
+    PCS_CALL (8, (const unsigned *) nullptr, (const unsigned *) nullptr);       // (257 .. 512 samples: 124 KB of LDS, one wave per CU at a time)
 #undef PCS_CALL
   if (heavy == 2)
     PCCHK (d, hipStreamWaitEvent (sc, d->ev_heavy_k[k], 0));    // (the chunk's results are whole when its early beam search is through too)

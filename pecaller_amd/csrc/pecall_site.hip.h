@@ -18,11 +18,12 @@
 // configurations, so the pools sit in LDS (32 entries); a column whose list outgrows that moves to per-wave pools in HBM
 // (flat pointers: the code is the same) for the rest of its passes.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "pecall_kernels.hip.h"
 
-#define PCS_MAXN 256            // samples per call at most: one lane per sample and chunk of 64 (NCH = 1, 2 or 4 chunks)
+#define PCS_MAXN 512            // samples per call at most: one lane per sample and chunk of 64 (NCH = 1, 2, 4 or 8 chunks; 8: 124 KB of LDS, a wave per CU)
 #define PCS_ROW(NCH) (64 * (NCH))
 #define PCS_NA 6
 #define PCS_NG 14
@@ -83,7 +84,7 @@ template < int NCH > struct __align__ (16) PcsShared
   int al[PCS_NG][PCS_NA], first[PCS_NG][PCS_NA];
   int reads[PCS_ROW (NCH)][PCS_NA];
   int tot[PCS_ROW (NCH)];
-  uint8_t sord[PCS_ROW (NCH)];          // samples by margin, descending
+  typename std::conditional < (NCH > 4), uint16_t, uint8_t >::type sord[PCS_ROW (NCH)];          // samples by margin, descending (a byte each while they are at most 256)
   uint8_t dup[PCS_SMALLCAP];
 };
 
@@ -998,7 +999,7 @@ template < int NCH > __global__ __launch_bounds__ (64) void pcs_call_kernel (Pcs
 #pragma unroll
             for (int c = 0; c < NCH; c++)
               if (64 * c + lane < N)
-                sh.sord[rank[c]] = (uint8_t) (64 * c + lane);
+                sh.sord[rank[c]] = (typename std::conditional < (NCH > 4), uint16_t, uint8_t >::type) (64 * c + lane);
           }
           pcs_sync ();
           for (int i = lane; i < total; i += 64)

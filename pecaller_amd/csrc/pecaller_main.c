@@ -17,7 +17,7 @@
  * With a BED guide file (the last argument, pecaller.c:925-1068) every position of the listed intervals is called, covered
  * or not, and columns on chrY / chrMT are called with HAPLOID forced (955-957).
  *
- * Not supported (an error, not a silent difference): more than 256 samples (up to 64 is the device caller's fast case).  `no_threads` - 1 threads (as many as the host has CPUs, at most 128) walk the pileup streams, format the rows and deflate <outfile>.base.gz.
+ * Not supported (an error, not a silent difference): more than 512 samples (up to 64 is the device caller's fast case).  `no_threads` - 1 threads (as many as the host has CPUs, at most 128) walk the pileup streams, format the rows and deflate <outfile>.base.gz.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -33,7 +33,7 @@
 #include "../../include/pemap_hip.h"
 #include "host_io.h"
 
-#define MAX_SAMPLES 256         /* PCS_MAXN of the device caller */
+#define MAX_SAMPLES 512         /* PCS_MAXN of the device caller */
 #define NA 6
 #define MAX_DIST 501            /* pecaller.c:222 */
 /* columns per device call, and genome positions per range of the stream merge.  A call has a fixed part (two kernel launches, the
@@ -850,7 +850,7 @@ run_once (int argc, char *argv[], int serial_merge)
   const int indiv = no_files;
   printf ("\n Found a total of %d individuals\n\n", indiv);
   if (indiv < 1 || indiv > MAX_SAMPLES)
-    die ("\n pecaller_hip: %s samples; the device caller takes 1 to 256 (64 and fewer are its fast case)", argv[3]);
+    die ("\n pecaller_hip: %s samples; the device caller takes 1 to 512 (64 and fewer are its fast case)", argv[3]);
 
   pecall_dev *pc;
   if (pecall_dev_create (&pc, getenv ("PEMAP_DEVICE") ? atoi (getenv ("PEMAP_DEVICE")) : 0))

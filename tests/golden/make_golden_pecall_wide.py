@@ -5,6 +5,7 @@ oracle/_ref): the reference takes any INDIV (pecaller.c:251-257); the device cal
 Runs the UNMODIFIED reference (oracle/_ref/pecaller, gcc -O1, one worker thread) on synthetic binary pileups of 100 samples
 over 1,500 columns and stores, under tests/golden/:
 
+  (python3 tests/golden/make_golden_pecall_wide.py --samples 300 --sites 400 --tag pecall_wide300: the same beyond 256 samples)
   pecall_wide.npz          inputs: reads[site][sample][6] (u16), pos[site], sample names, the reference's column order
   pecall_wide.base.txt.gz  the reference's <out>.base.gz rows, sorted
   pecall_wide.snp.txt      the reference's <out>.snp rows, sorted
@@ -31,6 +32,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--work", default="/tmp/gold_wide")
     ap.add_argument("--samples", type=int, default=100)
+    ap.add_argument("--sites", type=int, default=1500)
+    ap.add_argument("--tag", default="pecall_wide", help="name of the stored files (pecall_wide300: --samples 300 --sites 400, beyond 256 samples)")
     a = ap.parse_args()
     W = a.work
     shutil.rmtree(W, ignore_errors=True)
@@ -45,12 +48,13 @@ def main():
     rng = np.random.default_rng(10100)
     n_samp = a.samples
     names = ["w%03d" % i for i in range(n_samp)]
-    first, n_sites = 5000, 1500
+    first, n_sites = 5000, a.sites
     code = {65: 0, 67: 1, 71: 2, 84: 3}
     ref = np.array([code.get(seq[first + i], -1) for i in range(n_sites)])
     depth = rng.integers(18, 45, n_samp)
     depth[7] = 3                # a sample under the depth floor most of the time
-    depth[70] = 6
+    if n_samp > 70:
+        depth[70] = 6
     is_var = rng.random(n_sites) < 0.04
     q = rng.uniform(0.03, 0.6, n_sites)
     alt = rng.integers(0, 6, n_sites)
@@ -98,11 +102,11 @@ def main():
     last = int(pos[-1]) + 1                            # all sites lie in the first contig
     keep_rows = [x for x in rows if int(x.split("\t")[1]) <= last]
     keep_snp = [x for x in snp_rows if int(x.split("\t")[1]) <= last]
-    with gzip.open(os.path.join(HERE, "pecall_wide.base.txt.gz"), "wt") as f:
+    with gzip.open(os.path.join(HERE, a.tag + ".base.txt.gz"), "wt") as f:
         f.write(hdr + "\n" + "\n".join(keep_rows) + "\n")
-    with open(os.path.join(HERE, "pecall_wide.snp.txt"), "w") as f:
+    with open(os.path.join(HERE, a.tag + ".snp.txt"), "w") as f:
         f.write(snp[0] + "\n" + "\n".join(keep_snp) + "\n")
-    np.savez_compressed(os.path.join(HERE, "pecall_wide.npz"), reads=reads, pos=pos.astype(np.uint32), names=np.array(names),
+    np.savez_compressed(os.path.join(HERE, a.tag + ".npz"), reads=reads, pos=pos.astype(np.uint32), names=np.array(names),
                         columns=np.array(cols), pad=np.array([pad]))
     print("sites", n_sites, "samples", n_samp, "base rows", len(keep_rows), "snp rows", len(keep_snp))
 
