@@ -252,7 +252,7 @@ def main():
     ap.add_argument("--pecall-sites", type=int, default=2000000,
                     help="columns per launch of the PECaller leg (a launch ends with its slowest column: the few hundred-configuration "
                          "variant columns take ~50-90 ms each on one wave, so short launches measure that tail, not the rate)")
-    ap.add_argument("--pecall-wide-sites", type=int, default=200000, help="columns of the 128-sample data point of the PECaller leg (0 = skip)")
+    ap.add_argument("--pecall-wide-sites", type=int, default=1000000, help="columns of the 128-sample data point of the PECaller leg (0 = skip)")
     ap.add_argument("--pecall-cpu-seconds", type=float, default=10.0)
     ap.add_argument("--host-batches", type=int, default=4, help="distinct batches staged (and pinned) on the host; the steps cycle through them")
     ap.add_argument("--allow-fallback", action="store_true",
@@ -726,8 +726,8 @@ def pecaller_leg(a):
     kernel_ms = float(np.mean(kms))
     c2, p2 = pc.sites_collect()[:2]
     assert np.array_equal(c2, call) and np.array_equal(p2, post)
-    # beyond the fast case: 128 samples (65 .. 256 take the beam search's kernel for every column: no shortcut form), resident columns,
-    # a sample of them against the oracle
+    # beyond a lane per sample: 128 samples (the shortcut kernel with two samples per lane, round 4; 129 .. 512 take the beam search's
+    # kernel for every column), resident columns, a sample of them against the oracle
     wide = None
     if a.pecall_wide_sites > 0:
         nw, SW = a.pecall_wide_sites, 128
@@ -738,7 +738,7 @@ def pecaller_leg(a):
         chk = min(nw, 2000)
         oc, op = oracle_py.call_sites(wr[:chk], wd[:chk])[:2]
         wide = {"samples": SW, "columns": nw, "value": round(nw / (min(wms) * 1e-3) / 1e6, 4), "unit": "M columns/s", "kernel_ms": round(min(wms), 2),
-                "form": "pcs_call_kernel<2> on every column (no shortcut beyond 64 samples)",
+                "form": "pcs_fast_kernel<2048, 2> (two samples per lane) + pcs_call_kernel<2> of the columns it and pcs_heavy_kernel list",
                 "calls_equal_oracle": bool(np.array_equal(wc[:chk], oc)), "max_abs_dposterior": float(np.max(np.abs(wp[:chk] - op))), "compared_columns": chk}
         del wr, wd, wc, wp
     pc.close()

@@ -637,7 +637,8 @@ static int pcs_ensure_chunks (pecall_dev * d, long n_sites)
         const char *e = getenv ("PECALL_HEAVY_MIN");
         d->heavy_min = (e && *e) ? atoi (e) : 1;
       }
-      PCCHK (d, hipFuncSetAttribute ((const void *) pcs_fast_kernel < PC_TABLE >, hipFuncAttributeMaxDynamicSharedMemorySize, PCS_FAST_LDS_BYTES_OF (PC_TABLE)));
+      PCCHK (d, hipFuncSetAttribute ((const void *) pcs_fast_kernel < PC_TABLE, 1 >, hipFuncAttributeMaxDynamicSharedMemorySize, PCS_FAST_LDS_BYTES_OF (PC_TABLE)));
+      PCCHK (d, hipFuncSetAttribute ((const void *) pcs_fast_kernel < PC_TABLE, 2 >, hipFuncAttributeMaxDynamicSharedMemorySize, PCS_FAST_LDS_BYTES_OF (PC_TABLE)));
       PCCHK (d, hipFuncSetAttribute ((const void *) pcs_call_kernel < 4 >, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof (PcsShared < 4 >)));
       PCCHK (d, hipFuncSetAttribute ((const void *) pcs_call_kernel < 8 >, hipFuncAttributeMaxDynamicSharedMemorySize, (int) sizeof (PcsShared < 8 >)));
     }
@@ -717,7 +718,7 @@ static int pcs_chunk_kernels (pecall_dev * d, const PcsParams & P, int k, long o
       PCCHK (d, hipMemsetAsync (ctr, 0, 3 * sizeof (unsigned long long), d->stream));
       PCCHK (d, hipMemsetAsync (ctr + 4, 0, sizeof (unsigned long long), d->stream));
     }
-  if (nch != 1)
+  if (nch > 2)
     heavy = 0;
   if (heavy == 2 && !whole_table)
     {
@@ -725,18 +726,25 @@ static int pcs_chunk_kernels (pecall_dev * d, const PcsParams & P, int k, long o
       if (rc)
         return rc;
     }
-  if (nch == 1)
+  if (nch <= 2)
     {
+      // the shortcut kernel: a lane per sample up to 64 samples, two samples per lane up to 128 (round 4)
+#define PCS_FAST(TAB_, NCH_, GRID_) hipLaunchKernelGGL (HIP_KERNEL_NAME (pcs_fast_kernel < TAB_, NCH_ >), dim3 ((unsigned) (GRID_)), dim3 (PCS_FAST_BLOCK_OF (TAB_)), \
+    PCS_FAST_LDS_BYTES_OF (TAB_), d->stream, P, d->d_sreads + off * N * PCS_NA, d->d_dom + off, d->d_chromy + off, m, d->d_call + off * N, d->d_post + off * N, \
+    d->d_type + off, d->d_ac + off * PCS_NA, d->d_npass + off, d->d_den + off, slow, n_slow, deep_list, n_deep, next_piece, d->d_ta, \
+    heavy ? (const uint8_t *) d->d_heavy_flag + off : (const uint8_t *) nullptr)
       if (!whole_table)
         {
           constexpr int B = PCS_FAST_BLOCK_OF (PCS_FAST_TAB);
           long fgrid = (m + B / 64 - 1) / (B / 64);
-          if (fgrid > (long) d->grid / 2 * 3)
-            fgrid = (long) d->grid / 2 * 3;     // three workgroups of 4 waves per CU
-          hipLaunchKernelGGL (HIP_KERNEL_NAME (pcs_fast_kernel < PCS_FAST_TAB >), dim3 ((unsigned) fgrid), dim3 (B), PCS_FAST_LDS_BYTES_OF (PCS_FAST_TAB), d->stream, P,
-                              d->d_sreads + off * N * PCS_NA, d->d_dom + off, d->d_chromy + off, m, d->d_call + off * N, d->d_post + off * N, d->d_type + off,
-                              d->d_ac + off * PCS_NA, d->d_npass + off, d->d_den + off, slow, n_slow, deep_list, n_deep, next_piece, d->d_ta,
-                              heavy ? (const uint8_t *) d->d_heavy_flag + off : (const uint8_t *) nullptr);
+          // three workgroups of 4 waves per CU (two with two samples per lane: the registers)
+          const long cap = nch == 1 ? (long) d->grid / 2 * 3 : (long) d->grid;
+          if (fgrid > cap)
+            fgrid = cap;
+          if (nch == 1)
+            PCS_FAST (PCS_FAST_TAB, 1, fgrid);
+          else
+            PCS_FAST (PCS_FAST_TAB, 2, fgrid);
         }
       else
         {
@@ -744,16 +752,17 @@ static int pcs_chunk_kernels (pecall_dev * d, const PcsParams & P, int k, long o
           long fgrid = (m + B / 64 - 1) / (B / 64);
           if (fgrid > d->grid / 2)
             fgrid = d->grid / 2;        // one workgroup per CU: the whole ln n! table takes half its LDS
-          hipLaunchKernelGGL (HIP_KERNEL_NAME (pcs_fast_kernel < PC_TABLE >), dim3 ((unsigned) fgrid), dim3 (B), PCS_FAST_LDS_BYTES_OF (PC_TABLE), d->stream, P,
-                              d->d_sreads + off * N * PCS_NA, d->d_dom + off, d->d_chromy + off, m, d->d_call + off * N, d->d_post + off * N, d->d_type + off,
-                              d->d_ac + off * PCS_NA, d->d_npass + off, d->d_den + off, slow, n_slow, deep_list, n_deep, next_piece, d->d_ta,
-                              heavy ? (const uint8_t *) d->d_heavy_flag + off : (const uint8_t *) nullptr);
+          if (nch == 1)
+            PCS_FAST (PC_TABLE, 1, fgrid);
+          else
+            PCS_FAST (PC_TABLE, 2, fgrid);
         }
+#undef PCS_FAST
     }
   else if (whole_table)
-    return 0;                   // (more than 64 samples: one form only)
-  // (more than 64 samples: no shortcut kernel; the beam search's kernel takes every column of the chunk, a lane standing for a
-  // sample of each chunk of 64 -- the reference's range, any INDIV (pecaller.c:251-257), not this library's fast case)
+    return 0;                   // (more than 128 samples: one form only)
+  // (more than 128 samples: no shortcut kernel; the beam search's kernel takes every column of the chunk, a lane standing for a
+  // sample of each chunk of 64)
   PCCHK (d, hipEventRecord (d->ev_fast[k], d->stream));
   // (a chunk lists a few hundred columns for the beam search, a handful of them heavy -- milliseconds on one wave: behind each other
   // on one stream the chunks' searches were the caller's time, 8 x 5.5 ms.  They alternate on PCS_CALL_STREAMS streams.)
@@ -769,7 +778,7 @@ static int pcs_chunk_kernels (pecall_dev * d, const PcsParams & P, int k, long o
   if (nch == 1)
     PCS_CALL (1, slow, n_slow);
   else if (nch == 2)
-    PCS_CALL (2, (const unsigned *) nullptr, (const unsigned *) nullptr);
+    PCS_CALL (2, slow, n_slow);
   else if (nch == 4)
     PCS_CALL (4, (const unsigned *) nullptr, (const unsigned *) nullptr);
   else
@@ -807,11 +816,17 @@ static int pcs_heavy_start (pecall_dev * d, const PcsParams & P, long off, long 
                       n_list, d->d_heavy_flag + off);
   PCCHK (d, hipEventRecord (d->ev_heavy[0], d->stream));
   PCCHK (d, hipStreamWaitEvent (d->stream_heavy, d->ev_heavy[0], 0));
-  char *scratch = d->d_scratch + (size_t) d->site_grid * (2 * PCS_BIG_BYTES_OF (64) + PCS_BIGCAP);
+  const int row = N <= 64 ? 64 : 128;
+  char *scratch = d->d_scratch + (size_t) d->site_grid * (2 * PCS_BIG_BYTES_OF (row) + PCS_BIGCAP);
   const long grid = m < (long) d->heavy_grid ? m : (long) d->heavy_grid;
-  hipLaunchKernelGGL (HIP_KERNEL_NAME (pcs_call_kernel < 1 >), dim3 ((unsigned) grid), dim3 (64), sizeof (PcsShared < 1 >), d->stream_heavy, P,
-                      d->d_sreads + off * N * PCS_NA, d->d_dom + off, d->d_chromy + off, m, d->d_call + off * N, d->d_post + off * N, d->d_type + off,
-                      d->d_ac + off * PCS_NA, d->d_npass + off, d->d_den + off, scratch, ctr, (const unsigned *) list, (const unsigned *) n_list);
+#define PCS_HEAVY(NCH_) hipLaunchKernelGGL (HIP_KERNEL_NAME (pcs_call_kernel < NCH_ >), dim3 ((unsigned) grid), dim3 (64), sizeof (PcsShared < NCH_ >), d->stream_heavy, P, \
+                      d->d_sreads + off * N * PCS_NA, d->d_dom + off, d->d_chromy + off, m, d->d_call + off * N, d->d_post + off * N, d->d_type + off, \
+                      d->d_ac + off * PCS_NA, d->d_npass + off, d->d_den + off, scratch, ctr, (const unsigned *) list, (const unsigned *) n_list)
+  if (N <= 64)
+    PCS_HEAVY (1);
+  else
+    PCS_HEAVY (2);
+#undef PCS_HEAVY
   PCCHK (d, hipGetLastError ());
   PCCHK (d, hipEventRecord (done, d->stream_heavy));
   return 0;
@@ -822,8 +837,8 @@ static int pcs_deep_chunks (pecall_dev * d, const PcsParams & P, int nch, std::v
 {
   *n_deep = 0;
   deep.assign ((size_t) nch, 0);
-  if (P.indiv > 64)
-    return 0;
+  if (P.indiv > 128)
+    return 0;               // (no shortcut kernel, no deep list)
   // (into page-locked memory of the object's own: a pageable target that shares a page with an array the caller registered is refused)
   unsigned long long *c = d->h_ctrs;
   PCCHK (d, hipMemcpy (c, d->d_next_site, (size_t) nch * PCS_CTRS * sizeof (unsigned long long), hipMemcpyDeviceToHost));
@@ -855,7 +870,7 @@ extern "C" int pecall_dev_sites_run (pecall_dev * d, int haploid, double thresho
   std::vector < char >deep ((size_t) k, 0);
   // the long beam searches first (pcs_heavy_kernel): listed from the resident columns, started on a stream of their own beside everything
   // that follows -- a launch of the beam search ends with its slowest column, and the last chunk's used to be the run's last 8 ms
-  const bool heavy = indiv <= 64 && d->heavy_min > 0;
+  const bool heavy = indiv <= 128 && d->heavy_min > 0;
   if (heavy)
     if ((rc = pcs_heavy_start (d, P, 0, n_sites, 0, d->ev_heavy[1])))
       return rc;
@@ -1077,7 +1092,7 @@ static int pcs_call_sites_impl (pecall_dev * d, const uint16_t * reads, const ui
   {
     const long off = (long) j * C, m = n_sites - off < C ? n_sites - off : C;
     int rc2 = whole_table ? 0 : pcs_chunk_reset (d, P, j, off, m);
-    if (rc2 || (rc2 = pcs_chunk_kernels (d, P, j, off, m, whole_table, sparse, (N <= 64 && d->heavy_min > 0) ? 2 : 0)))
+    if (rc2 || (rc2 = pcs_chunk_kernels (d, P, j, off, m, whole_table, sparse, (N <= 128 && d->heavy_min > 0) ? 2 : 0)))
       return rc2;
     PCCHK (d, hipStreamWaitEvent (d->stream_d2h, d->ev_call[j], 0));
     char *o = out_direct ? nullptr : d->h_out[j % PCS_SLOTS];

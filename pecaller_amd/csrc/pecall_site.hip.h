@@ -1296,80 +1296,144 @@ template < int NCH > __global__ __launch_bounds__ (64) void pcs_call_kernel (Pcs
 // variant carrier: it would come first in the order), a list that grows past four configurations before the last expansion, no
 // homozygous configuration left after a cut (the fallback of 2286-2333), or calls that change (a second pass).
 #define PCS_MINI_U 4
-__device__ __forceinline__ int pcs_pack_ac (const int (&ac)[PCS_NA], int which)
+// allele counts of a configuration packed into ints: a byte each while the column has at most 64 samples (255 >= 2 x 64 alleles), 16 bits
+// each beyond (NCH chunks of 64 samples)
+template < int NCH > struct PcsAcPack
 {
-  return which ? (ac[3] | (ac[4] << 8) | (ac[5] << 16)) : (ac[0] | (ac[1] << 8) | (ac[2] << 16));
-}
+  static constexpr int BITS = NCH == 1 ? 8 : 16, PER = NCH == 1 ? 3 : 2, WORDS = PCS_NA / PER, MASK = (1 << BITS) - 1;
+  static __device__ __forceinline__ int pack (const int (&ac)[PCS_NA], int w)
+  {
+    int v = 0;
+#pragma unroll
+    for (int q = 0; q < PER; q++)
+      v |= ac[w * PER + q] << (BITS * q);
+    return v;
+  }
+  static __device__ __forceinline__ int get (const int (&word)[WORDS], int k)     // (k a compile-time constant at every use)
+  {
+    return (word[k / PER] >> (BITS * (k % PER))) & MASK;
+  }
+};
 
-__device__ bool pcs_mini_beam (const PcsParams & P, const double *tab_unused, const double (&lk)[PCS_NG], const int (&r)[PCS_NA], bool deep, bool ok, int best,
-                               double margin, int dom, int site_hap, uint8_t * w_sord, double *w_like, int lane, int &final_call, double &final_p)
+template < int NCH > __device__ bool pcs_mini_beam (const PcsParams & P, const double (&lk)[NCH][PCS_NG], const int (&r)[NCH][PCS_NA], const bool (&deep)[NCH],
+                                                    const bool (&ok)[NCH], const int (&best)[NCH], const double (&margin)[NCH], int dom, int site_hap,
+                                                    uint8_t * w_sord, double *w_like, int lane, int (&final_call)[NCH], double (&final_p)[NCH])
 {
+  typedef PcsAcPack < NCH > AC;
   const int N = P.indiv, G = P.max_gen;
-  const unsigned long long deep_m = __ballot (deep), unset_m = __ballot (deep && !ok);
-  const int nu = __popcll (unset_m);
+  unsigned long long deep_m[NCH], unset_m[NCH];
+  int nu = 0, n_deep = 0, n_set = 0;
+#pragma unroll
+  for (int c = 0; c < NCH; c++)
+    {
+      deep_m[c] = __ballot (deep[c]);
+      unset_m[c] = __ballot (deep[c] && !ok[c]);
+      nu += (int) __popcll (unset_m[c]);
+      n_deep += (int) __popcll (deep_m[c]);
+      n_set += (int) __popcll (deep_m[c] & ~unset_m[c]);
+    }
   if (P.use_ped || nu > PCS_MINI_U || nu == 0)
     return false;
-  if ((int) __popcll (deep_m) * (site_hap ? 1 : 2) > 255)
-    return false;               // (allele counts are packed in bytes here)
+  if (n_deep * (site_hap ? 1 : 2) > AC::MASK)
+    return false;               // (allele counts are packed here)
   // ---- the order of the samples: margin descending, sample index ascending on ties (sort_compare_sample_pointer; the sort is stable)
-  const double ip = deep ? margin : -1.0;        // (the samples under the depth floor last: they take no part in the beam)
-  int rank = 0;
+  double ip[NCH];               // (the samples under the depth floor last: they take no part in the beam)
+  int rank[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; c++)
+    {
+      ip[c] = deep[c] ? margin[c] : -1.0;
+      rank[c] = 0;
+    }
   for (int jn = 0; jn < N; jn++)
     {
-      const double pj = pcs_bcast (ip, jn);
-      rank += (pj > ip) || (pj == ip && jn < lane);
+      const double pj = pcs_bcast (pcs_chunk_of < NCH > (ip, jn), jn & 63);
+#pragma unroll
+      for (int c = 0; c < NCH; c++)
+        rank[c] += (pj > ip[c]) || (pj == ip[c] && jn < 64 * c + lane);
     }
-  const int n_set = (int) __popcll (deep_m & ~unset_m);
   // the unsettled samples must follow every settled one (the leading run of settled samples is then all of them)
-  if (__any (deep && !ok && rank < n_set))
-    return false;
-  if (lane < N)
-    w_sord[rank] = (uint8_t) lane;
+  {
+    bool early = false;
+#pragma unroll
+    for (int c = 0; c < NCH; c++)
+      early = early || (deep[c] && !ok[c] && rank[c] < n_set);
+    if (__any (early))
+      return false;
+  }
+#pragma unroll
+  for (int c = 0; c < NCH; c++)
+    if (64 * c + lane < N)
+      w_sord[rank[c]] = (uint8_t) (64 * c + lane);
   pcs_sync ();
-  const int sord = (int) w_sord[lane];
+  int sord[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; c++)
+    sord[c] = (int) w_sord[64 * c + lane];
+  auto sample_at = [&] (int k)->int     // (k the same in every lane)
+  {
+    return pcs_bcast (pcs_chunk_of < NCH > (sord, k), k & 63);
+  };
   // ---- fill_config_like of the all-reference configuration (pecaller.c:2347-2360): the deep samples' likelihoods of `dom`, in
   //      sample order; then the settled samples' expansions, each of which leaves (L - l) + l
-  double lk_dom = 0.0;
+  double lk_dom[NCH];
 #pragma unroll
-  for (int g = 0; g < 4; g++)
-    lk_dom = (g == dom) ? lk[g] : lk_dom;
+  for (int c = 0; c < NCH; c++)
+    {
+      lk_dom[c] = 0.0;
+#pragma unroll
+      for (int g = 0; g < 4; g++)
+        lk_dom[c] = (g == dom) ? lk[c][g] : lk_dom[c];
+    }
   double L = 0.0;
   for (int i = 0; i < N; i++)
-    if ((deep_m >> i) & 1ull)
-      L += pcs_bcast (lk_dom, i);
+    if ((pcs_chunk_of < NCH > (deep_m, i) >> (i & 63)) & 1ull)
+      L += pcs_bcast (pcs_chunk_of < NCH > (lk_dom, i), i & 63);
   for (int k = 0; k < n_set; k++)
     {
-      const double l = pcs_bcast (lk_dom, pcs_bcast (sord, k));
+      const int who = sample_at (k);
+      const double l = pcs_bcast (pcs_chunk_of < NCH > (lk_dom, who), who & 63);
       L = (L - l) + l;
     }
   // ---- the list: configuration i in lane i
   double c_like = L, c_prior = 0.0, c_post = 0.0 + L;
-  int c_ac0, c_ac1, c_misc = 1 << 8;   // misc: hets | nall << 8 | genotypes of the unsettled samples << 12
+  int c_ac[AC::WORDS], c_misc = 1 << 8;   // misc: hets | nall << 8 | genotypes of the unsettled samples << 12
   {
     int ac[PCS_NA] = { 0, 0, 0, 0, 0, 0 };
 #pragma unroll
     for (int k = 0; k < 4; k++)
-      ac[k] = (k == dom) ? (int) __popcll (deep_m) * (site_hap ? 1 : 2) : 0;
-    c_ac0 = pcs_pack_ac (ac, 0);
-    c_ac1 = pcs_pack_ac (ac, 1);
+      ac[k] = (k == dom) ? n_deep * (site_hap ? 1 : 2) : 0;
+#pragma unroll
+    for (int w = 0; w < AC::WORDS; w++)
+      c_ac[w] = AC::pack (ac, w);
   }
+  (void) c_prior;
   int n = 1;
   const double thres = 2.3;
   for (int t = 0; t < nu; t++)
     {
       if (n > 4)
         return false;
-      const int who = pcs_bcast (sord, n_set + t);
+      const int who = sample_at (n_set + t);
       // the sample's likelihoods, where every lane can index them
       pcs_sync ();
-      if (lane == who)
-        {
 #pragma unroll
-          for (int g = 0; g < PCS_NG; g++)
-            w_like[g] = lk[g];
-        }
+      for (int c = 0; c < NCH; c++)
+        if (64 * c + lane == who)
+          {
+#pragma unroll
+            for (int g = 0; g < PCS_NG; g++)
+              w_like[g] = lk[c][g];
+          }
       pcs_sync ();
-      const int r4 = pcs_bcast (r[4], who), r5 = pcs_bcast (r[5], who);
+      int r4v[NCH], r5v[NCH];
+#pragma unroll
+      for (int c = 0; c < NCH; c++)
+        {
+          r4v[c] = r[c][4];
+          r5v[c] = r[c][5];
+        }
+      const int r4 = pcs_bcast (pcs_chunk_of < NCH > (r4v, who), who & 63), r5 = pcs_bcast (pcs_chunk_of < NCH > (r5v, who), who & 63);
       double best_post = pcs_bcast (c_post, 0), best_like = pcs_bcast (c_like, 0);
       // ---- every candidate (configuration, genotype) priced by its own lane (pcs_expand; the sample's old genotype is `dom`)
       const int total = n * G;
@@ -1377,7 +1441,11 @@ __device__ bool pcs_mini_beam (const PcsParams & P, const double *tab_unused, co
       const int pos = in ? lane / G : 0, jj = in ? lane - pos * G : 0;
       const int j = pcs_order (dom, jj, P.haploid);
       const double s_like = __hiloint2double (__shfl (__double2hiint (c_like), pos), __shfl (__double2loint (c_like), pos));
-      const int s_ac0 = __shfl (c_ac0, pos), s_ac1 = __shfl (c_ac1, pos), s_misc = __shfl (c_misc, pos);
+      int s_ac[AC::WORDS];
+#pragma unroll
+      for (int w = 0; w < AC::WORDS; w++)
+        s_ac[w] = __shfl (c_ac[w], pos);
+      const int s_misc = __shfl (c_misc, pos);
       double base = s_like;
       base -= w_like[dom];
       double templ = base + w_like[j];
@@ -1396,7 +1464,7 @@ __device__ bool pcs_mini_beam (const PcsParams & P, const double *tab_unused, co
 #pragma unroll
       for (int k = 0; k < PCS_NA; k++)
         {
-          const int old = ((k < 3 ? s_ac0 : s_ac1) >> (8 * (k % 3))) & 0xFF;
+          const int old = AC::get (s_ac, k);
           ac[k] = old - (k == oa) - (k == ob) + (k == na) + (k == nb);
           nall += ac[k] > 0;
         }
@@ -1438,10 +1506,16 @@ __device__ bool pcs_mini_beam (const PcsParams & P, const double *tab_unused, co
         }
       const double post = prior + templ;
       const int misc_new = hets | (nall << 8) | (s_misc & ~0xFFF) | (j << (12 + 4 * t));
-      const int ac0_new = pcs_pack_ac (ac, 0), ac1_new = pcs_pack_ac (ac, 1);
+      int ac_new[AC::WORDS];
+#pragma unroll
+      for (int w = 0; w < AC::WORDS; w++)
+        ac_new[w] = AC::pack (ac, w);
       // ---- the acceptance rule in candidate order (pecaller.c:2628, 2738-2758); the kept ones become the new list, in that order
       double n_like = 0, n_prior = 0, n_post = 0;
-      int n_ac0 = 0, n_ac1 = 0, n_misc = 0, newcount = 0;
+      int n_ac[AC::WORDS], n_misc = 0, newcount = 0;
+#pragma unroll
+      for (int w = 0; w < AC::WORDS; w++)
+        n_ac[w] = 0;
       unsigned long long m = __ballot (in && ((templ + thres > best_post) || (templ + 0.01 > best_like)));
       while (m)
         {
@@ -1455,14 +1529,19 @@ __device__ bool pcs_mini_beam (const PcsParams & P, const double *tab_unused, co
           if (!(po + thres > best_post))
             continue;
           const double pr = pcs_bcast (prior, k);
-          const int a0 = pcs_bcast (ac0_new, k), a1 = pcs_bcast (ac1_new, k), mi = pcs_bcast (misc_new, k);
+          const int mi = pcs_bcast (misc_new, k);
+          int av[AC::WORDS];
+#pragma unroll
+          for (int w = 0; w < AC::WORDS; w++)
+            av[w] = pcs_bcast (ac_new[w], k);
           if (lane == newcount)
             {
               n_like = tt;
               n_prior = pr;
               n_post = po;
-              n_ac0 = a0;
-              n_ac1 = a1;
+#pragma unroll
+              for (int w = 0; w < AC::WORDS; w++)
+                n_ac[w] = av[w];
               n_misc = mi;
             }
           newcount++;
@@ -1479,8 +1558,9 @@ __device__ bool pcs_mini_beam (const PcsParams & P, const double *tab_unused, co
       c_like = __hiloint2double (PCS_PUSH (__double2hiint (n_like)), PCS_PUSH (__double2loint (n_like)));
       c_prior = __hiloint2double (PCS_PUSH (__double2hiint (n_prior)), PCS_PUSH (__double2loint (n_prior)));
       c_post = __hiloint2double (PCS_PUSH (__double2hiint (n_post)), PCS_PUSH (__double2loint (n_post)));
-      c_ac0 = PCS_PUSH (n_ac0);
-      c_ac1 = PCS_PUSH (n_ac1);
+#pragma unroll
+      for (int w = 0; w < AC::WORDS; w++)
+        c_ac[w] = PCS_PUSH (n_ac[w]);
       c_misc = PCS_PUSH (n_misc);
 #undef PCS_PUSH
       int mx = newcount;        // (at most 56: max_configs = 514 is out of reach)
@@ -1506,39 +1586,43 @@ __device__ bool pcs_mini_beam (const PcsParams & P, const double *tab_unused, co
     e /= tot_post;
   }
   // ---- marginal posteriors and calls (pecaller.c:1443-1468), lane = sample: a settled sample is `dom` in every configuration
-  int my_t = -1;
-  for (int t = 0; t < nu; t++)
-    my_t = (pcs_bcast (sord, n_set + t) == lane) ? t : my_t;
-  int besti = 0;
-  double bestp = 0;
-  for (int g = 0; g < G; g++)
-    {
-      double acc = 0;
-      for (int i = 0; i < n; i++)
-        {
-          const double pi = pcs_bcast (e, i);
-          const int gi = pcs_bcast (c_misc, i);
-          const int mine = my_t >= 0 ? ((gi >> (12 + 4 * my_t)) & 0xF) : dom;
-          if (mine == g)
-            acc += pi;
-        }
-      if (g == 0 || acc > bestp)
-        {
-          besti = g;
-          bestp = acc;
-        }
-    }
   bool changed = false;
-  if (deep)
+#pragma unroll
+  for (int c = 0; c < NCH; c++)
     {
-      final_p = bestp;
-      final_call = besti;
-      changed = final_call != best || final_p < P.threshold;
-    }
-  else
-    {
-      final_call = PCS_NG;
-      final_p = 1.0;
+      int my_t = -1;
+      for (int t = 0; t < nu; t++)
+        my_t = (sample_at (n_set + t) == 64 * c + lane) ? t : my_t;
+      int besti = 0;
+      double bestp = 0;
+      for (int g = 0; g < G; g++)
+        {
+          double acc = 0;
+          for (int i = 0; i < n; i++)
+            {
+              const double pi = pcs_bcast (e, i);
+              const int gi = pcs_bcast (c_misc, i);
+              const int mine = my_t >= 0 ? ((gi >> (12 + 4 * my_t)) & 0xF) : dom;
+              if (mine == g)
+                acc += pi;
+            }
+          if (g == 0 || acc > bestp)
+            {
+              besti = g;
+              bestp = acc;
+            }
+        }
+      if (deep[c])
+        {
+          final_p[c] = bestp;
+          final_call[c] = besti;
+          changed = changed || final_call[c] != best[c] || final_p[c] < P.threshold;
+        }
+      else
+        {
+          final_call[c] = PCS_NG;
+          final_p[c] = 1.0;
+        }
     }
   if (__any (changed) && N >= 4)
     return false;               // a second pass (pecaller.c:1454-1471): the whole machinery
@@ -1553,14 +1637,12 @@ __device__ bool pcs_mini_beam (const PcsParams & P, const double *tab_unused, co
 // by more than 2.31 nats.  Then the column's result is known -- every such sample is called the reference base with
 // posterior 1 after one pass, site type REF -- and is written here; so are the columns the site filters drop (every call N,
 // zero passes) and the ones whose reference base is not A/C/G/T.  Everything else goes to slow_list for pcs_call_kernel.
-#define PCS_FAST_WAVE_BYTES (64 + PCS_NG * 8 + 16)        // per wave: the samples' order, one sample's likelihoods (pcs_mini_beam)
 // The ln n! table in LDS comes in two sizes.  Pass 1 looks up n <= 600 + the sample's depth (ta <= 100 per allele): for a column with
 // no sample deeper than ~1,400 reads 2,048 entries serve, a workgroup is 4 waves with 30 KB and 12 waves per CU run (the registers'
 // limit) beside whatever else is resident; the form with the whole table (80 KB, workgroups of 8 waves, one per CU, as before round 3)
 // takes the columns the first form found too deep and listed, in a launch of its own when there are any.
 #define PCS_FAST_TAB 2048
 #define PCS_FAST_GRAB 8                // columns a wave of the shortcut kernel takes per fetch of the work counter
-#define PCS_FAST_WAVE_BYTES (64 + PCS_NG * 8 + 16)        // per wave: the samples' order, one sample's likelihoods (pcs_mini_beam)
 #define PCS_FAST_BLOCK_OF(TABN) ((TABN) == PCS_FAST_TAB ? 256 : 512)
 // pass 1's integer Dirichlet parameters ta = max (1, ceil (scale * mean[g][a])) (pecaller.c:2478) depend on the reference base, the
 // genotype, the allele and on scale = min (depth, 100) clamped to 10 .. 100 only: 4 x 91 x 14 x 6 bytes, built by the host with the
@@ -1568,7 +1650,8 @@ __device__ bool pcs_mini_beam (const PcsParams & P, const double *tab_unused, co
 #define PCS_TA_SCALES 91
 #define PCS_TA_ROWS (4 * PCS_TA_SCALES * PCS_NG)
 #define PCS_TA_BYTES (PCS_TA_ROWS * 4 + PCS_TA_ROWS * 2)        // a0..a3 packed in a word per row, a4 a5 in a half-word
-#define PCS_FAST_LDS_BYTES_OF(TABN) (((TABN) + 1) * 8 + PCS_TA_BYTES + (PCS_FAST_BLOCK_OF (TABN) / 64) * PCS_FAST_WAVE_BYTES)
+#define PCS_FAST_WAVE_BYTES_OF(NCH) (64 * (NCH) + PCS_NG * 8 + 16)        // per wave: the samples' order, one sample's likelihoods (pcs_mini_beam)
+#define PCS_FAST_LDS_BYTES_OF(TABN) (((TABN) + 1) * 8 + PCS_TA_BYTES + (PCS_FAST_BLOCK_OF (TABN) / 64) * PCS_FAST_WAVE_BYTES_OF (2))
 
 // the ta table as words: PCS_TA_ROWS words (alleles 0..3) followed by PCS_TA_ROWS half-words (alleles 4, 5); every ta is at most 100
 static void pcs_ta_table (uint32_t * out)
@@ -1604,7 +1687,9 @@ static void pcs_ta_table (uint32_t * out)
       }
 }
 
-template < int TABN > __global__ __launch_bounds__ (PCS_FAST_BLOCK_OF (TABN), TABN == PCS_FAST_TAB ? 3 : 2)
+// NCH chunks of 64 samples per lane (1: up to 64 samples, the form everything above describes; 2: up to 128 -- every per-sample value an
+// array of two, the wave-wide counts sums of two ballots, the small beam with 16-bit allele counts: round 4)
+template < int TABN, int NCH > __global__ __launch_bounds__ (PCS_FAST_BLOCK_OF (TABN), (TABN == PCS_FAST_TAB && NCH == 1) ? 3 : 2)
 void pcs_fast_kernel (PcsParams P, const uint16_t * reads, const uint8_t * dom_of, const uint8_t * chrom_of,
                       long n_sites, int8_t * call, double *post_out, int8_t * type_out,
                       int32_t * allele_count, int8_t * n_pass, int32_t * denovo_out,
@@ -1630,8 +1715,8 @@ void pcs_fast_kernel (PcsParams P, const uint16_t * reads, const uint8_t * dom_o
   const int N = P.indiv, G = P.max_gen, md = P.min_depth;
   __syncthreads ();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint8_t *w_sord = (uint8_t *) (ta_hi + PCS_TA_ROWS) + (size_t) wave * PCS_FAST_WAVE_BYTES;
-  double *w_like = (double *) (w_sord + 64);
+  uint8_t *w_sord = (uint8_t *) (ta_hi + PCS_TA_ROWS) + (size_t) wave * PCS_FAST_WAVE_BYTES_OF (NCH);
+  double *w_like = (double *) (w_sord + 64 * NCH);
   // Columns are handed out PCS_FAST_GRAB at a time through a counter (next_piece; the first grid-ful of pieces by wave index).
   // With a fixed stride the launch took as long as its unluckiest workgroup: beside the beam searches of earlier chunks, whose
   // waves hold 40 KB of LDS each for milliseconds, a CU now and then has room for two of these workgroups instead of three, the third
@@ -1654,55 +1739,67 @@ void pcs_fast_kernel (PcsParams P, const uint16_t * reads, const uint8_t * dom_o
       const int chrom = chrom_of[site] & 3;
       int decided = 1;          // 1: written here, 0: left to the beam
       int n_unset = 0;          // samples the shortcut could not settle (left to the beam: a measure of its work)
-      int my_call = PCS_NG, npass = 0, ac_dom = 0, type = 0;
+      int my_call[NCH], npass = 0, ac_dom = 0, type = 0;
+#pragma unroll
+      for (int c = 0; c < NCH; c++)
+        my_call[c] = PCS_NG;
       if (dom > 3)
         type = -1;              // the reference skips the column (pecaller.c:1208, 1718)
       else
         {
-          int r[PCS_NA], tot = 0;
+          int r[NCH][PCS_NA], tot[NCH];
+          bool too_deep = false;
+          int tsum = 0, sample_count = 0;
 #pragma unroll
-          for (int a = 0; a < PCS_NA; a++)
-            r[a] = lane < N ? (int) reads[(site * N + lane) * PCS_NA + a] : 0;
-          tot = r[0] + r[1] + r[2] + r[3] + r[4];
-          if (!LISTED && __any (tot + r[5] + 6 * 100 + 1 >= TABN))
+          for (int c = 0; c < NCH; c++)
+            {
+              const bool have = 64 * c + lane < N;
+#pragma unroll
+              for (int a = 0; a < PCS_NA; a++)
+                r[c][a] = have ? (int) reads[(site * N + 64 * c + lane) * PCS_NA + a] : 0;
+              tot[c] = r[c][0] + r[c][1] + r[c][2] + r[c][3] + r[c][4];
+              too_deep = too_deep || (tot[c] + r[c][5] + 6 * 100 + 1 >= TABN);
+              tsum += tot[c];
+              sample_count += (int) __popcll (__ballot (have && tot[c] >= 8));
+            }
+          if (!LISTED && __any (too_deep))
             {
               // (a sample too deep for the table's head: the column waits for the form with the whole table; its posteriors read 1
               // until then, so that pcs_sparse_kernel does not take what an earlier call left there)
               if (lane == 0)
                 deep_list[atomicAdd (n_deep, 1u)] = (unsigned) site;
-              if (lane < N)
-                post_out[site * N + lane] = 1.0;
+#pragma unroll
+              for (int c = 0; c < NCH; c++)
+                if (64 * c + lane < N)
+                  post_out[site * N + 64 * c + lane] = 1.0;
               continue;
             }
-          int tsum = tot;
           for (int o = 32; o; o >>= 1)
             tsum += __shfl_xor (tsum, o);
           const double average_depth = (double) tsum / (double) N;
           bool bad_base = average_depth < 8;
-          const int sample_count = __popcll (__ballot (lane < N && tot >= 8));
           if (sample_count < (double) 0.5 * N && chrom != 2)
             bad_base = true;
           if (!bad_base)
             {
-              const bool deep = lane < N && tot > md;
-              bool ok = true;
-              double lk[PCS_NG], margin = 0.0;
-              int best = PCS_NG;
-              auto likelihoods = [&] (const double *tb)
+              bool deep[NCH], ok[NCH];
+              double lk[NCH][PCS_NG], margin[NCH];
+              int best[NCH];
+              auto likelihoods = [&] (const double *tb, const int (&rr)[PCS_NA], const int tt, double (&lkc)[PCS_NG], int &bestc, double &marginc)
               {
-                double coef = pc_factln (tb, tot);
+                double coef = pc_factln (tb, tt);
 #pragma unroll
                 for (int a = 0; a < PCS_NA; a++)
-                  coef -= pc_factln (tb, r[a]);
+                  coef -= pc_factln (tb, rr[a]);
                 // scale = min (depth, 100) * norm (1 in pass 1), at least 10: an integer 10 .. 100, the row of the ta table
-                const int sci = (tot < 10 ? 10 : (tot > 100 ? 100 : tot)) - 10;
+                const int sci = (tt < 10 ? 10 : (tt > 100 ? 100 : tt)) - 10;
                 const uint32_t *tl = ta_lo + (dom * PCS_TA_SCALES + sci) * PCS_NG;
                 const uint16_t *th = ta_hi + (dom * PCS_TA_SCALES + sci) * PCS_NG;
                 double mx = -1e100;
 #pragma unroll
                 for (int g = 0; g < PCS_NG; g++)
                   {
-                    lk[g] = 0.0;
+                    lkc[g] = 0.0;
                     if (g < G)
                       {
                         const uint32_t w4 = tl[g], w2 = th[g];
@@ -1713,68 +1810,93 @@ void pcs_fast_kernel (PcsParams P, const uint16_t * reads, const uint8_t * dom_o
                           {
                             const int ta = (int) ((a < 4 ? (w4 >> (8 * a)) : (w2 >> (8 * (a - 4)))) & 0xFFu);
                             tot_a += ta;
-                            tot_tot += ta + r[a];
+                            tot_tot += ta + rr[a];
                             cf -= pc_factln (tb, ta - 1);
-                            l += pc_factln (tb, ta + r[a] - 1);
+                            l += pc_factln (tb, ta + rr[a] - 1);
                           }
                         cf += pc_factln (tb, tot_a - 1);
                         l += cf;
                         l -= pc_factln (tb, tot_tot - 1);
-                        lk[g] = l;
+                        lkc[g] = l;
                         if (l > mx)
                           {
-                            best = g;
+                            bestc = g;
                             mx = l;
                           }
                       }
                   }
                 // initial_p: the margin of the best genotype over every other one (pecaller.c:2494-2504)
-                margin = 1e100;
+                marginc = 1e100;
 #pragma unroll
                 for (int g = 0; g < PCS_NG; g++)
-                  if (g < G && g != best)
+                  if (g < G && g != bestc)
                     {
-                      const double dlt = mx - lk[g];
-                      margin = (dlt < margin) ? dlt : margin;
+                      const double dlt = mx - lkc[g];
+                      marginc = (dlt < marginc) ? dlt : marginc;
                     }
               };
-              if (deep)
+              bool all_ok = true;
+              int n_deep_s = 0;
+#pragma unroll
+              for (int c = 0; c < NCH; c++)
                 {
-                  likelihoods (tab);
-                  // best genotype the reference homozygote, and its margin above 2.31
-                  ok = best == dom && margin > 2.31;
-                  my_call = dom;
+                  deep[c] = 64 * c + lane < N && tot[c] > md;
+                  ok[c] = true;
+                  margin[c] = 0.0;
+                  best[c] = PCS_NG;
+#pragma unroll
+                  for (int g = 0; g < PCS_NG; g++)
+                    lk[c][g] = 0.0;
+                  if (deep[c])
+                    {
+                      likelihoods (tab, r[c], tot[c], lk[c], best[c], margin[c]);
+                      // best genotype the reference homozygote, and its margin above 2.31
+                      ok[c] = best[c] == dom && margin[c] > 2.31;
+                      my_call[c] = dom;
+                    }
+                  all_ok = all_ok && __all (ok[c]);
+                  n_deep_s += (int) __popcll (__ballot (deep[c]));
                 }
-              if (__all (ok))
+              if (all_ok)
                 {
                   npass = 1;
                   // Allele_Counts of the row (pecaller.c:1575-1597): every confident call adds its alleles; the posterior is 1
                   if (1.0 >= P.threshold)
-                    ac_dom = (int) __popcll (__ballot (deep)) * (P.haploid ? 1 : 2);
+                    ac_dom = n_deep_s * (P.haploid ? 1 : 2);
                 }
               else
                 {
                   // a few unsettled samples: the small beam, here and now (pcs_mini_beam); anything else is listed for pcs_call_kernel
-                  int fc = PCS_NG;
-                  double fp = 1.0;
-                  const int site_hap = P.haploid | ((chrom_of[site] >> 4) & 1);
-                  if (pcs_mini_beam (P, tab, lk, r, deep, ok, best, margin, dom, site_hap, w_sord, w_like, lane, fc, fp))
+                  int fc[NCH];
+                  double fp[NCH];
+#pragma unroll
+                  for (int c = 0; c < NCH; c++)
                     {
-                      pcs_write_site (P, site, lane, dom, chrom, r, tot, average_depth, fc, fp, 1, call, post_out, type_out, allele_count, n_pass, denovo_out);
+                      fc[c] = PCS_NG;
+                      fp[c] = 1.0;
+                    }
+                  const int site_hap = P.haploid | ((chrom_of[site] >> 4) & 1);
+                  if (pcs_mini_beam < NCH > (P, lk, r, deep, ok, best, margin, dom, site_hap, w_sord, w_like, lane, fc, fp))
+                    {
+                      pcs_write_site < NCH > (P, site, lane, dom, chrom, r, tot, average_depth, fc, fp, 1, call, post_out, type_out, allele_count, n_pass, denovo_out);
                       continue;
                     }
                   decided = 0;
-                  n_unset = (int) __popcll (__ballot (!ok));
+#pragma unroll
+                  for (int c = 0; c < NCH; c++)
+                    n_unset += (int) __popcll (__ballot (!ok[c]));
                 }
             }
         }
       if (decided)
         {
-          if (lane < N)
-            {
-              call[site * N + lane] = (int8_t) my_call;
-              post_out[site * N + lane] = 1.0;
-            }
+#pragma unroll
+          for (int c = 0; c < NCH; c++)
+            if (64 * c + lane < N)
+              {
+                call[site * N + 64 * c + lane] = (int8_t) my_call[c];
+                post_out[site * N + 64 * c + lane] = 1.0;
+              }
           if (lane < PCS_NA)
             allele_count[site * PCS_NA + lane] = (type == 0 && lane == dom) ? ac_dom : 0;
           if (lane == 0)
@@ -1804,7 +1926,7 @@ void pcs_fast_kernel (PcsParams P, const uint16_t * reads, const uint8_t * dom_o
 // more reads that are not the reference base's -- and at least an eighth of their depth -- and lists the columns with `thr` or more of
 // them by that count (the list's PCS_BUCKETS parts, as the shortcut kernel files its own); flag[site] = 1 tells the shortcut kernel to
 // leave the column alone.  pcs_call_kernel is the whole caller and takes any column, so the choice only moves work: the listed columns'
-// beam searches start at once, beside the shortcut kernels of all chunks.  Up to 64 samples (the shortcut's range).
+// beam searches start at once, beside the shortcut kernels of all chunks.  Up to 128 samples (the shortcut's range).
 __global__ __launch_bounds__ (256) void pcs_heavy_kernel (const uint16_t * reads, const uint8_t * dom_of, long n_sites, int N, int thr, unsigned *list,
                                                           unsigned *n_list, uint8_t * flag)
 {
@@ -1815,21 +1937,25 @@ __global__ __launch_bounds__ (256) void pcs_heavy_kernel (const uint16_t * reads
       const int dom = dom_of[site];
       if (dom > 3)
         continue;
-      int alt = 0, tot = 0;
-      if (lane < N)
+      int c = 0;
+      for (int s0 = 0; s0 < N; s0 += 64)         // (a lane per sample, 64 at a time)
         {
-          const uint16_t *r = reads + (site * N + lane) * PCS_NA;
-          int ref = 0;
-#pragma unroll
-          for (int a = 0; a < PCS_NA; a++)
+          int alt = 0, tot = 0;
+          if (s0 + lane < N)
             {
-              const int v = (int) r[a];
-              tot += v;
-              ref = a == dom ? v : ref;
+              const uint16_t *r = reads + (site * N + s0 + lane) * PCS_NA;
+              int ref = 0;
+#pragma unroll
+              for (int a = 0; a < PCS_NA; a++)
+                {
+                  const int v = (int) r[a];
+                  tot += v;
+                  ref = a == dom ? v : ref;
+                }
+              alt = tot - ref;
             }
-          alt = tot - ref;
+          c += (int) __popcll (__ballot (alt >= 3 && 8 * alt >= tot));
         }
-      const int c = (int) __popcll (__ballot (alt >= 3 && 8 * alt >= tot));
       if (c < thr)
         continue;
       if (lane == 0)
