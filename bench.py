@@ -780,6 +780,7 @@ def pecaller_leg(a):
             "config": {"workload": "%d pileup columns x %d samples, 30x Poisson depth, 0.4%% error, 1 variant/kb under HWE, seed 777, "
                                    "prob_to_call 0.95, theta 0.001, diploid, no pedigree" % (n, S), "generated_in_s": round(t_gen, 1)},
             "variant_rows": int((typ > 0).sum()), "passes_histogram": np.bincount(npass).tolist(), "samples_128": wide,
+            "kernel_ms_runs": [round(x, 2) for x in kms],
             "roofline": {"bound": sq["bound"] if sq else "hbm", "kernel": "pcs_fast_kernel+pcs_call_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc, "avg_launch_ms": round(kernel_ms, 3),
                          # what the kernels are bound by is not HBM (their traffic is a fifth of the algorithmic figure: the likelihood table

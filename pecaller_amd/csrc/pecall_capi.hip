@@ -627,9 +627,19 @@ static int pcs_ensure_chunks (pecall_dev * d, long n_sites)
       for (int i = 0; i < PCS_CALL_STREAMS; i++)
         // (a stream priority for the beam searches was tried: 64 -> 60 M columns/s, the shortcut kernels wait for them then)
         PCCHK (d, hipStreamCreateWithFlags (&d->stream_call[i], hipStreamNonBlocking));
-      PCCHK (d, hipStreamCreateWithFlags (&d->stream_h2d, hipStreamNonBlocking));
-      PCCHK (d, hipStreamCreateWithFlags (&d->stream_d2h, hipStreamNonBlocking));
-      PCCHK (d, hipStreamCreateWithFlags (&d->stream_heavy, hipStreamNonBlocking));
+      // Which streams share one of the runtime's 4 hardware queues (per priority level) is settled when they are made and depends on every
+      // stream the process made before: with the early beam search's stream on the queue of the shortcut kernels' stream a resident run of
+      // 2 M columns took 23.4 ms instead of 19.2, with a copy stream on a beam-search stream's queue the seam did 25 M columns/s instead
+      // of 43 -- the FIRST object of a process had the one, every later object the other (profiles/r04_ab_sweeps.txt; the order the
+      // streams are first used in changes nothing).  Streams of another priority take queues of their own: the copies' streams high,
+      // the early beam search's low, the shortcut kernels' and the chunks' beam searches' streams at the default.
+      int prio_low = 0, prio_high = 0;
+      PCCHK (d, hipDeviceGetStreamPriorityRange (&prio_low, &prio_high));
+      if (getenv ("PECALL_FLAT_PRIORITIES"))    // (diagnostic: every stream at the default priority, as before round 4)
+        prio_low = prio_high = 0;
+      PCCHK (d, hipStreamCreateWithPriority (&d->stream_h2d, hipStreamNonBlocking, prio_high));
+      PCCHK (d, hipStreamCreateWithPriority (&d->stream_d2h, hipStreamNonBlocking, prio_high));
+      PCCHK (d, hipStreamCreateWithPriority (&d->stream_heavy, hipStreamNonBlocking, prio_low));
       PCCHK (d, hipEventCreateWithFlags (&d->ev_heavy[0], hipEventDisableTiming));
       PCCHK (d, hipEventCreateWithFlags (&d->ev_heavy[1], hipEventDisableTiming));
       {
@@ -699,7 +709,8 @@ static int pcs_chunk_reset (pecall_dev * d, const PcsParams & P, int k, long off
   return 0;
 }
 
-static int pcs_heavy_start (pecall_dev * d, const PcsParams & P, long off, long m, int slot, hipEvent_t done);
+static int pcs_heavy_start (pecall_dev * d, const PcsParams & P, long off, long m, int slot, hipEvent_t done, hipStream_t on = nullptr, char *scratch_at = nullptr,
+                            long waves = 0);
 // heavy: 0 no early beam search; 1 the run made its list already (pcs_heavy_start over all columns): the shortcut kernel passes the flagged
 // columns over; 2 the chunk makes its own list here (the seam: columns arrive chunk by chunk) and its results wait for that beam search too
 static int pcs_chunk_kernels (pecall_dev * d, const PcsParams & P, int k, long off, long m, bool whole_table, bool sparse = false, int heavy = 0)
@@ -722,7 +733,12 @@ static int pcs_chunk_kernels (pecall_dev * d, const PcsParams & P, int k, long o
     heavy = 0;
   if (heavy == 2 && !whole_table)
     {
-      const int rc = pcs_heavy_start (d, P, off, m, 1 + k, d->ev_heavy_k[k]);
+      // (on the chunk's own beam-search stream, in front of the search of what the shortcut kernel lists: the chunks' early searches
+      // then alternate on PCS_CALL_STREAMS streams like the others -- on the one stream of the resident form they ran one behind the
+      // other, 8 x 5 ms, and every chunk's results waited for its own)
+      const int rc = pcs_heavy_start (d, P, off, m, 1 + k, d->ev_heavy_k[k], d->stream_call[k % PCS_CALL_STREAMS],
+                                      d->d_scratch + (size_t) (k % PCS_CALL_STREAMS) * (size_t) (d->site_grid / PCS_CALL_STREAMS) * (2 * PCS_BIG_BYTES_OF (64 * nch) + PCS_BIGCAP),
+                                      d->site_grid / PCS_CALL_STREAMS);
       if (rc)
         return rc;
     }
@@ -801,8 +817,9 @@ static int pcs_chunk_kernels (pecall_dev * d, const PcsParams & P, int k, long o
 
 // pcs_heavy_kernel over the columns [off, off + m) on the object's stream, then -- on a stream of its own, with scratch of its own --
 // the beam search of what it listed, heaviest part first; `done` closes it.  slot: the list's counters (0: a whole run, 1 + k: chunk k).
-static int pcs_heavy_start (pecall_dev * d, const PcsParams & P, long off, long m, int slot, hipEvent_t done)
+static int pcs_heavy_start (pecall_dev * d, const PcsParams & P, long off, long m, int slot, hipEvent_t done, hipStream_t on, char *scratch_at, long waves)
 {
+  hipStream_t hs = on ? on : d->stream_heavy;
   const int N = P.indiv;
   unsigned long long *ctr = d->d_heavy_ctr + (size_t) slot * PCS_CTRS;
   unsigned *n_list = (unsigned *) (ctr + 1);
@@ -815,11 +832,12 @@ static int pcs_heavy_start (pecall_dev * d, const PcsParams & P, long off, long 
   hipLaunchKernelGGL (pcs_heavy_kernel, dim3 ((unsigned) hgrid), dim3 (256), 0, d->stream, d->d_sreads + off * N * PCS_NA, d->d_dom + off, m, N, d->heavy_min, list,
                       n_list, d->d_heavy_flag + off);
   PCCHK (d, hipEventRecord (d->ev_heavy[0], d->stream));
-  PCCHK (d, hipStreamWaitEvent (d->stream_heavy, d->ev_heavy[0], 0));
+  PCCHK (d, hipStreamWaitEvent (hs, d->ev_heavy[0], 0));
   const int row = N <= 64 ? 64 : 128;
-  char *scratch = d->d_scratch + (size_t) d->site_grid * (2 * PCS_BIG_BYTES_OF (row) + PCS_BIGCAP);
-  const long grid = m < (long) d->heavy_grid ? m : (long) d->heavy_grid;
-#define PCS_HEAVY(NCH_) hipLaunchKernelGGL (HIP_KERNEL_NAME (pcs_call_kernel < NCH_ >), dim3 ((unsigned) grid), dim3 (64), sizeof (PcsShared < NCH_ >), d->stream_heavy, P, \
+  char *scratch = scratch_at ? scratch_at : d->d_scratch + (size_t) d->site_grid * (2 * PCS_BIG_BYTES_OF (row) + PCS_BIGCAP);
+  const long hw = waves > 0 ? waves : (long) d->heavy_grid;
+  const long grid = m < hw ? m : hw;
+#define PCS_HEAVY(NCH_) hipLaunchKernelGGL (HIP_KERNEL_NAME (pcs_call_kernel < NCH_ >), dim3 ((unsigned) grid), dim3 (64), sizeof (PcsShared < NCH_ >), hs, P, \
                       d->d_sreads + off * N * PCS_NA, d->d_dom + off, d->d_chromy + off, m, d->d_call + off * N, d->d_post + off * N, d->d_type + off, \
                       d->d_ac + off * PCS_NA, d->d_npass + off, d->d_den + off, scratch, ctr, (const unsigned *) list, (const unsigned *) n_list)
   if (N <= 64)
@@ -828,7 +846,7 @@ static int pcs_heavy_start (pecall_dev * d, const PcsParams & P, long off, long 
     PCS_HEAVY (2);
 #undef PCS_HEAVY
   PCCHK (d, hipGetLastError ());
-  PCCHK (d, hipEventRecord (done, d->stream_heavy));
+  PCCHK (d, hipEventRecord (done, hs));
   return 0;
 }
 

@@ -97,7 +97,7 @@ def test_caller_argument_errors():
     with pytest.raises(PemapError):
         dev.call_sites(np.zeros((0, 8, 6), np.uint16), np.zeros(0, np.uint8))
     with pytest.raises(PemapError):
-        dev.call_sites(np.zeros((4, 257, 6), np.uint16), np.zeros(4, np.uint8))       # more than 256 samples
+        dev.call_sites(np.zeros((4, 513, 6), np.uint16), np.zeros(4, np.uint8))       # more than 512 samples
     with pytest.raises(PemapError):
         dev.call_sites(np.zeros((4, 8, 6), np.uint16), np.zeros(4, np.uint8), theta=0.9)   # pecaller.c:305-309
     dev.close()
