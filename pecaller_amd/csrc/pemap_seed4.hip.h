@@ -37,6 +37,12 @@
 #ifndef PM_S4_KCAP
 #define PM_S4_KCAP 1536         // positions of BOTH strands the list holds (reads of up to 160 bases, first tier)
 #endif
+#ifndef PM_S4_KCAP_LONG
+#define PM_S4_KCAP_LONG 2048    // ... for reads of more than 160 bases (3,072: 28 KB of LDS and 5 waves per CU at 16 segments; 2,048: 22.9 KB and 7 -- 2 x 245 bases 44.4 -> 41.3 ms per step, a quarter more ends for the second tier)
+#endif
+#ifndef PM_S4_NH_LOG2_LONG
+#define PM_S4_NH_LOG2_LONG 12   // log2 of the bins of the vote's table for those (11 for reads of up to 160 bases)
+#endif
 #ifndef PM_S4_WAVES_PER_EU
 #define PM_S4_WAVES_PER_EU 4
 #endif
@@ -52,9 +58,9 @@ template < int SMAX, int TIER > struct __align__ (16) PmSeed4Shared
 {
   static constexpr int NSEG = 2 * SMAX;
   // the list: positions of both strands.  Second tier (the first tier's big-end list): twice / four times that
-  static constexpr int KCAP = (SMAX <= 10 ? PM_S4_KCAP : 3072) * (TIER ? (SMAX <= 10 ? 4 : 2) : 1);
+  static constexpr int KCAP = TIER ? (SMAX <= 10 ? 4 * PM_S4_KCAP : 6144) : (SMAX <= 10 ? PM_S4_KCAP : PM_S4_KCAP_LONG);
   static constexpr bool CELL16 = SMAX <= 16;                                    // a bin's segment set: 16 bits while the segments fit
-  static constexpr int NH_LOG2 = (SMAX <= 10 ? 11 : 12) + ((TIER && CELL16) ? 1 : 0);
+  static constexpr int NH_LOG2 = TIER ? (SMAX <= 10 ? 12 : CELL16 ? 13 : 12) : (SMAX <= 10 ? 11 : PM_S4_NH_LOG2_LONG);
   static constexpr int NH = 1 << NH_LOG2;
   static constexpr int RCAP = (SMAX <= 10 ? 160 : 256) * (TIER ? 2 : 1);
   static constexpr int CELL_WORDS = ((CELL16 ? NH / 2 : NH) + 2 + 3) & ~3;       // cell c is stored at index c + 1: a pad cell either side
