@@ -433,6 +433,49 @@ __device__ __forceinline__ double pm_add_ones (double y, int n)
 // 150-base reads have at most two.  One half-wave per problem, lane = diagonal; wrong diagonals drop out after a few
 // bases.
 // ============================================================================================================
+// ---- eight bases at a time (the gapless rule's comparisons were one byte per trip round a loop: half of the kernel's instructions)
+// bit k = byte k of x is not zero (k = 0 the lowest byte).  Per 32-bit word the usual carry trick leaves a byte's top bit set where
+// the byte is non-zero; the two words' marks are packed into nibbles and gathered by ONE multiplication: source bits 0, 4, 8 ... 28
+// times 2^21 + 2^14 + 2^7 + 1 land on 32 distinct positions (no carries), those wanted on bits 21..28.
+__device__ __forceinline__ unsigned pm_nonzero_bytes (uint64_t x)
+{
+  const uint32_t lo = (uint32_t) x, hi = (uint32_t) (x >> 32);
+  const uint32_t a = ((lo & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | lo, b = ((hi & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | hi;
+  const uint32_t w = ((a >> 7) & 0x01010101u) | ((b >> 3) & 0x10101010u);
+  return ((w * 0x00204081u) >> 21) & 0xFFu;
+}
+
+// does a word hold an 'N' or an 'n'?  (non-zero = yes; the bytes above a true hit may be marked as well, which an "is there one" test does not mind)
+__device__ __forceinline__ uint32_t pm_has_n (uint32_t v)
+{
+  const uint32_t y = (v | 0x20202020u) ^ 0x6E6E6E6Eu;
+  return (y - 0x01010101u) & ~y & 0x80808080u;
+}
+
+// complements of four bases at once: bits 1..2 of 'A' 'C' 'T' 'G' are 0 1 2 3, and v_perm_b32 looks the four complements up in a
+// four-byte table.  Any other byte comes out as SOME base, so complementing twice gives the word back iff all four bytes are plain
+// upper-case bases: the test that guards the fast path (pm_rc_flat's 'N' for the rest is the slow one's business).
+__device__ __forceinline__ uint32_t pm_comp4 (uint32_t v)
+{
+  return __builtin_amdgcn_perm (0u, 0x43414754u, (v >> 1) & 0x03030303u);     // table bytes 0..3 = 'T' 'G' 'A' 'C'
+}
+
+// reverse_transcribe (pemapper.c:2303-2337) of eight read bytes: byte k of the result = complement of byte 7 - k
+__device__ __forceinline__ uint64_t pm_rc8 (uint64_t v, int vacated_bits)
+{
+  // (bytes vacated by the caller's shift hold zeros and are masked out of the result by the caller: as 'A's they pass the fast path's test)
+  const uint64_t vv = v | (0x4141414141414141ull & ~(~0ull << vacated_bits));
+  const uint32_t lo = (uint32_t) vv, hi = (uint32_t) (vv >> 32);
+  const uint32_t clo = pm_comp4 (lo), chi = pm_comp4 (hi);
+  if (pm_comp4 (clo) == lo && pm_comp4 (chi) == hi)
+    return ((uint64_t) __builtin_amdgcn_perm (0u, clo, 0x00010203u) << 32) | (uint64_t) __builtin_amdgcn_perm (0u, chi, 0x00010203u);
+  uint64_t w = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++)
+    w |= (uint64_t) pm_rc_flat ((uint8_t) (v >> (8 * (7 - k)))) << (8 * k);
+  return w;
+}
+
 #define PM_GAPLESS 4            // flag in PmHits::stk beside the plane number
 #define PM_GL_QUEUE 32           // problems a wave of pm_gapless_kernel collects before it fetches a list's counter
 
@@ -554,11 +597,7 @@ __global__ __launch_bounds__ (PM_GL_BLOCK, 6) void pm_gapless_kernel (PmIndex ix
                 if (orient)
                   {
                     v <<= sh_up[u];
-                    uint64_t w = 0;
-#pragma unroll
-                    for (int k = 0; k < 8; k++)
-                      w |= (uint64_t) pm_rc_flat ((uint8_t) (v >> (8 * (7 - k)))) << (8 * k);
-                    v = w;
+                    v = pm_rc8 (v, sh_up[u]);
                   }
                 if (nb < 8)
                   v &= (1ull << (8 * nb)) - 1ull;
@@ -587,11 +626,17 @@ __global__ __launch_bounds__ (PM_GL_BLOCK, 6) void pm_gapless_kernel (PmIndex ix
         uint64_t x = q ^ r;
         if (nb < 8)
           x &= (1ull << (8 * nb)) - 1ull;
-        unsigned m = 0u;
-        if (x != 0ull)
-          for (int k = 0; k < nb; k++)
-            if (((x >> (8 * k)) & 0xFFull) && !pm_match ((uint8_t) (r >> (8 * k)), (uint8_t) (q >> (8 * k)), bis))
-              m |= 1u << k;
+        if (x == 0ull)
+          return 0u;
+        // bytes that differ mismatch unless pm_match's exceptions apply: an 'N' or 'n' on either side, or bisulfite
+        unsigned m = pm_nonzero_bytes (x);
+        if (bis | (int) (pm_has_n ((uint32_t) q) | pm_has_n ((uint32_t) (q >> 32)) | pm_has_n ((uint32_t) r) | pm_has_n ((uint32_t) (r >> 32))))
+          {
+            m = 0u;
+            for (int k = 0; k < nb; k++)
+              if (((x >> (8 * k)) & 0xFFull) && !pm_match ((uint8_t) (r >> (8 * k)), (uint8_t) (q >> (8 * k)), bis))
+                m |= 1u << k;
+          }
         return m;
       };
       // Forward: the mismatches of every diagonal, exactly up to PM_BAND_MAXX_ (three decide the rule, PM_BAND_MAXX_ the banded DP),
