@@ -68,7 +68,7 @@ struct pecall_dev
   unsigned long long *d_heavy_ctr;      // [1 + cap_chunks][PCS_CTRS]: slot 0 for a whole run's list (resident columns), slot 1 + k for chunk k's (the seam)
   hipStream_t stream_heavy;
   hipEvent_t ev_heavy[2], *ev_heavy_k;  // list made / its beam search done; per chunk: done
-  int heavy_min, heavy_grid;
+  int heavy_min, heavy_min_wide, heavy_grid;
   unsigned *d_deep;             // columns too deep for the head of the ln n! table (per chunk, at the chunk's offset)
   // pecall_dev_call_sites_sparse: the columns with a posterior that is not 1 (pcs_sparse_kernel)
   unsigned *d_sp_cols;
@@ -646,6 +646,10 @@ static int pcs_ensure_chunks (pecall_dev * d, long n_sites)
         // PECALL_HEAVY_MIN: samples with variant reads from which a column's beam search is started ahead of the shortcut kernels; 0 = never
         const char *e = getenv ("PECALL_HEAVY_MIN");
         d->heavy_min = (e && *e) ? atoi (e) : 1;
+        // ... beyond 128 samples (PECALL_HEAVY_MIN_WIDE): a column's beam search costs tens of milliseconds there and the small beam settles
+        // most columns whose only variant reads are errors, so the early start takes the columns with several such samples only
+        e = getenv ("PECALL_HEAVY_MIN_WIDE");
+        d->heavy_min_wide = (e && *e) ? atoi (e) : 3;
       }
       PCCHK (d, hipFuncSetAttribute ((const void *) pcs_fast_kernel < PC_TABLE, 1 >, hipFuncAttributeMaxDynamicSharedMemorySize, PCS_FAST_LDS_BYTES_OF (PC_TABLE)));
       PCCHK (d, hipFuncSetAttribute ((const void *) pcs_fast_kernel < PC_TABLE, 2 >, hipFuncAttributeMaxDynamicSharedMemorySize, PCS_FAST_LDS_BYTES_OF (PC_TABLE)));
@@ -729,8 +733,6 @@ static int pcs_chunk_kernels (pecall_dev * d, const PcsParams & P, int k, long o
       PCCHK (d, hipMemsetAsync (ctr, 0, 3 * sizeof (unsigned long long), d->stream));
       PCCHK (d, hipMemsetAsync (ctr + 4, 0, sizeof (unsigned long long), d->stream));
     }
-  if (nch > 2)
-    heavy = 0;
   if (heavy == 2 && !whole_table)
     {
       // (on the chunk's own beam-search stream, in front of the search of what the shortcut kernel lists: the chunks' early searches
@@ -742,11 +744,12 @@ static int pcs_chunk_kernels (pecall_dev * d, const PcsParams & P, int k, long o
       if (rc)
         return rc;
     }
-  if (nch <= 2)
+  if (nch <= 2 || !whole_table)
     {
-      // the shortcut kernel: a lane per sample up to 64 samples, two samples per lane up to 128 (round 4)
+      // the shortcut kernel: a lane per sample up to 64 samples, two samples per lane up to 128 (round 4); beyond that its test alone,
+      // a chunk of 64 samples at a time: what it cannot write goes to the beam search's list (no second pass: too deep = listed)
 #define PCS_FAST(TAB_, NCH_, GRID_) hipLaunchKernelGGL (HIP_KERNEL_NAME (pcs_fast_kernel < TAB_, NCH_ >), dim3 ((unsigned) (GRID_)), dim3 (PCS_FAST_BLOCK_OF (TAB_)), \
-    PCS_FAST_LDS_BYTES_OF (TAB_), d->stream, P, d->d_sreads + off * N * PCS_NA, d->d_dom + off, d->d_chromy + off, m, d->d_call + off * N, d->d_post + off * N, \
+    PCS_FAST_LDS_BYTES_OF2 (TAB_, NCH_), d->stream, P, d->d_sreads + off * N * PCS_NA, d->d_dom + off, d->d_chromy + off, m, d->d_call + off * N, d->d_post + off * N, \
     d->d_type + off, d->d_ac + off * PCS_NA, d->d_npass + off, d->d_den + off, slow, n_slow, deep_list, n_deep, next_piece, d->d_ta, \
     heavy ? (const uint8_t *) d->d_heavy_flag + off : (const uint8_t *) nullptr)
       if (!whole_table)
@@ -759,8 +762,12 @@ static int pcs_chunk_kernels (pecall_dev * d, const PcsParams & P, int k, long o
             fgrid = cap;
           if (nch == 1)
             PCS_FAST (PCS_FAST_TAB, 1, fgrid);
-          else
+          else if (nch == 2)
             PCS_FAST (PCS_FAST_TAB, 2, fgrid);
+          else if (nch == 4)
+            PCS_FAST (PCS_FAST_TAB, 4, fgrid);
+          else
+            PCS_FAST (PCS_FAST_TAB, 8, fgrid);
         }
       else
         {
@@ -777,8 +784,7 @@ static int pcs_chunk_kernels (pecall_dev * d, const PcsParams & P, int k, long o
     }
   else if (whole_table)
     return 0;                   // (more than 128 samples: one form only)
-  // (more than 128 samples: no shortcut kernel; the beam search's kernel takes every column of the chunk, a lane standing for a
-  // sample of each chunk of 64)
+  // (the beam search's kernel takes the columns the shortcut kernel listed, a lane standing for a sample of each chunk of 64)
   PCCHK (d, hipEventRecord (d->ev_fast[k], d->stream));
   // (a chunk lists a few hundred columns for the beam search, a handful of them heavy -- milliseconds on one wave: behind each other
   // on one stream the chunks' searches were the caller's time, 8 x 5.5 ms.  They alternate on PCS_CALL_STREAMS streams.)
@@ -796,9 +802,9 @@ static int pcs_chunk_kernels (pecall_dev * d, const PcsParams & P, int k, long o
   else if (nch == 2)
     PCS_CALL (2, slow, n_slow);
   else if (nch == 4)
-    PCS_CALL (4, (const unsigned *) nullptr, (const unsigned *) nullptr);
+    PCS_CALL (4, slow, n_slow);
   else
-    PCS_CALL (8, (const unsigned *) nullptr, (const unsigned *) nullptr);       // (257 .. 512 samples: 124 KB of LDS, one wave per CU at a time)
+    PCS_CALL (8, slow, n_slow); // (257 .. 512 samples: 124 KB of LDS, one wave per CU at a time)
 #undef PCS_CALL
   if (heavy == 2)
     PCCHK (d, hipStreamWaitEvent (sc, d->ev_heavy_k[k], 0));    // (the chunk's results are whole when its early beam search is through too)
@@ -829,11 +835,11 @@ static int pcs_heavy_start (pecall_dev * d, const PcsParams & P, long off, long 
   long hgrid = (m + 3) / 4;
   if (hgrid > (long) d->grid * 4)
     hgrid = (long) d->grid * 4;
-  hipLaunchKernelGGL (pcs_heavy_kernel, dim3 ((unsigned) hgrid), dim3 (256), 0, d->stream, d->d_sreads + off * N * PCS_NA, d->d_dom + off, m, N, d->heavy_min, list,
+  hipLaunchKernelGGL (pcs_heavy_kernel, dim3 ((unsigned) hgrid), dim3 (256), 0, d->stream, d->d_sreads + off * N * PCS_NA, d->d_dom + off, m, N, N <= 128 ? d->heavy_min : d->heavy_min_wide, list,
                       n_list, d->d_heavy_flag + off);
   PCCHK (d, hipEventRecord (d->ev_heavy[0], d->stream));
   PCCHK (d, hipStreamWaitEvent (hs, d->ev_heavy[0], 0));
-  const int row = N <= 64 ? 64 : 128;
+  const int row = N <= 64 ? 64 : N <= 128 ? 128 : N <= 256 ? 256 : 512;
   char *scratch = scratch_at ? scratch_at : d->d_scratch + (size_t) d->site_grid * (2 * PCS_BIG_BYTES_OF (row) + PCS_BIGCAP);
   const long hw = waves > 0 ? waves : (long) d->heavy_grid;
   const long grid = m < hw ? m : hw;
@@ -842,8 +848,12 @@ static int pcs_heavy_start (pecall_dev * d, const PcsParams & P, long off, long 
                       d->d_ac + off * PCS_NA, d->d_npass + off, d->d_den + off, scratch, ctr, (const unsigned *) list, (const unsigned *) n_list)
   if (N <= 64)
     PCS_HEAVY (1);
-  else
+  else if (N <= 128)
     PCS_HEAVY (2);
+  else if (N <= 256)
+    PCS_HEAVY (4);
+  else
+    PCS_HEAVY (8);
 #undef PCS_HEAVY
   PCCHK (d, hipGetLastError ());
   PCCHK (d, hipEventRecord (done, hs));
@@ -888,7 +898,7 @@ extern "C" int pecall_dev_sites_run (pecall_dev * d, int haploid, double thresho
   std::vector < char >deep ((size_t) k, 0);
   // the long beam searches first (pcs_heavy_kernel): listed from the resident columns, started on a stream of their own beside everything
   // that follows -- a launch of the beam search ends with its slowest column, and the last chunk's used to be the run's last 8 ms
-  const bool heavy = indiv <= 128 && d->heavy_min > 0;
+  const bool heavy = (indiv <= 128 ? d->heavy_min : d->heavy_min_wide) > 0;
   if (heavy)
     if ((rc = pcs_heavy_start (d, P, 0, n_sites, 0, d->ev_heavy[1])))
       return rc;
@@ -1110,7 +1120,7 @@ static int pcs_call_sites_impl (pecall_dev * d, const uint16_t * reads, const ui
   {
     const long off = (long) j * C, m = n_sites - off < C ? n_sites - off : C;
     int rc2 = whole_table ? 0 : pcs_chunk_reset (d, P, j, off, m);
-    if (rc2 || (rc2 = pcs_chunk_kernels (d, P, j, off, m, whole_table, sparse, (N <= 128 && d->heavy_min > 0) ? 2 : 0)))
+    if (rc2 || (rc2 = pcs_chunk_kernels (d, P, j, off, m, whole_table, sparse, (N <= 128 ? d->heavy_min : d->heavy_min_wide) > 0 ? 2 : 0)))
       return rc2;
     PCCHK (d, hipStreamWaitEvent (d->stream_d2h, d->ev_call[j], 0));
     char *o = out_direct ? nullptr : d->h_out[j % PCS_SLOTS];

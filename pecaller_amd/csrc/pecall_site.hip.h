@@ -597,10 +597,11 @@ template < int NCH > __device__ int pcs_expand (const PcsPool & cur, PcsPool & n
 
 // calls and site classification of one column (pecaller.c:1565-1636, de-novo rows 1650-1671), lane = sample (of each chunk of 64):
 // what the reference prints for it -- calls and posteriors, Allele_Counts, the row's type, the passes it took
-template < int NCH > __device__ __forceinline__ void pcs_write_site (const PcsParams & P, long site, int lane, int dom, int chrom, const int (&r)[NCH][PCS_NA],
-                                                                    const int (&tot)[NCH], double average_depth, const int (&final_call)[NCH],
-                                                                    const double (&final_p)[NCH], int pass, int8_t * call, double *post_out,
-                                                                    int8_t * type_out, int32_t * allele_count, int8_t * n_pass, int32_t * denovo_out)
+// (RD: the reads of chunk c as six ints and their depth -- the caller's registers, or the column's row read again where the registers do not hold NCH x 6)
+template < int NCH, class RD > __device__ __forceinline__ void pcs_write_site_rd (const PcsParams & P, long site, int lane, int dom, int chrom, RD rd,
+                                                                              double average_depth, const int (&final_call)[NCH],
+                                                                              const double (&final_p)[NCH], int pass, int8_t * call, double *post_out,
+                                                                              int8_t * type_out, int32_t * allele_count, int8_t * n_pass, int32_t * denovo_out)
 {
   const int N = P.indiv, md = P.min_depth;
   // ---- calls and site classification (pecaller.c:1565-1636)
@@ -610,7 +611,9 @@ template < int NCH > __device__ __forceinline__ void pcs_write_site (const PcsPa
 #pragma unroll
   for (int c = 0; c < NCH; c++)
     {
-      called[c] = 64 * c + lane < N && tot[c] > md;
+      int rc[PCS_NA], totc;
+      rd (c, rc, totc);
+      called[c] = 64 * c + lane < N && totc > md;
       if (called[c] && final_p[c] >= P.threshold)
         {
 #pragma unroll
@@ -620,12 +623,12 @@ template < int NCH > __device__ __forceinline__ void pcs_write_site (const PcsPa
               if (k)
                 {
                   ac6[a] += k;
-                  on_target += r[c][a];
+                  on_target += rc[a];
                 }
               else if (a != dom || final_call[c] != PCS_NA - 1)
-                off_target += r[c][a];
+                off_target += rc[a];
             }
-          if (tot[c] > low_base && final_call[c] != dom)
+          if (totc > low_base && final_call[c] != dom)
             not_low += 1;
         }
     }
@@ -731,6 +734,21 @@ template < int NCH > __device__ __forceinline__ void pcs_write_site (const PcsPa
       n_pass[site] = (int8_t) pass;
       denovo_out[site] = dcount;
     }
+}
+
+template < int NCH > __device__ __forceinline__ void pcs_write_site (const PcsParams & P, long site, int lane, int dom, int chrom, const int (&r)[NCH][PCS_NA],
+                                                                    const int (&tot)[NCH], double average_depth, const int (&final_call)[NCH],
+                                                                    const double (&final_p)[NCH], int pass, int8_t * call, double *post_out,
+                                                                    int8_t * type_out, int32_t * allele_count, int8_t * n_pass, int32_t * denovo_out)
+{
+  auto rd = [&] (const int c, int (&rc)[PCS_NA], int &totc)
+  {
+#pragma unroll
+    for (int a = 0; a < PCS_NA; a++)
+      rc[a] = r[c][a];
+    totc = tot[c];              // (the caller's: 0 in a column the site filters drop)
+  };
+  pcs_write_site_rd < NCH > (P, site, lane, dom, chrom, rd, average_depth, final_call, final_p, pass, call, post_out, type_out, allele_count, n_pass, denovo_out);
 }
 
 // (one chunk of samples, as the shortcut kernel has them)
@@ -1315,11 +1333,53 @@ template < int NCH > struct PcsAcPack
   }
 };
 
-template < int NCH > __device__ bool pcs_mini_beam (const PcsParams & P, const double (&lk)[NCH][PCS_NG], const int (&r)[NCH][PCS_NA], const bool (&deep)[NCH],
-                                                    const bool (&ok)[NCH], const int (&best)[NCH], const double (&margin)[NCH], int dom, int site_hap,
-                                                    uint8_t * w_sord, double *w_like, int lane, int (&final_call)[NCH], double (&final_p)[NCH])
+// The small beam's sizes.  Up to 128 samples (NCH <= 2, all likelihoods in the caller's registers): four unsettled samples, their genotypes
+// in an int above the configuration's heterozygote and allele counts.  Beyond (pcs_fast_kernel's form for 4 or 8 chunks, the unsettled
+// samples' likelihoods parked in LDS): sixteen, in 64 bits of their own (SPLIT) -- at 512 samples a column has eight on average.
+template < int NCH > struct PcsMini
+{
+  typedef typename std::conditional < (NCH > 2), unsigned long long, int >::type Misc;
+  typedef typename std::conditional < (NCH > 4), uint16_t, uint8_t >::type Sord;
+  static constexpr int MAXU = NCH > 2 ? 16 : PCS_MINI_U;
+  static constexpr bool SPLIT = NCH > 2;
+  static constexpr int GSHIFT = SPLIT ? 0 : 12;         // where the genotypes start in Misc
+};
+
+__device__ __forceinline__ unsigned long long pcs_bcast (unsigned long long v, int l)
+{
+  return ((unsigned long long) (unsigned) __builtin_amdgcn_readlane ((int) (v >> 32), l) << 32) | (unsigned long long) (unsigned) __builtin_amdgcn_readlane ((int) v, l);
+}
+
+__device__ __forceinline__ int pcs_permute (int dst, int v)
+{
+  return __builtin_amdgcn_ds_permute (dst, v);
+}
+
+__device__ __forceinline__ unsigned long long pcs_permute (int dst, unsigned long long v)
+{
+  return ((unsigned long long) (unsigned) __builtin_amdgcn_ds_permute (dst, (int) (v >> 32)) << 32) | (unsigned long long) (unsigned) __builtin_amdgcn_ds_permute (dst, (int) v);
+}
+
+__device__ __forceinline__ int pcs_shfl (int v, int src)
+{
+  return __shfl (v, src);
+}
+
+__device__ __forceinline__ unsigned long long pcs_shfl (unsigned long long v, int src)
+{
+  return ((unsigned long long) (unsigned) __shfl ((int) (v >> 32), src) << 32) | (unsigned long long) (unsigned) __shfl ((int) v, src);
+}
+
+// lk_dom: every sample's likelihood of the reference homozygote; stage (who, r4, r5) -> the 14 likelihoods of sample `who` where every lane
+// can index them (LDS), and its deletion / insertion reads
+template < int NCH, class STAGE > __device__ bool pcs_mini_core (const PcsParams & P, const double (&lk_dom)[NCH], const bool (&deep)[NCH],
+                                                                const bool (&ok)[NCH], const int (&best)[NCH], const double (&margin)[NCH], int dom, int site_hap,
+                                                                typename PcsMini < NCH >::Sord * w_sord, STAGE stage, int lane, int (&final_call)[NCH],
+                                                                double (&final_p)[NCH])
 {
   typedef PcsAcPack < NCH > AC;
+  typedef typename PcsMini < NCH >::Misc Misc;
+  typedef typename PcsMini < NCH >::Sord Sord;
   const int N = P.indiv, G = P.max_gen;
   unsigned long long deep_m[NCH], unset_m[NCH];
   int nu = 0, n_deep = 0, n_set = 0;
@@ -1332,7 +1392,7 @@ template < int NCH > __device__ bool pcs_mini_beam (const PcsParams & P, const d
       n_deep += (int) __popcll (deep_m[c]);
       n_set += (int) __popcll (deep_m[c] & ~unset_m[c]);
     }
-  if (P.use_ped || nu > PCS_MINI_U || nu == 0)
+  if (P.use_ped || nu > PcsMini < NCH >::MAXU || nu == 0)
     return false;
   if (n_deep * (site_hap ? 1 : 2) > AC::MASK)
     return false;               // (allele counts are packed here)
@@ -1364,7 +1424,7 @@ template < int NCH > __device__ bool pcs_mini_beam (const PcsParams & P, const d
 #pragma unroll
   for (int c = 0; c < NCH; c++)
     if (64 * c + lane < N)
-      w_sord[rank[c]] = (uint8_t) (64 * c + lane);
+      w_sord[rank[c]] = (Sord) (64 * c + lane);
   pcs_sync ();
   int sord[NCH];
 #pragma unroll
@@ -1376,15 +1436,6 @@ template < int NCH > __device__ bool pcs_mini_beam (const PcsParams & P, const d
   };
   // ---- fill_config_like of the all-reference configuration (pecaller.c:2347-2360): the deep samples' likelihoods of `dom`, in
   //      sample order; then the settled samples' expansions, each of which leaves (L - l) + l
-  double lk_dom[NCH];
-#pragma unroll
-  for (int c = 0; c < NCH; c++)
-    {
-      lk_dom[c] = 0.0;
-#pragma unroll
-      for (int g = 0; g < 4; g++)
-        lk_dom[c] = (g == dom) ? lk[c][g] : lk_dom[c];
-    }
   double L = 0.0;
   for (int i = 0; i < N; i++)
     if ((pcs_chunk_of < NCH > (deep_m, i) >> (i & 63)) & 1ull)
@@ -1397,7 +1448,11 @@ template < int NCH > __device__ bool pcs_mini_beam (const PcsParams & P, const d
     }
   // ---- the list: configuration i in lane i
   double c_like = L, c_prior = 0.0, c_post = 0.0 + L;
-  int c_ac[AC::WORDS], c_misc = 1 << 8;   // misc: hets | nall << 8 | genotypes of the unsettled samples << 12
+  constexpr bool SPLIT = PcsMini < NCH >::SPLIT;
+  constexpr int GSHIFT = PcsMini < NCH >::GSHIFT;
+  int c_ac[AC::WORDS];
+  Misc c_misc = SPLIT ? 0 : 1 << 8;     // misc: hets | nall << 8 | genotypes of the unsettled samples << 12 (SPLIT: the genotypes alone ...
+  int c_hn = 1 << 8;                    // ... hets | nall << 8 here)
   {
     int ac[PCS_NA] = { 0, 0, 0, 0, 0, 0 };
 #pragma unroll
@@ -1416,24 +1471,8 @@ template < int NCH > __device__ bool pcs_mini_beam (const PcsParams & P, const d
         return false;
       const int who = sample_at (n_set + t);
       // the sample's likelihoods, where every lane can index them
-      pcs_sync ();
-#pragma unroll
-      for (int c = 0; c < NCH; c++)
-        if (64 * c + lane == who)
-          {
-#pragma unroll
-            for (int g = 0; g < PCS_NG; g++)
-              w_like[g] = lk[c][g];
-          }
-      pcs_sync ();
-      int r4v[NCH], r5v[NCH];
-#pragma unroll
-      for (int c = 0; c < NCH; c++)
-        {
-          r4v[c] = r[c][4];
-          r5v[c] = r[c][5];
-        }
-      const int r4 = pcs_bcast (pcs_chunk_of < NCH > (r4v, who), who & 63), r5 = pcs_bcast (pcs_chunk_of < NCH > (r5v, who), who & 63);
+      int r4, r5;
+      const double *w_like = stage (who, r4, r5);
       double best_post = pcs_bcast (c_post, 0), best_like = pcs_bcast (c_like, 0);
       // ---- every candidate (configuration, genotype) priced by its own lane (pcs_expand; the sample's old genotype is `dom`)
       const int total = n * G;
@@ -1445,7 +1484,8 @@ template < int NCH > __device__ bool pcs_mini_beam (const PcsParams & P, const d
 #pragma unroll
       for (int w = 0; w < AC::WORDS; w++)
         s_ac[w] = __shfl (c_ac[w], pos);
-      const int s_misc = __shfl (c_misc, pos);
+      const Misc s_misc = pcs_shfl (c_misc, pos);
+      const int s_hn = SPLIT ? __shfl (c_hn, pos) : (int) (s_misc & 0xFFF);
       double base = s_like;
       base -= w_like[dom];
       double templ = base + w_like[j];
@@ -1468,7 +1508,7 @@ template < int NCH > __device__ bool pcs_mini_beam (const PcsParams & P, const d
           ac[k] = old - (k == oa) - (k == ob) + (k == na) + (k == nb);
           nall += ac[k] > 0;
         }
-      const int hets = (s_misc & 0xFF) + (j >= PCS_NA ? 1 : 0);
+      const int hets = (s_hn & 0xFF) + (j >= PCS_NA ? 1 : 0);
       double prior = 0;
       if (nall > 1)
         prior = (nall - 1) * P.ln_theta;
@@ -1505,14 +1545,16 @@ template < int NCH > __device__ bool pcs_mini_beam (const PcsParams & P, const d
             prior += P.hw[P.hw_off[tot_n] + (long) minor * (tot_n + 1) + hh];
         }
       const double post = prior + templ;
-      const int misc_new = hets | (nall << 8) | (s_misc & ~0xFFF) | (j << (12 + 4 * t));
+      const int hn_new = hets | (nall << 8);
+      const Misc misc_new = (SPLIT ? s_misc : (Misc) hn_new | (s_misc & ~(Misc) 0xFFF)) | ((Misc) j << (GSHIFT + 4 * t));
       int ac_new[AC::WORDS];
 #pragma unroll
       for (int w = 0; w < AC::WORDS; w++)
         ac_new[w] = AC::pack (ac, w);
       // ---- the acceptance rule in candidate order (pecaller.c:2628, 2738-2758); the kept ones become the new list, in that order
       double n_like = 0, n_prior = 0, n_post = 0;
-      int n_ac[AC::WORDS], n_misc = 0, newcount = 0;
+      int n_ac[AC::WORDS], newcount = 0, n_hn = 0;
+      Misc n_misc = 0;
 #pragma unroll
       for (int w = 0; w < AC::WORDS; w++)
         n_ac[w] = 0;
@@ -1529,7 +1571,8 @@ template < int NCH > __device__ bool pcs_mini_beam (const PcsParams & P, const d
           if (!(po + thres > best_post))
             continue;
           const double pr = pcs_bcast (prior, k);
-          const int mi = pcs_bcast (misc_new, k);
+          const Misc mi = pcs_bcast (misc_new, k);
+          const int hn = SPLIT ? pcs_bcast (hn_new, k) : 0;
           int av[AC::WORDS];
 #pragma unroll
           for (int w = 0; w < AC::WORDS; w++)
@@ -1543,6 +1586,7 @@ template < int NCH > __device__ bool pcs_mini_beam (const PcsParams & P, const d
               for (int w = 0; w < AC::WORDS; w++)
                 n_ac[w] = av[w];
               n_misc = mi;
+              n_hn = hn;
             }
           newcount++;
         }
@@ -1561,7 +1605,11 @@ template < int NCH > __device__ bool pcs_mini_beam (const PcsParams & P, const d
 #pragma unroll
       for (int w = 0; w < AC::WORDS; w++)
         c_ac[w] = PCS_PUSH (n_ac[w]);
-      c_misc = PCS_PUSH (n_misc);
+      c_misc = pcs_permute (dst, n_misc);
+      if (SPLIT)
+        c_hn = pcs_permute (dst, n_hn);
+      else
+        c_hn = (int) (c_misc & 0xFFF);
 #undef PCS_PUSH
       int mx = newcount;        // (at most 56: max_configs = 514 is out of reach)
       {
@@ -1570,7 +1618,7 @@ template < int NCH > __device__ bool pcs_mini_beam (const PcsParams & P, const d
         if (cutm)
           mx = __ffsll ((long long) cutm) - 1;
       }
-      if (!__any (lane < mx && ((c_misc >> 8) & 0xF) == 1))
+      if (!__any (lane < mx && ((c_hn >> 8) & 0xF) == 1))
         return false;           // no homozygous configuration in the list: the reference adds one (2286-2333) -- pcs_call_kernel's case
       n = mx;
     }
@@ -1601,8 +1649,8 @@ template < int NCH > __device__ bool pcs_mini_beam (const PcsParams & P, const d
           for (int i = 0; i < n; i++)
             {
               const double pi = pcs_bcast (e, i);
-              const int gi = pcs_bcast (c_misc, i);
-              const int mine = my_t >= 0 ? ((gi >> (12 + 4 * my_t)) & 0xF) : dom;
+              const Misc gi = pcs_bcast (c_misc, i);
+              const int mine = my_t >= 0 ? (int) ((gi >> (GSHIFT + 4 * my_t)) & 0xF) : dom;
               if (mine == g)
                 acc += pi;
             }
@@ -1629,6 +1677,46 @@ template < int NCH > __device__ bool pcs_mini_beam (const PcsParams & P, const d
   return true;
 }
 
+// up to 128 samples: the likelihoods of every sample are in the caller's registers
+template < int NCH > __device__ bool pcs_mini_beam (const PcsParams & P, const double (&lk)[NCH][PCS_NG], const int (&r)[NCH][PCS_NA], const bool (&deep)[NCH],
+                                                    const bool (&ok)[NCH], const int (&best)[NCH], const double (&margin)[NCH], int dom, int site_hap,
+                                                    uint8_t * w_sord, double *w_like, int lane, int (&final_call)[NCH], double (&final_p)[NCH])
+{
+  double lk_dom[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; c++)
+    {
+      lk_dom[c] = 0.0;
+#pragma unroll
+      for (int g = 0; g < 4; g++)
+        lk_dom[c] = (g == dom) ? lk[c][g] : lk_dom[c];
+    }
+  auto stage = [&] (int who, int &r4, int &r5)->const double *
+  {
+    pcs_sync ();
+#pragma unroll
+    for (int c = 0; c < NCH; c++)
+      if (64 * c + lane == who)
+        {
+#pragma unroll
+          for (int g = 0; g < PCS_NG; g++)
+            w_like[g] = lk[c][g];
+        }
+    pcs_sync ();
+    int r4v[NCH], r5v[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; c++)
+      {
+        r4v[c] = r[c][4];
+        r5v[c] = r[c][5];
+      }
+    r4 = pcs_bcast (pcs_chunk_of < NCH > (r4v, who), who & 63);
+    r5 = pcs_bcast (pcs_chunk_of < NCH > (r5v, who), who & 63);
+    return w_like;
+  };
+  return pcs_mini_core < NCH > (P, lk_dom, deep, ok, best, margin, dom, site_hap, w_sord, stage, lane, final_call, final_p);
+}
+
 
 // ---- the columns every sample agrees on, without the beam.  One wave per column (lane = sample), eight columns per
 // workgroup round, the ln n! table (80 KB) and the four first-pass Dirichlet mean tables in the workgroup's LDS.  Per column:
@@ -1650,8 +1738,11 @@ template < int NCH > __device__ bool pcs_mini_beam (const PcsParams & P, const d
 #define PCS_TA_SCALES 91
 #define PCS_TA_ROWS (4 * PCS_TA_SCALES * PCS_NG)
 #define PCS_TA_BYTES (PCS_TA_ROWS * 4 + PCS_TA_ROWS * 2)        // a0..a3 packed in a word per row, a4 a5 in a half-word
-#define PCS_FAST_WAVE_BYTES_OF(NCH) (64 * (NCH) + PCS_NG * 8 + 16)        // per wave: the samples' order, one sample's likelihoods (pcs_mini_beam)
-#define PCS_FAST_LDS_BYTES_OF(TABN) (((TABN) + 1) * 8 + PCS_TA_BYTES + (PCS_FAST_BLOCK_OF (TABN) / 64) * PCS_FAST_WAVE_BYTES_OF (2))
+// per wave: the samples' order and one sample's likelihoods (pcs_mini_beam); beyond 128 samples 16 = PcsMini::MAXU unsettled samples' likelihoods
+// (128 bytes each) and the order (two bytes a sample beyond 256)
+#define PCS_FAST_WAVE_BYTES_OF(NCH) ((NCH) <= 2 ? 64 * (NCH) + PCS_NG * 8 + 16 : 16 * 128 + ((NCH) > 4 ? 2 : 1) * 64 * (NCH))
+#define PCS_FAST_LDS_BYTES_OF2(TABN, NCH) (((TABN) + 1) * 8 + PCS_TA_BYTES + (PCS_FAST_BLOCK_OF (TABN) / 64) * PCS_FAST_WAVE_BYTES_OF ((NCH) <= 2 ? 2 : (NCH)))
+#define PCS_FAST_LDS_BYTES_OF(TABN) PCS_FAST_LDS_BYTES_OF2 (TABN, 2)
 
 // the ta table as words: PCS_TA_ROWS words (alleles 0..3) followed by PCS_TA_ROWS half-words (alleles 4, 5); every ta is at most 100
 static void pcs_ta_table (uint32_t * out)
@@ -1715,7 +1806,8 @@ void pcs_fast_kernel (PcsParams P, const uint16_t * reads, const uint8_t * dom_o
   const int N = P.indiv, G = P.max_gen, md = P.min_depth;
   __syncthreads ();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint8_t *w_sord = (uint8_t *) (ta_hi + PCS_TA_ROWS) + (size_t) wave * PCS_FAST_WAVE_BYTES_OF (NCH);
+  uint8_t *w_wave = (uint8_t *) (ta_hi + PCS_TA_ROWS) + (size_t) wave * PCS_FAST_WAVE_BYTES_OF (NCH);
+  uint8_t *w_sord = w_wave;             // (up to 128 samples; beyond that the wave's bytes are laid out where they are used)
   double *w_like = (double *) (w_sord + 64 * NCH);
   // Columns are handed out PCS_FAST_GRAB at a time through a counter (next_piece; the first grid-ful of pieces by wave index).
   // With a fixed stride the launch took as long as its unluckiest workgroup: beside the beam searches of earlier chunks, whose
@@ -1743,8 +1835,221 @@ void pcs_fast_kernel (PcsParams P, const uint16_t * reads, const uint8_t * dom_o
 #pragma unroll
       for (int c = 0; c < NCH; c++)
         my_call[c] = PCS_NG;
+      auto likelihoods = [&] (const double *tb, const int (&rr)[PCS_NA], const int tt, double (&lkc)[PCS_NG], int &bestc, double &marginc)
+      {
+        double coef = pc_factln (tb, tt);
+#pragma unroll
+        for (int a = 0; a < PCS_NA; a++)
+          coef -= pc_factln (tb, rr[a]);
+        // scale = min (depth, 100) * norm (1 in pass 1), at least 10: an integer 10 .. 100, the row of the ta table
+        const int sci = (tt < 10 ? 10 : (tt > 100 ? 100 : tt)) - 10;
+        const uint32_t *tl = ta_lo + (dom * PCS_TA_SCALES + sci) * PCS_NG;
+        const uint16_t *th = ta_hi + (dom * PCS_TA_SCALES + sci) * PCS_NG;
+        double mx = -1e100;
+#pragma unroll
+        for (int g = 0; g < PCS_NG; g++)
+          {
+            lkc[g] = 0.0;
+            if (g < G)
+              {
+                const uint32_t w4 = tl[g], w2 = th[g];
+                int tot_a = 0, tot_tot = 0;
+                double cf = coef, l = 0.0;
+#pragma unroll
+                for (int a = 0; a < PCS_NA; a++)
+                  {
+                    const int ta = (int) ((a < 4 ? (w4 >> (8 * a)) : (w2 >> (8 * (a - 4)))) & 0xFFu);
+                    tot_a += ta;
+                    tot_tot += ta + rr[a];
+                    cf -= pc_factln (tb, ta - 1);
+                    l += pc_factln (tb, ta + rr[a] - 1);
+                  }
+                cf += pc_factln (tb, tot_a - 1);
+                l += cf;
+                l -= pc_factln (tb, tot_tot - 1);
+                lkc[g] = l;
+                if (l > mx)
+                  {
+                    bestc = g;
+                    mx = l;
+                  }
+              }
+          }
+        // initial_p: the margin of the best genotype over every other one (pecaller.c:2494-2504)
+        marginc = 1e100;
+#pragma unroll
+        for (int g = 0; g < PCS_NG; g++)
+          if (g < G && g != bestc)
+            {
+              const double dlt = mx - lkc[g];
+              marginc = (dlt < marginc) ? dlt : marginc;
+            }
+      };
       if (dom > 3)
         type = -1;              // the reference skips the column (pecaller.c:1208, 1718)
+      else if constexpr (NCH > 2)
+        {
+          // More than 128 samples: the same test and the same small beam, a chunk of 64 samples at a time.  The likelihoods of four or
+          // eight samples per lane do not fit the registers, and the small beam needs few of them: every sample's likelihood of the
+          // reference homozygote, its margin and its verdict stay in registers, the 14 likelihoods of an UNSETTLED sample (and its
+          // deletion / insertion reads) are parked in the wave's LDS as they are computed -- up to PcsMini::MAXU of them; a column with
+          // more, like any column the small beam hands back and a column too deep for the table's head, is listed for pcs_call_kernel,
+          // which is the whole caller.
+          typedef PcsMini < NCH > MINI;
+          static_assert (PCS_FAST_WAVE_BYTES_OF (NCH) == MINI::MAXU * 128 + (int) sizeof (typename MINI::Sord) * 64 * NCH, "the wave's bytes: the parked likelihoods, the order");
+          bool too_deep = false;
+          int tsum = 0, sample_count = 0;
+#pragma unroll
+          for (int c = 0; c < NCH; c++)
+            {
+              const bool have = 64 * c + lane < N;
+              int tt = 0, r5 = 0;
+              if (have)
+                {
+                  const uint16_t *p = reads + (site * N + 64 * c + lane) * PCS_NA;
+                  tt = (int) p[0] + (int) p[1] + (int) p[2] + (int) p[3] + (int) p[4];
+                  r5 = (int) p[5];
+                }
+              too_deep = too_deep || (tt + r5 + 6 * 100 + 1 >= TABN);
+              tsum += tt;
+              sample_count += (int) __popcll (__ballot (have && tt >= 8));
+            }
+          for (int o = 32; o; o >>= 1)
+            tsum += __shfl_xor (tsum, o);
+          const double average_depth = (double) tsum / (double) N;
+          bool bad_base = average_depth < 8;
+          if (sample_count < (double) 0.5 * N && chrom != 2)
+            bad_base = true;
+          if (!bad_base)
+            {
+              if (__any (too_deep))
+                {
+                  decided = 0;
+                  n_unset = 64;
+                }
+              else
+                {
+                  double *stash = (double *) w_wave;            // [MAXU][16]: 14 likelihoods, {r4, r5}, {sample, -}
+                  typename MINI::Sord * w_sord = (typename MINI::Sord *) (w_wave + MINI::MAXU * 128);
+                  double lk_dom[NCH], margin[NCH];
+                  bool deep[NCH], ok[NCH];
+                  int best[NCH], n_deep_s = 0;
+#pragma unroll
+                  for (int c = 0; c < NCH; c++)
+                    {
+                      lk_dom[c] = 0.0;
+                      margin[c] = 0.0;
+                      deep[c] = false;
+                      ok[c] = true;
+                      best[c] = PCS_NG;
+                    }
+                  pcs_sync ();          // (the previous column's beam has read its stash)
+                  // (a loop that is not unrolled -- eight copies of the likelihoods would not fit the instruction cache -- whose chunk's
+                  // results go to their registers through selects: an array indexed by the loop variable would live in scratch)
+#pragma unroll 1
+                  for (int c = 0; c < NCH; c++)
+                    {
+                      int rr[PCS_NA];
+                      const bool have = 64 * c + lane < N;
+#pragma unroll
+                      for (int a = 0; a < PCS_NA; a++)
+                        rr[a] = have ? (int) reads[(site * N + 64 * c + lane) * PCS_NA + a] : 0;
+                      const int tt = rr[0] + rr[1] + rr[2] + rr[3] + rr[4];
+                      const bool dp = have && tt > md;
+                      bool okc = true;
+                      double lkc[PCS_NG], mg = 0.0, lkd = 0.0;
+                      int bc = PCS_NG;
+#pragma unroll
+                      for (int g = 0; g < PCS_NG; g++)
+                        lkc[g] = 0.0;
+                      if (dp)
+                        {
+                          likelihoods (tab, rr, tt, lkc, bc, mg);
+                          okc = bc == dom && mg > 2.31;
+#pragma unroll
+                          for (int g = 0; g < 4; g++)
+                            lkd = (g == dom) ? lkc[g] : lkd;
+                        }
+                      const unsigned long long um = __ballot (dp && !okc);
+                      if (dp && !okc)
+                        {
+                          const int slot = n_unset + (int) __popcll (um & ((1ull << lane) - 1ull));
+                          if (slot < MINI::MAXU)
+                            {
+                              double *sl = stash + 16 * slot;
+#pragma unroll
+                              for (int g = 0; g < PCS_NG; g++)
+                                sl[g] = lkc[g];
+                              ((int *) (sl + 14))[0] = rr[4];
+                              ((int *) (sl + 14))[1] = rr[5];
+                              ((int *) (sl + 15))[0] = 64 * c + lane;
+                            }
+                        }
+#pragma unroll
+                      for (int cc = 0; cc < NCH; cc++)
+                        {
+                          const bool here = cc == c;
+                          my_call[cc] = (here && dp) ? dom : my_call[cc];
+                          lk_dom[cc] = here ? lkd : lk_dom[cc];
+                          margin[cc] = here ? mg : margin[cc];
+                          deep[cc] = here ? dp : deep[cc];
+                          ok[cc] = here ? okc : ok[cc];
+                          best[cc] = here ? bc : best[cc];
+                        }
+                      n_unset += (int) __popcll (um);
+                      n_deep_s += (int) __popcll (__ballot (dp));
+                    }
+                  if (n_unset == 0)
+                    {
+                      npass = 1;
+                      if (1.0 >= P.threshold)
+                        ac_dom = n_deep_s * (P.haploid ? 1 : 2);
+                    }
+                  else
+                    {
+                      if (n_unset <= MINI::MAXU)
+                        {
+                          pcs_sync ();
+                          const int nst = n_unset;
+                          auto stage = [&] (int who, int &r4, int &r5)->const double *
+                          {
+                            int slot = 0;
+                            for (int q = 1; q < nst; q++)
+                              slot = (((const int *) (stash + 16 * q + 15))[0] == who) ? q : slot;
+                            const int *ri = (const int *) (stash + 16 * slot + 14);
+                            r4 = ri[0];
+                            r5 = ri[1];
+                            return stash + 16 * slot;
+                          };
+                          int fc[NCH];
+                          double fp[NCH];
+#pragma unroll
+                          for (int c = 0; c < NCH; c++)
+                            {
+                              fc[c] = PCS_NG;
+                              fp[c] = 1.0;
+                            }
+                          const int site_hap = P.haploid | ((chrom_of[site] >> 4) & 1);
+                          if (pcs_mini_core < NCH > (P, lk_dom, deep, ok, best, margin, dom, site_hap, w_sord, stage, lane, fc, fp))
+                            {
+                              auto rd = [&] (const int c, int (&rc)[PCS_NA], int &totc)
+                              {
+                                const bool have = 64 * c + lane < N;
+#pragma unroll
+                                for (int a = 0; a < PCS_NA; a++)
+                                  rc[a] = have ? (int) reads[(site * N + 64 * c + lane) * PCS_NA + a] : 0;
+                                totc = rc[0] + rc[1] + rc[2] + rc[3] + rc[4];
+                              };
+                              pcs_write_site_rd < NCH > (P, site, lane, dom, chrom, rd, average_depth, fc, fp, 1, call, post_out, type_out, allele_count, n_pass,
+                                                         denovo_out);
+                              continue;
+                            }
+                        }
+                      decided = 0;
+                    }
+                }
+            }
+        }
       else
         {
           int r[NCH][PCS_NA], tot[NCH];
@@ -1785,56 +2090,6 @@ void pcs_fast_kernel (PcsParams P, const uint16_t * reads, const uint8_t * dom_o
               bool deep[NCH], ok[NCH];
               double lk[NCH][PCS_NG], margin[NCH];
               int best[NCH];
-              auto likelihoods = [&] (const double *tb, const int (&rr)[PCS_NA], const int tt, double (&lkc)[PCS_NG], int &bestc, double &marginc)
-              {
-                double coef = pc_factln (tb, tt);
-#pragma unroll
-                for (int a = 0; a < PCS_NA; a++)
-                  coef -= pc_factln (tb, rr[a]);
-                // scale = min (depth, 100) * norm (1 in pass 1), at least 10: an integer 10 .. 100, the row of the ta table
-                const int sci = (tt < 10 ? 10 : (tt > 100 ? 100 : tt)) - 10;
-                const uint32_t *tl = ta_lo + (dom * PCS_TA_SCALES + sci) * PCS_NG;
-                const uint16_t *th = ta_hi + (dom * PCS_TA_SCALES + sci) * PCS_NG;
-                double mx = -1e100;
-#pragma unroll
-                for (int g = 0; g < PCS_NG; g++)
-                  {
-                    lkc[g] = 0.0;
-                    if (g < G)
-                      {
-                        const uint32_t w4 = tl[g], w2 = th[g];
-                        int tot_a = 0, tot_tot = 0;
-                        double cf = coef, l = 0.0;
-#pragma unroll
-                        for (int a = 0; a < PCS_NA; a++)
-                          {
-                            const int ta = (int) ((a < 4 ? (w4 >> (8 * a)) : (w2 >> (8 * (a - 4)))) & 0xFFu);
-                            tot_a += ta;
-                            tot_tot += ta + rr[a];
-                            cf -= pc_factln (tb, ta - 1);
-                            l += pc_factln (tb, ta + rr[a] - 1);
-                          }
-                        cf += pc_factln (tb, tot_a - 1);
-                        l += cf;
-                        l -= pc_factln (tb, tot_tot - 1);
-                        lkc[g] = l;
-                        if (l > mx)
-                          {
-                            bestc = g;
-                            mx = l;
-                          }
-                      }
-                  }
-                // initial_p: the margin of the best genotype over every other one (pecaller.c:2494-2504)
-                marginc = 1e100;
-#pragma unroll
-                for (int g = 0; g < PCS_NG; g++)
-                  if (g < G && g != bestc)
-                    {
-                      const double dlt = mx - lkc[g];
-                      marginc = (dlt < marginc) ? dlt : marginc;
-                    }
-              };
               bool all_ok = true;
               int n_deep_s = 0;
 #pragma unroll

@@ -100,6 +100,58 @@ def test_gpu_site_caller_64_samples_and_haploid():
     dev.close()
 
 
+def _wide_reference_columns(n, n_sites, seed, var_frac, deep_every):
+    """mostly reference columns of n samples (30x, 0.4 % errors: a handful of samples per column miss the shortcut's margin by error reads
+    alone), a few variant columns, a sample too deep for the head of the ln n! table in every deep_every-th column"""
+    rng = np.random.default_rng(seed)
+    dom = rng.integers(0, 4, n_sites).astype(np.uint8)
+    dom[::97] = 14
+    depth = rng.integers(20, 40, n)
+    depth[5] = 3
+    is_var = rng.random(n_sites) < var_frac
+    q = rng.uniform(0.01, 0.5, n_sites)
+    alt = rng.integers(0, 6, n_sites)
+    reads = np.zeros((n_sites, n, 6), np.int64)
+    idx = np.arange(n_sites)
+    r = np.where(dom < 4, dom, 0)
+    for i in range(n):
+        d = rng.poisson(depth[i], n_sites)
+        dose = np.where(is_var, rng.binomial(2, q), 0)
+        e = rng.binomial(d, 0.004)
+        ar = rng.binomial(d - e, dose / 2.0)
+        reads[idx, i, r] += d - e - ar
+        reads[idx, i, alt] += ar
+        reads[idx, i, r] += np.where(alt == 5, ar, 0)
+        reads[idx, i, rng.integers(0, 4, n_sites)] += e
+    reads[::deep_every, 7, r[::deep_every]] += 1600
+    return reads.astype(np.uint16), dom
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,n_sites,var_frac", [(160, 1500, 0.02), (300, 1500, 0.02), (512, 250, 0.01)])
+def test_gpu_site_caller_wide_small_beam(n, n_sites, var_frac):
+    """beyond 128 samples the shortcut kernel works a chunk of 64 samples at a time and parks the unsettled samples' likelihoods in LDS for
+    the small beam (round 4; pcs_fast_kernel<., 4|8>): columns whose unsettled samples are error reads only -- nearly all of a real run --
+    against the oracle, with columns too deep for the table's head (listed for the beam search) and variant columns among them"""
+    from pecaller_amd.pecall import PecallDev
+    reads, dom = _wide_reference_columns(n, n_sites, 7000 + n, var_frac, 211)
+    dev = PecallDev(0)
+    got = dev.call_sites(reads, dom)
+    exp = oracle_py.call_sites(reads, dom)
+    assert np.array_equal(got[0], exp[0])
+    assert np.max(np.abs(got[1] - exp[1])) <= 1e-6
+    for a, b in zip(got[2:], exp[2:]):
+        assert np.array_equal(a, b)
+    assert (exp[4] == 1).sum() > 0.9 * n_sites and (exp[2] > 0).sum() >= 3
+    # the same columns resident (sites_stage / sites_run: the heavy columns' beam search starts ahead of the shortcut kernels)
+    dev.sites_stage(reads, dom)
+    dev.sites_run()
+    res = dev.sites_collect()
+    for a, b in zip(res, got):
+        assert np.array_equal(a, b)
+    dev.close()
+
+
 @pytest.mark.gpu
 def test_gpu_site_caller_deep_columns():
     """columns with samples thousands of reads deep: the shortcut kernel then stages the whole ln n! table instead of its head
