@@ -253,6 +253,7 @@ def main():
                     help="columns per launch of the PECaller leg (a launch ends with its slowest column: the few hundred-configuration "
                          "variant columns take ~50-90 ms each on one wave, so short launches measure that tail, not the rate)")
     ap.add_argument("--pecall-wide-sites", type=int, default=1000000, help="columns of the 128-sample data point of the PECaller leg (0 = skip)")
+    ap.add_argument("--pecall-wide256-sites", type=int, default=400000, help="columns of the 256-sample data point of the PECaller leg (0 = skip)")
     ap.add_argument("--pecall-cpu-seconds", type=float, default=10.0)
     ap.add_argument("--host-batches", type=int, default=4, help="distinct batches staged (and pinned) on the host; the steps cycle through them")
     ap.add_argument("--allow-fallback", action="store_true",
@@ -726,21 +727,24 @@ def pecaller_leg(a):
     kernel_ms = float(np.mean(kms))
     c2, p2 = pc.sites_collect()[:2]
     assert np.array_equal(c2, call) and np.array_equal(p2, post)
-    # beyond a lane per sample: 128 samples (the shortcut kernel with two samples per lane, round 4; 129 .. 512 take the beam search's
-    # kernel for every column), resident columns, a sample of them against the oracle
-    wide = None
-    if a.pecall_wide_sites > 0:
-        nw, SW = a.pecall_wide_sites, 128
-        wr, wd = pecall_columns(nw, SW, seed=778)
+    # beyond a lane per sample (round 4): 128 samples -- the shortcut kernel with two samples per lane -- and 256 -- a chunk of 64 samples
+    # at a time, the unsettled samples' likelihoods parked in LDS for the small beam; resident columns, a sample of them against the oracle
+    def wide_point(nw, SW, seed, chk, form):
+        wr, wd = pecall_columns(nw, SW, seed=seed)
         pc.sites_stage(wr, wd)
         wms = [pc.sites_run() for _ in range(2)]
         wc, wp = pc.sites_collect()[:2]
-        chk = min(nw, 2000)
+        chk = min(nw, chk)
         oc, op = oracle_py.call_sites(wr[:chk], wd[:chk])[:2]
-        wide = {"samples": SW, "columns": nw, "value": round(nw / (min(wms) * 1e-3) / 1e6, 4), "unit": "M columns/s", "kernel_ms": round(min(wms), 2),
-                "form": "pcs_fast_kernel<2048, 2> (two samples per lane) + pcs_call_kernel<2> of the columns it and pcs_heavy_kernel list",
+        return {"samples": SW, "columns": nw, "value": round(nw / (min(wms) * 1e-3) / 1e6, 4), "unit": "M columns/s", "kernel_ms": round(min(wms), 2), "form": form,
                 "calls_equal_oracle": bool(np.array_equal(wc[:chk], oc)), "max_abs_dposterior": float(np.max(np.abs(wp[:chk] - op))), "compared_columns": chk}
-        del wr, wd, wc, wp
+    wide = wide256 = None
+    if a.pecall_wide_sites > 0:
+        wide = wide_point(a.pecall_wide_sites, 128, 778, 2000,
+                          "pcs_fast_kernel<2048, 2> (two samples per lane) + pcs_call_kernel<2> of the columns it and pcs_heavy_kernel list")
+    if a.pecall_wide256_sites > 0:
+        wide256 = wide_point(a.pecall_wide256_sites, 256, 779, 600,
+                             "pcs_fast_kernel<2048, 4> (a chunk of 64 samples at a time) + pcs_call_kernel<4> of the columns it and pcs_heavy_kernel list")
     pc.close()
     # CPU: the oracle, one caller per thread on disjoint slices of the same columns (columns are independent)
     nt = a.cpu_threads if a.cpu_threads > 0 else physical_cores()
@@ -779,7 +783,7 @@ def pecaller_leg(a):
             "dtype": "f64", "data": "synthetic", "n_gpus": 1,
             "config": {"workload": "%d pileup columns x %d samples, 30x Poisson depth, 0.4%% error, 1 variant/kb under HWE, seed 777, "
                                    "prob_to_call 0.95, theta 0.001, diploid, no pedigree" % (n, S), "generated_in_s": round(t_gen, 1)},
-            "variant_rows": int((typ > 0).sum()), "passes_histogram": np.bincount(npass).tolist(), "samples_128": wide,
+            "variant_rows": int((typ > 0).sum()), "passes_histogram": np.bincount(npass).tolist(), "samples_128": wide, "samples_256": wide256,
             "kernel_ms_runs": [round(x, 2) for x in kms],
             "roofline": {"bound": sq["bound"] if sq else "hbm", "kernel": "pcs_fast_kernel+pcs_call_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc, "avg_launch_ms": round(kernel_ms, 3),

@@ -232,7 +232,8 @@ int pecall_dev_collect (pecall_dev * dev, int n_sites, int indiv, double *like, 
  *   allele_count[n_sites][6], n_pass[n_sites]  (may be NULL) Allele_Counts of the .snp row; passes run
  *   denovo[n_sites]     (may be NULL) d_count of the row (pecaller.c:1650-1671): > 0 = the type is printed as DENOVO_<type>
  * indiv <= 512: up to 64 samples one lane per sample (the fast case: shortcut kernel + beam search of the columns it lists);
- * 65..512 a lane stands for a sample of each chunk of 64 and every column takes the beam search's kernel (257..512: one wave per CU).  Text formatting and
+ * 65..512 a lane stands for a sample of each chunk of 64 -- the shortcut kernel holds two chunks in registers (up to 128 samples) or works a
+ * chunk at a time; the beam search of the columns it lists runs one wave per CU from 257 samples on.  Text formatting and
  * the merge of the pileup streams stay on the host.
  * The columns travel in chunks of 2^18 (PECALL_CHUNK_LOG2): the host-to-device copy of chunk k + 1, the kernels of chunk k and the
  * device-to-host copy of chunk k - 1 run side by side.  Arrays the caller page-locked with pecall_dev_pin_host are copied from and
