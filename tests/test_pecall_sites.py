@@ -128,7 +128,7 @@ def _wide_reference_columns(n, n_sites, seed, var_frac, deep_every):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,n_sites,var_frac", [(160, 1500, 0.02), (300, 1500, 0.02), (512, 250, 0.01)])
+@pytest.mark.parametrize("n,n_sites,var_frac", [(160, 800, 0.02), (300, 800, 0.02), (512, 160, 0.02)])
 def test_gpu_site_caller_wide_small_beam(n, n_sites, var_frac):
     """beyond 128 samples the shortcut kernel works a chunk of 64 samples at a time and parks the unsettled samples' likelihoods in LDS for
     the small beam (round 4; pcs_fast_kernel<., 4|8>): columns whose unsettled samples are error reads only -- nearly all of a real run --
@@ -142,7 +142,7 @@ def test_gpu_site_caller_wide_small_beam(n, n_sites, var_frac):
     assert np.max(np.abs(got[1] - exp[1])) <= 1e-6
     for a, b in zip(got[2:], exp[2:]):
         assert np.array_equal(a, b)
-    assert (exp[4] == 1).sum() > 0.9 * n_sites and (exp[2] > 0).sum() >= 3
+    assert (exp[4] == 1).sum() > 0.9 * n_sites and (exp[2] > 0).sum() >= 2
     # the same columns resident (sites_stage / sites_run: the heavy columns' beam search starts ahead of the shortcut kernels)
     dev.sites_stage(reads, dom)
     dev.sites_run()
