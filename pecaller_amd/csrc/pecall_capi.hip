@@ -746,8 +746,9 @@ static int pcs_chunk_kernels (pecall_dev * d, const PcsParams & P, int k, long o
     }
   if (nch <= 2 || !whole_table)
     {
-      // the shortcut kernel: a lane per sample up to 64 samples, two samples per lane up to 128 (round 4); beyond that its test alone,
-      // a chunk of 64 samples at a time: what it cannot write goes to the beam search's list (no second pass: too deep = listed)
+      // the shortcut kernel: a lane per sample up to 64 samples, two samples per lane up to 128 (round 4); beyond that a chunk of 64
+      // samples at a time, the unsettled samples' likelihoods parked in LDS for the small beam: what it cannot write goes to the beam
+      // search's list (no second pass with the whole table: too deep = listed)
 #define PCS_FAST(TAB_, NCH_, GRID_) hipLaunchKernelGGL (HIP_KERNEL_NAME (pcs_fast_kernel < TAB_, NCH_ >), dim3 ((unsigned) (GRID_)), dim3 (PCS_FAST_BLOCK_OF (TAB_)), \
     PCS_FAST_LDS_BYTES_OF2 (TAB_, NCH_), d->stream, P, d->d_sreads + off * N * PCS_NA, d->d_dom + off, d->d_chromy + off, m, d->d_call + off * N, d->d_post + off * N, \
     d->d_type + off, d->d_ac + off * PCS_NA, d->d_npass + off, d->d_den + off, slow, n_slow, deep_list, n_deep, next_piece, d->d_ta, \
@@ -783,7 +784,7 @@ static int pcs_chunk_kernels (pecall_dev * d, const PcsParams & P, int k, long o
 #undef PCS_FAST
     }
   else if (whole_table)
-    return 0;                   // (more than 128 samples: one form only)
+    return 0;                   // (more than 128 samples: no second pass, a column too deep for the table's head was listed for the beam search)
   // (the beam search's kernel takes the columns the shortcut kernel listed, a lane standing for a sample of each chunk of 64)
   PCCHK (d, hipEventRecord (d->ev_fast[k], d->stream));
   // (a chunk lists a few hundred columns for the beam search, a handful of them heavy -- milliseconds on one wave: behind each other

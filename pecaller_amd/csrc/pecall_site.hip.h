@@ -769,7 +769,7 @@ __device__ __forceinline__ void pcs_write_site (const PcsParams & P, long site, 
 // One wave per site.  Outputs are what the reference prints per row: call 0..13 or 14 (N), posterior,
 // site type (0 REF, 1 SNP, 2 DEL, 3 INS, 4 LOW, 5 MULTIALLELIC, 6 MESS; -1 = reference base not A/C/G/T, skipped),
 // Allele_Counts, passes.
-// NCH = chunks of 64 samples (1, 2 or 4): a lane stands for sample 64 c + lane of every chunk c
+// NCH = chunks of 64 samples (1, 2, 4 or 8): a lane stands for sample 64 c + lane of every chunk c
 extern __shared__ __align__ (16) uint8_t pcs_call_lds[];
 template < int NCH > __global__ __launch_bounds__ (64) void pcs_call_kernel (PcsParams P, const uint16_t * reads, const uint8_t * dom_of, const uint8_t * chrom_of,
                                                                           long n_sites, int8_t * call, double *post_out, int8_t * type_out,
@@ -2181,7 +2181,8 @@ void pcs_fast_kernel (PcsParams P, const uint16_t * reads, const uint8_t * dom_o
 // more reads that are not the reference base's -- and at least an eighth of their depth -- and lists the columns with `thr` or more of
 // them by that count (the list's PCS_BUCKETS parts, as the shortcut kernel files its own); flag[site] = 1 tells the shortcut kernel to
 // leave the column alone.  pcs_call_kernel is the whole caller and takes any column, so the choice only moves work: the listed columns'
-// beam searches start at once, beside the shortcut kernels of all chunks.  Up to 128 samples (the shortcut's range).
+// beam searches start at once, beside the shortcut kernels of all chunks.  (Any sample count; beyond 128 samples the threshold is
+// PECALL_HEAVY_MIN_WIDE: the small beam settles the columns whose variant reads are errors, and a beam search is expensive there.)
 __global__ __launch_bounds__ (256) void pcs_heavy_kernel (const uint16_t * reads, const uint8_t * dom_of, long n_sites, int N, int thr, unsigned *list,
                                                           unsigned *n_list, uint8_t * flag)
 {
