@@ -153,6 +153,27 @@ def test_gpu_site_caller_wide_small_beam(n, n_sites, var_frac):
 
 
 @pytest.mark.gpu
+def test_gpu_site_caller_wide_small_beam_haploid_and_chromosome_types():
+    """the wide shortcut kernel's small beam with HAPLOID set (6 genotypes, one allele per call) and with the column types that force it per
+    column (chrY / chrMT in guide mode: bit 4 of the type) or change the site filter (chrY), 200 samples, against the oracle"""
+    from pecaller_amd.pecall import PecallDev
+    reads, dom = _wide_reference_columns(200, 600, 7777, 0.02, 211)
+    rng = np.random.default_rng(12)
+    chrom = rng.integers(0, 4, len(dom)).astype(np.uint8)
+    chrom[chrom >= 2] |= 16
+    dev = PecallDev(0)
+    for kw in (dict(haploid=True), dict(chrom=chrom)):
+        got = dev.call_sites(reads, dom, **kw)
+        exp = oracle_py.call_sites(reads, dom, **kw)
+        assert np.array_equal(got[0], exp[0]), kw.keys()
+        assert np.max(np.abs(got[1] - exp[1])) <= 1e-6
+        for a, b in zip(got[2:], exp[2:]):
+            assert np.array_equal(a, b), kw.keys()
+        assert (exp[4] == 1).sum() > 0.9 * len(dom)
+    dev.close()
+
+
+@pytest.mark.gpu
 def test_gpu_site_caller_deep_columns():
     """columns with samples thousands of reads deep: the shortcut kernel then stages the whole ln n! table instead of its head
     (the head form leaves the deep columns on a list for a second launch with the whole table), and counts above 10,000 take the table's log formula; mixed with ordinary columns
