@@ -949,6 +949,26 @@ extern "C" int pecall_dev_sites_run (pecall_dev * d, int haploid, double thresho
               tot[b] += c[b];
         }
       fprintf (stderr, "[pecall] %ld columns, listed for the beam by unsettled samples <3 / <8 / <20 / more: %llu %llu %llu %llu\n", n_sites, tot[0], tot[1], tot[2], tot[3]);
+#ifdef PECALL_TIMING_PROBES
+      {
+        // the beam search's phase probes (pecall_site.hip.h): wave cycles summed over the run's launches
+        (void) hipDeviceSynchronize ();
+        unsigned long long pr[16], z[16] = { 0ull };
+        if (hipMemcpyFromSymbol (pr, HIP_SYMBOL (pcs_probe), sizeof pr) == hipSuccess)
+          {
+            static const char *nm[13] = { "set-up, likelihoods, re-estimation", "expand: duplicates", "expand: pricing", "expand: acceptance + rows", "clean: sort", "clean: end",
+              "below-floor samples", "posteriors + marginals", "before write", "write", "clean: cut + homozygous?", "clean: fallback's configuration", "clean: its sort" };
+            double tot_c = 0;
+            for (int i = 0; i < 13; i++)
+              tot_c += (double) pr[i];
+            fprintf (stderr, "[pcs_probe]");
+            for (int i = 0; i < 13; i++)
+              fprintf (stderr, " %s %.1f%%", nm[i], tot_c > 0 ? 100.0 * (double) pr[i] / tot_c : 0.0);
+            fprintf (stderr, " | total %.3f G wave-cycles\n", tot_c / 1e9);
+            (void) hipMemcpyToSymbol (HIP_SYMBOL (pcs_probe), z, sizeof z);
+          }
+      }
+#endif
       unsigned hc[PCS_BUCKETS] = { 0u, 0u, 0u, 0u };
       if (heavy && hipMemcpy (hc, (unsigned *) (d->d_heavy_ctr + 1), sizeof hc, hipMemcpyDeviceToHost) == hipSuccess)
         fprintf (stderr, "[pecall] started ahead of the shortcut kernels, by samples with variant reads <12 / <20 / <32 / more: %u %u %u %u\n", hc[0], hc[1], hc[2], hc[3]);

@@ -63,6 +63,22 @@ struct PcsPool
   int row;                      // bytes of a calls row: 64 per chunk of samples
 };
 
+// phase probes of the beam search (only in a library built with -DPECALL_TIMING_PROBES, tools/variants.sh): wave cycles per phase, summed
+// over the waves of a launch into pcs_probe[], printed by pecall_dev_sites_run under PECALL_LIST_STATS
+#ifdef PECALL_TIMING_PROBES
+__device__ unsigned long long pcs_probe[16];
+struct PcsProbe
+{
+  unsigned long long acc[16], last;
+};
+#define PCS_T(pp, i) do { const unsigned long long t_ = __builtin_readcyclecounter (); (pp).acc[i] += t_ - (pp).last; (pp).last = t_; } while (0)
+#else
+struct PcsProbe
+{
+};
+#define PCS_T(pp, i) do { } while (0)
+#endif
+
 template < int NCH > struct __align__ (16) PcsSmallPool
 {
   double like[PCS_SMALLCAP], prior[PCS_SMALLCAP], post[PCS_SMALLCAP];
@@ -277,6 +293,51 @@ template < int NCH > __device__ __forceinline__ void pcs_cfg_like (const PcsPool
   p.post[s] = l + p.prior[s];
 }
 
+// the same by the whole wave: lane = sample fetches its term (the slot's call of the sample -- a byte of a pool that may lie in HBM -- and the
+// likelihood it selects), then the terms are added in sample order as the reference adds them.  One lane walking the samples waited for a
+// trip to memory per sample: pcs_clean's homozygous fallback (a list without a homozygous configuration -- every cut of a variant column
+// with many carriers) was 86-91 % of the beam search's cycles at 256 and 512 samples and half of them at 64 (profiles/r04_ab_sweeps.txt).
+template < int NCH > __device__ __forceinline__ double pcs_cfg_like_wave (const PcsPool & p, int s, const PcsShared < NCH > &sh, const PcsMask < NCH > &deep, int N,
+                                                                          int lane)
+{
+  double term[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; c++)
+    {
+      const int i = 64 * c + lane;
+      term[c] = (i < N && ((deep.w[c] >> lane) & 1ull)) ? sh.like[i][p.calls[(size_t) s * p.row + i]] : 0.0;
+    }
+  // (sample order = chunk by chunk, the set bits of the chunk's mask in ascending order: a scalar bit scan and two v_readlane per sample --
+  // a loop over the sample number that selects the chunk's register and tests the chunk's mask per sample was ~60 instructions a sample)
+  double l = 0;
+#pragma unroll
+  for (int c = 0; c < NCH; c++)
+    {
+      const double tc = term[c];
+      unsigned long long m = deep.w[c];
+      while (m)
+        {
+          const int k = __ffsll ((long long) m) - 1;
+          m &= m - 1;
+          l += pcs_bcast (tc, k);
+        }
+    }
+  if (lane == 0)
+    {
+      p.like[s] = l;
+      p.post[s] = l + p.prior[s];
+    }
+  return l;                     // (the same in every lane)
+}
+
+// the likelihood of the configuration "every sample above the depth floor homozygous for allele a", a = 0 .. 3, once it has been summed in
+// a pass: it depends on the pass's likelihoods only, and pcs_clean's fallback asks for it after nearly every expansion of a variant column
+struct PcsHomCache
+{
+  double v[4];
+  unsigned have;
+};
+
 // stable sort of the list's first n positions by posterior, descending (qsort + sort_configs; glibc's merge sort is stable)
 __device__ __forceinline__ void pcs_sort (PcsPool & p, int n, int lane)
 {
@@ -300,9 +361,10 @@ __device__ __forceinline__ void pcs_sort (PcsPool & p, int n, int lane)
 
 // clean_config_probs, pecaller.c:2248-2344; returns the new list length
 template < int NCH > __device__ __forceinline__ int pcs_clean (PcsPool & p, int n, int ref, double ct, const PcsShared < NCH > &sh, const PcsMask < NCH > &deep,
-                                                              const PcsParams & P, int site_hap, int lane)
+                                                              const PcsParams & P, int site_hap, int lane, PcsProbe & pp, PcsHomCache & hc)
 {
   pcs_sort (p, n, lane);
+  PCS_T (pp, 4);
   int mx = min (PCS_MAXCFG, n);
   {
     const double p0 = p.post[p.ord[0]];
@@ -323,6 +385,7 @@ template < int NCH > __device__ __forceinline__ int pcs_clean (PcsPool & p, int 
       const int i = i0 + lane;
       found_hom = __any (i < mx && p.nall[p.ord[i < mx ? i : 0]] == 1);
     }
+  PCS_T (pp, 10);
   if (!found_hom)
     {
       const int s0 = p.ord[0];
@@ -335,17 +398,35 @@ template < int NCH > __device__ __forceinline__ int pcs_clean (PcsPool & p, int 
       const int s = n;          // slots 0 .. n-1 hold the list, slot n is free
       pcs_cfg_init (p, s, best_hom, deep, site_hap, lane);
       pcs_sync ();
+      double lh = 0.0;
+      if ((hc.have >> best_hom) & 1u)
+        {
+#pragma unroll
+          for (int a = 0; a < 4; a++)
+            lh = (a == best_hom) ? hc.v[a] : lh;
+        }
+      else
+        {
+          lh = pcs_cfg_like_wave (p, s, sh, deep, P.indiv, lane);
+#pragma unroll
+          for (int a = 0; a < 4; a++)
+            hc.v[a] = (a == best_hom) ? lh : hc.v[a];
+          hc.have |= 1u << best_hom;
+        }
       if (lane == 0)
         {
-          pcs_cfg_like (p, s, sh, deep, P.indiv);
-          p.post[s] = p.like[s];
+          p.like[s] = lh;
+          p.post[s] = lh;
           p.ord[mx] = (uint16_t) s;
         }
       pcs_sync ();
+      PCS_T (pp, 11);
       if (p.post[s] > p.post[p.ord[mx - 1]])
         pcs_sort (p, mx + 1, lane);
+      PCS_T (pp, 12);
       mx++;
     }
+  PCS_T (pp, 5);
   return mx;
 }
 
@@ -428,7 +509,8 @@ __device__ __forceinline__ int pcs_denovo_around (const PcsParams & P, const int
 // dupbuf: one byte per list position (LDS for short lists, HBM for long ones).  Returns the length of the list built in nw;
 // nw may be switched to `big_nw` (the wave's pool in HBM) when it outgrows LDS: *went_big is set.
 template < int NCH > __device__ int pcs_expand (const PcsPool & cur, PcsPool & nw, const PcsPool & big_nw, bool &went_big, int n, int who, int ref, double thres,
-                                                const PcsShared < NCH > &sh, uint8_t * dupbuf, int r4, int r5, int chrom, int site_hap, const PcsParams & P, int lane)
+                                                const PcsShared < NCH > &sh, uint8_t * dupbuf, int r4, int r5, int chrom, int site_hap, const PcsParams & P, int lane,
+                                                PcsProbe & pp)
 {
   const int G = P.max_gen, N = P.indiv;
   // ---- a configuration equal to an earlier one on every other sample is skipped (pecaller.c:2542-2558)
@@ -456,6 +538,7 @@ template < int NCH > __device__ int pcs_expand (const PcsPool & cur, PcsPool & n
       dupbuf[i] = (uint8_t) dup;
     }
   pcs_sync ();
+  PCS_T (pp, 1);
   double best_post = cur.post[cur.ord[0]], best_like = cur.like[cur.ord[0]];
   int newcount = 0;
   const long total = (long) n * G;
@@ -545,6 +628,7 @@ template < int NCH > __device__ int pcs_expand (const PcsPool & cur, PcsPool & n
       // best_like / best_post only grow, so a candidate that fails the first test against their values at the start of the
       // chunk fails it later too: only the others take part in the ordered replay
       unsigned long long m = __ballot (valid && ((templ + thres > best_post) || (templ + 0.01 > best_like)));
+      PCS_T (pp, 2);
       while (m)
         {
           const int k = __ffsll ((long long) m) - 1;
@@ -590,6 +674,7 @@ template < int NCH > __device__ int pcs_expand (const PcsPool & cur, PcsPool & n
             }
           newcount++;
         }
+      PCS_T (pp, 3);
     }
   pcs_sync ();
   return newcount;
@@ -785,6 +870,12 @@ template < int NCH > __global__ __launch_bounds__ (64) void pcs_call_kernel (Pcs
   pcs_pool_big (bigp[0], my, ROW);
   pcs_pool_big (bigp[1], my + PCS_BIG_BYTES_OF (ROW), ROW);
   uint8_t *big_dup = (uint8_t *) (my + 2 * PCS_BIG_BYTES_OF (ROW));
+  PcsProbe pp;
+#ifdef PECALL_TIMING_PROBES
+  for (int i_ = 0; i_ < 16; i_++)
+    pp.acc[i_] = 0ull;
+  pp.last = __builtin_readcyclecounter ();
+#endif
   // columns are handed out through a counter (the first grid-ful by block index): a column that needs the whole beam search
   // takes ~50 times as long as one settled by the shortcut below, so a fixed stride would leave most waves waiting for a few
   // (site_list: only the listed columns -- the ones pcs_fast_kernel could not settle)
@@ -910,6 +1001,11 @@ template < int NCH > __global__ __launch_bounds__ (64) void pcs_call_kernel (Pcs
       while (calls_changed && pass < 5)
         {
           pass++;
+          PcsHomCache hom_cache;        // (of this pass's likelihoods)
+          hom_cache.have = 0u;
+#pragma unroll
+          for (int a = 0; a < 4; a++)
+            hom_cache.v[a] = 0.0;
           // ---- Dirichlet means of the pass (pecaller.c:1354-1364)
           if (lane < G)
             {
@@ -1020,10 +1116,16 @@ template < int NCH > __global__ __launch_bounds__ (64) void pcs_call_kernel (Pcs
                 sh.sord[rank[c]] = (typename std::conditional < (NCH > 4), uint16_t, uint8_t >::type) (64 * c + lane);
           }
           pcs_sync ();
-          for (int i = lane; i < total; i += 64)
-            pcs_cfg_like (pool[ci], pool[ci].ord[i], sh, deep, N);
+          // (a pass starts from one configuration: the wave adds its samples' terms; a longer list a lane per configuration)
+          if (total <= 4)
+            for (int i = 0; i < total; i++)
+              pcs_cfg_like_wave (pool[ci], pool[ci].ord[i], sh, deep, N, lane);
+          else
+            for (int i = lane; i < total; i += 64)
+              pcs_cfg_like (pool[ci], pool[ci].ord[i], sh, deep, N);
           pcs_sync ();
-          total = pcs_clean (pool[ci], total, dom, ct, sh, deep, P, site_hap, lane);
+          PCS_T (pp, 0);
+          total = pcs_clean (pool[ci], total, dom, ct, sh, deep, P, site_hap, lane, pp, hom_cache);
           // ---- the settled samples at the head of the order, in one go.  While the list is the single all-`dom` configuration, a
           //      sample whose best genotype is `dom` by more than 2.31 nats leaves it that: pcs_expand prices the candidate `dom`
           //      first (templ = (like - l_dom) + l_dom, prior 0: it is kept and becomes the list), and every other candidate has
@@ -1070,10 +1172,10 @@ template < int NCH > __global__ __launch_bounds__ (64) void pcs_call_kernel (Pcs
                   bool went_big = big;
                   const int r4 = sh.reads[ind][4], r5 = sh.reads[ind][5];
                   const int cnt = pcs_expand (pool[ci], pool[ni], bigp[ni], went_big, total, ind, dom, ct, sh, (total <= PCS_SMALLCAP) ? sh.dup : big_dup,
-                                              r4, r5, chrom, site_hap, P, lane);
+                                              r4, r5, chrom, site_hap, P, lane, pp);
                   big = went_big;
                   ci = ni;
-                  total = pcs_clean (pool[ci], cnt, dom, ct, sh, deep, P, site_hap, lane);
+                  total = pcs_clean (pool[ci], cnt, dom, ct, sh, deep, P, site_hap, lane, pp, hom_cache);
                 }
               else
                 {
@@ -1090,6 +1192,7 @@ template < int NCH > __global__ __launch_bounds__ (64) void pcs_call_kernel (Pcs
                   pcs_sync ();
                 }
             }
+          PCS_T (pp, 6);
           // ---- posteriors of the configurations (pecaller.c:1423-1441): exp of the difference to the best, normalised
           const PcsPool & cp = pool[ci];
           {
@@ -1140,6 +1243,7 @@ template < int NCH > __global__ __launch_bounds__ (64) void pcs_call_kernel (Pcs
                   calls_changed = true;
               }
           calls_changed = __any (calls_changed);
+          PCS_T (pp, 7);
           if (N < 4 || pass == 5)
             calls_changed = false;
           if (calls_changed)
@@ -1293,9 +1397,17 @@ template < int NCH > __global__ __launch_bounds__ (64) void pcs_call_kernel (Pcs
           for (int c = 0; c < NCH; c++)
             initial_call[c] = final_call[c];
         }
+      PCS_T (pp, 8);
       pcs_write_site < NCH > (P, site, lane, dom, chrom, r, tot, average_depth, final_call, final_p, pass, call, post_out, type_out, allele_count, n_pass, denovo_out);
       pcs_sync ();
+      PCS_T (pp, 9);
     }
+#ifdef PECALL_TIMING_PROBES
+  if (lane == 0)
+    for (int i_ = 0; i_ < 16; i_++)
+      if (pp.acc[i_])
+        atomicAdd (&pcs_probe[i_], pp.acc[i_]);
+#endif
 }
 
 // ---- The columns with a few unsettled samples, without the pools.  In a column of BASELINE config 4 (64 samples, 30x) one or two
@@ -1437,9 +1549,26 @@ template < int NCH, class STAGE > __device__ bool pcs_mini_core (const PcsParams
   // ---- fill_config_like of the all-reference configuration (pecaller.c:2347-2360): the deep samples' likelihoods of `dom`, in
   //      sample order; then the settled samples' expansions, each of which leaves (L - l) + l
   double L = 0.0;
-  for (int i = 0; i < N; i++)
-    if ((pcs_chunk_of < NCH > (deep_m, i) >> (i & 63)) & 1ull)
-      L += pcs_bcast (pcs_chunk_of < NCH > (lk_dom, i), i & 63);
+  if constexpr (NCH > 2)
+    {
+      // (chunk by chunk, the set bits of the chunk's mask in ascending order: the same order without a register select per sample)
+#pragma unroll
+      for (int c = 0; c < NCH; c++)
+        {
+          const double tc = lk_dom[c];
+          unsigned long long m = deep_m[c];
+          while (m)
+            {
+              const int k = __ffsll ((long long) m) - 1;
+              m &= m - 1;
+              L += pcs_bcast (tc, k);
+            }
+        }
+    }
+  else
+    for (int i = 0; i < N; i++)
+      if ((pcs_chunk_of < NCH > (deep_m, i) >> (i & 63)) & 1ull)
+        L += pcs_bcast (pcs_chunk_of < NCH > (lk_dom, i), i & 63);
   for (int k = 0; k < n_set; k++)
     {
       const int who = sample_at (k);
