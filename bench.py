@@ -757,7 +757,7 @@ def pecaller_leg(a):
         got = []
         while time.time() < stop_at and (k + 1) * per <= n:
             s = slice(k * per, (k + 1) * per)
-            got.append((s, oracle_py.call_sites(reads[s], dom[s])))
+            got.append((s, oracle_py.call_sites(reads[s], dom[s], threads=1)))
             k += nt
         return got
     t0 = time.time()

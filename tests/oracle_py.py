@@ -184,10 +184,13 @@ def kid_lists(dad, mom, order=None):
     return off, np.array([x for k in kids for x in k] + [0], np.int32)
 
 
-def call_sites(reads, dom, threshold=0.95, theta=0.001, haploid=False, chrom=None, ped=None):
+def call_sites(reads, dom, threshold=0.95, theta=0.001, haploid=False, chrom=None, ped=None, threads=None):
     """the per-site caller oracle (oracle/pecall_site_oracle.c): reads[n_sites][indiv][6], dom[n_sites] in 0..3 (else skipped),
     chrom[n_sites] 0 autosome / 1 X / 2 Y / 3 MT, ped = dict(dad, mom, sex, order, denovo_rate) or None
-    -> call[n_sites][indiv] (0..13, 14 = N), p, site type, allele counts, passes; call_sites.denovo = d_count per site"""
+    -> call[n_sites][indiv] (0..13, 14 = N), p, site type, allele counts, passes; call_sites.denovo = d_count per site.
+    Columns are independent: blocks of them go to `threads` callers side by side (default: up to 8, one per CPU; a variant column of a
+    few hundred samples costs the oracle seconds), each with its own handle, writing its rows of the shared result arrays."""
+    import threading
     L = pecall_lib()
     reads = np.ascontiguousarray(reads, np.uint16)
     dom = np.ascontiguousarray(dom, np.uint8)
@@ -199,17 +202,48 @@ def call_sites(reads, dom, threshold=0.95, theta=0.001, haploid=False, chrom=Non
     ac = np.zeros((n_sites, 6), np.int32)
     npass = np.zeros(n_sites, np.int8)
     den = np.zeros(n_sites, np.int32)
-    h = L.ora_caller_create(indiv, int(haploid), float(threshold), float(theta))
-    try:
-        if ped is not None:
-            dad = np.ascontiguousarray(ped["dad"], np.int32)
-            mom = np.ascontiguousarray(ped["mom"], np.int32)
-            sex = np.ascontiguousarray(ped["sex"], np.int32)
-            off, lst = kid_lists(dad, mom, ped.get("order"))
-            L.ora_caller_set_ped(h, _p(dad), _p(mom), _p(sex), _p(off), _p(lst), float(ped["denovo_rate"]))
-        L.ora_call_sites(h, _p(reads), _p(dom), _p(cy), n_sites, _p(call), _p(p), _p(typ), _p(ac), _p(npass), _p(den))
-        call_sites.max_list = L.ora_caller_max_list(h)      # longest configuration list seen (coverage statistic)
-        call_sites.denovo = den
-    finally:
-        L.ora_caller_destroy(h)
+    if ped is not None:
+        dad = np.ascontiguousarray(ped["dad"], np.int32)
+        mom = np.ascontiguousarray(ped["mom"], np.int32)
+        sex = np.ascontiguousarray(ped["sex"], np.int32)
+        off, lst = kid_lists(dad, mom, ped.get("order"))
+    block = 8 if indiv > 64 else 64
+    blocks = iter(range(0, n_sites, block))
+    lock = threading.Lock()
+    max_list = [0]
+    errors = []
+
+    def worker():
+        h = L.ora_caller_create(indiv, int(haploid), float(threshold), float(theta))
+        try:
+            if ped is not None:
+                L.ora_caller_set_ped(h, _p(dad), _p(mom), _p(sex), _p(off), _p(lst), float(ped["denovo_rate"]))
+            while True:
+                with lock:
+                    a = next(blocks, None)
+                if a is None:
+                    break
+                b = min(a + block, n_sites)
+                L.ora_call_sites(h, _p(reads[a:b]), _p(dom[a:b]), _p(cy[a:b]), b - a, _p(call[a:b]), _p(p[a:b]), _p(typ[a:b]), _p(ac[a:b]), _p(npass[a:b]),
+                                 _p(den[a:b]))
+            with lock:
+                max_list[0] = max(max_list[0], L.ora_caller_max_list(h))      # longest configuration list seen (coverage statistic)
+        except Exception as e:          # (surfaced by the caller: a thread's exception would otherwise be lost)
+            errors.append(e)
+        finally:
+            L.ora_caller_destroy(h)
+
+    nt = threads if threads else max(1, min(8, os.cpu_count() or 1, (n_sites + block - 1) // block))
+    if nt <= 1:
+        worker()
+    else:
+        ts = [threading.Thread(target=worker) for _ in range(nt)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+    if errors:
+        raise errors[0]
+    call_sites.max_list = max_list[0]
+    call_sites.denovo = den
     return call, p, typ, ac, npass
