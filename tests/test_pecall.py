@@ -92,3 +92,38 @@ def test_gpu_64_samples_30x_and_deep_counts():
         assert np.array_equal(best, ob)
         assert np.abs(like - ol).max() <= 1e-6 and np.abs(margin - om).max() <= 1e-6
     dev.close()
+
+
+def test_site_oracle_threads_do_not_change_results():
+    """tests/oracle_py.call_sites hands blocks of columns to several callers side by side (columns are independent): the same arrays as
+    one caller over all of them, with a pedigree as well (its de-novo counts travel per column)"""
+    rng = np.random.default_rng(4)
+    n, n_sites = 70, 300
+    dom = rng.integers(0, 4, n_sites).astype(np.uint8)
+    dom[::41] = 14
+    reads = np.zeros((n_sites, n, 6), np.int64)
+    idx = np.arange(n_sites)
+    is_var = rng.random(n_sites) < 0.2
+    alt = rng.integers(0, 6, n_sites)
+    for i in range(n):
+        d = rng.poisson(25, n_sites)
+        dose = np.where(is_var, rng.binomial(2, 0.3, n_sites), 0)
+        e = rng.binomial(d, 0.004)
+        ar = rng.binomial(d - e, dose / 2.0)
+        reads[idx, i, np.where(dom < 4, dom, 0)] += d - e - ar
+        reads[idx, i, alt] += ar
+        reads[idx, i, rng.integers(0, 4, n_sites)] += e
+    reads = reads.astype(np.uint16)
+    dad = np.full(n, -1, np.int32)
+    mom = np.full(n, -1, np.int32)
+    sex = (1 + (np.arange(n) % 2)).astype(np.int32)
+    for c in range(0, 18, 3):
+        dad[c], mom[c] = c + 1, c + 2
+        sex[c + 1], sex[c + 2] = 1, 2
+    for ped in (None, dict(dad=dad, mom=mom, sex=sex, denovo_rate=1e-5)):
+        one = oracle_py.call_sites(reads, dom, ped=ped, threads=1)
+        den1 = oracle_py.call_sites.denovo.copy()
+        many = oracle_py.call_sites(reads, dom, ped=ped, threads=5)
+        assert all(np.array_equal(a, b) for a, b in zip(one, many))
+        assert np.array_equal(den1, oracle_py.call_sites.denovo)
+    assert (one[2] > 0).sum() > 20
